@@ -1,0 +1,126 @@
+"""Pin the CPU oracle (oracle/cc_oracle.py) to the reference.
+
+Two anchors: (1) golden vectors produced by the reference itself
+(tests/golden/make_golden.py); (2) the reference's own analytic known-answer
+tests (reference tests/test_numerical_validation.py:18-97, 319-402), restated
+against the oracle's quadrature tables.  CPU only.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import cc_oracle as O
+from tests import _util as U
+
+TOL = 2e-5      # oracle (numpy sgemm) vs reference (ATen sgemm): summation-order noise only
+
+
+def test_cc_tables_bit_exact():
+    G = U.load("g1_cc_tables")
+    for n in (5, 7, 20, 30, 50, 51, 100, 200):
+        w, s = O.cc_tables(n)
+        assert np.array_equal(w, G[f"w{n}"].reshape(-1)), n
+        assert np.array_equal(s, G[f"s{n}"].reshape(-1)), n
+        assert abs(float(w.astype(np.float64).sum()) - 2.0) < 1e-5
+
+
+@pytest.mark.parametrize("name", U.g2_names())
+def test_integrate_matches_reference(name):
+    G = U.load(name)
+    net = U.net_from_g2(G)
+    x0, x, h, n = G["x0"], G["x"], G["h"], int(G["n"])
+    assert U.rel_err(O.integrand(net, x, h), G["f_x"]) < TOL
+    assert U.rel_err(O.integrand(net, x0, h), G["f_x0"]) < TOL
+    assert U.rel_err(O.integrate_parallel(net, x0, x, h, n), G["F_par"]) < TOL
+    assert U.rel_err(O.integrate_sequential(net, x0, x, h, n), G["F_seq"]) < TOL
+    assert U.rel_err(O.integrate_parallel(net, x0, x, h, n, inv_f=True), G["F_inv"]) < TOL
+    # the autograd.Function forward is the same quadrature
+    assert U.rel_err(G["Fapply_par"], G["F_par"]) < 1e-6
+
+
+@pytest.mark.parametrize("name", U.g2_names())
+def test_backward_matches_reference(name):
+    G = U.load(name)
+    net = U.net_from_g2(G)
+    dx0, dx, dh, _, _, flat = O.integrate_backward(net, G["x0"], G["x"], G["h"], int(G["n"]), G["g"])
+    for tag in ("par", "seq"):
+        assert U.rel_err(dx0, G[f"dx0_{tag}"]) < TOL
+        assert U.rel_err(dx, G[f"dx_{tag}"]) < TOL
+        assert U.scaled_err(dh, G[f"dh_{tag}"]) < 5e-5
+        assert U.scaled_err(flat, G[f"dtheta_{tag}"]) < 5e-5
+
+
+@pytest.mark.parametrize("name", U.g2_names()[:4])
+def test_fp64_oracle_agrees(name):
+    """fp32 oracle vs the same algorithm in fp64: the noise floor the 1e-4 tolerance sits on."""
+    G = U.load(name)
+    net32, net64 = U.net_from_g2(G), U.net_from_g2(G, np.float64)
+    a = O.integrate_parallel(net32, G["x0"], G["x"], G["h"], int(G["n"]))
+    b = O.integrate_parallel(net64, G["x0"].astype(np.float64), G["x"].astype(np.float64),
+                             G["h"].astype(np.float64), int(G["n"]))
+    assert U.rel_err(a, b) < 2e-5
+
+
+@pytest.mark.parametrize("name", U.g4_names())
+def test_flow_matches_reference(name):
+    G = U.load(name)
+    blocks = U.blocks_from_g4(G)
+    ctx = G.get("context")
+    n, solver = int(G["n"]), str(G["solver"])
+    ll, z = O.flow_compute_ll(blocks, G["x"], n, solver, ctx)
+    for mode in ("train", "eval"):
+        assert U.rel_err(ll, G[f"ll_{mode}"]) < 1e-4
+        assert U.rel_err(z, G[f"z_{mode}"]) < 5e-5
+        assert U.rel_err(O.flow_forward(blocks, G["x"], n, solver, ctx), G[f"fwd_{mode}"]) < 5e-5
+        zb, lj = O.flow_log_jac(blocks, G["x"], n, solver, ctx)
+        assert U.rel_err(zb, G[f"z_bis_{mode}"]) < 5e-5
+        assert U.rel_err(lj, G[f"log_jac_bis_{mode}"]) < 5e-5
+        assert U.rel_err(lj, G[f"log_jac_{mode}"]) < 5e-5
+
+
+def test_made_masks_match_reference():
+    for name in U.g4_names():
+        G = U.load(name)
+        sd = U.state_dict_of(G)
+        d, cond = int(G["d"]), int(G["cond_in"])
+        he = [int(v) for v in G["hidden_embedding"]]
+        masks = O.made_masks(d + cond, he, (d + cond) * int(G["E"]))
+        for l, mk in enumerate(masks):
+            assert np.array_equal(mk.astype(np.float32), sd[f"Flow0.net.made.net.{2 * l}.mask"]), (name, l)
+
+
+@pytest.mark.parametrize("n", [50, 100])
+def test_monotonic_matches_reference(n):
+    G = U.load(f"g5_monotonic_n{n}")
+    sd = U.state_dict_of(G)
+    iW, ib, _ = U._seq(sd, "integrand.net.", np.float32)
+    cW, cb, _ = U._seq(sd, "net.", np.float32)
+    y = O.monotonic_forward(O.Net(iW, ib, O.RELU, O.ELU1), cW, cb, G["x"], G["h"], n)
+    assert U.rel_err(y, G["y"]) < TOL
+
+
+# ---- the reference's own analytic known-answer tests, on the oracle's tables ----------
+def _quad(fn, a, b, n):
+    w, s = O.cc_tables(n, np.float32)
+    a, b = np.float32(a), np.float32(b)
+    t = a + (b - a) * (s + np.float32(1)) / np.float32(2)
+    return float((fn(t) * w).sum() * (b - a) / np.float32(2))
+
+
+def test_kat_one_plus_x2_converges():
+    # reference tests/test_numerical_validation.py:18-97: int_0^2 (1+x^2) = 14/3, error@200 < 1e-4
+    errs = [abs(_quad(lambda t: 1 + t ** 2, 0., 2., n) - 14. / 3.) for n in (5, 10, 20, 50, 100, 200)]
+    assert errs[-1] < 1e-4
+
+
+@pytest.mark.parametrize("fn,a,b,true", [
+    (lambda t: np.full_like(t, 2.0), 0., 3., 6.0),
+    (lambda t: t, 0., 2., 2.0),
+    (lambda t: t ** 2, 1., 3., 26. / 3.),
+    (np.exp, 0., 1., math.e - 1.),
+])
+def test_kat_various_functions(fn, a, b, true):
+    # reference tests/test_numerical_validation.py:319-402: error < 1e-3 at 100 steps
+    for n in (20, 50, 100):
+        assert abs(_quad(fn, a, b, n) - true) < 1e-3
