@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""Headline benchmark: UMNN-MAF log-density evals/s (BASELINE.json metric) on MI355X.
+
+  python bench.py [--gpus N --steps K --warmup W --workload bsds300|power|toy]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = one ``UMNNMAFFlow.compute_ll`` pass (MADE conditioner + fused HIP quadrature, all flow blocks) over one
+synthetic batch already resident in HBM.  Default workload: BASELINE config C3 -- BSDS300-shaped (d=63), 8192 rows
+per GPU (65536 rows sharded over 8 GPUs), n_steps=100, 5 blocks, MADE [512,512], E=30, integrand 31-50^4-1, fp32.
+Weak scaling: the per-GPU shard is fixed; no collective on the forward path.  One JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: nb_flow, d, hidden_embedding, hidden_derivative, E, n_steps, rows per GPU
+    "bsds300": dict(nb_flow=5, d=63, he=[512, 512], hd=[50] * 4, E=30, n=100, rows=8192,
+                    desc="C3 BSDS300-shaped UMNN-MAF compute_ll: d=63, 8192 rows/GPU (65536 over 8), n_steps=100"),
+    "power": dict(nb_flow=5, d=6, he=[512, 512], hd=[50] * 4, E=30, n=100, rows=10000,
+                  desc="C2 POWER-shaped UMNN-MAF compute_ll: d=6, batch 10000, n_steps=100"),
+    "toy": dict(nb_flow=1, d=2, he=[100] * 4, hd=[100] * 4, E=10, n=50, rows=4096,
+                desc="C1 2-moons UMNN-MAF compute_ll: d=2, batch 4096, n_steps=50"),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def build_model(cfg, device, seed=0):
+    import umnn_amd
+    torch.manual_seed(seed)
+    m = umnn_amd.UMNNMAFFlow(nb_flow=cfg["nb_flow"], nb_in=cfg["d"], hidden_derivative=cfg["hd"],
+                             hidden_embedding=cfg["he"], embedding_s=cfg["E"], nb_steps=cfg["n"],
+                             solver="CCParallel")
+    return m.to(device).eval()
+
+
+def cpu_baseline(cfg, model, budget_s=20.0):
+    """Time the torch port of the reference's ParallelNeuralIntegral-based compute_ll on the host cores, on a
+    bounded sample of the same workload (chunks of 128 rows; the un-chunked node axis would need terabytes)."""
+    from oracle import torch_port as TP
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    blocks = TP.blocks_from_state_dict(sd, cfg["nb_flow"])
+    chunk = 128 if cfg["d"] > 8 else 1024
+    torch.manual_seed(123)
+    x = torch.randn(chunk, cfg["d"])
+    with torch.no_grad():
+        TP.flow_compute_ll(blocks, x, cfg["n"])                 # warm-up
+        t0 = time.perf_counter()
+        TP.flow_compute_ll(blocks, x, cfg["n"])
+        one = time.perf_counter() - t0
+        reps = max(1, min(8, int(budget_s / max(one, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            TP.flow_compute_ll(blocks, x, cfg["n"])
+        dt = time.perf_counter() - t0
+    return {"value": chunk * reps / dt, "unit": "evals/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x {chunk}-row chunks of the same flow through oracle/torch_port.py "
+                      f"(reference ParallelNeuralIntegral algorithm, torch CPU, {threads} threads)",
+            "integrals_per_s": chunk * reps * cfg["d"] * cfg["nb_flow"] / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="bsds300", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from umnn_amd import _lib, sharding
+    import torch.distributed as dist
+    rank, world, device = sharding.init_from_env()
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs a GPU"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    cfg = dict(WORKLOADS[args.workload])
+    if args.rows:
+        cfg["rows"] = args.rows
+    lib = _lib.lib()
+
+    model = build_model(cfg, device)
+    torch.manual_seed(1000 + rank)                      # every rank owns a different shard of the global batch
+    x = torch.randn(cfg["rows"], cfg["d"], device=device)
+
+    def step():
+        with torch.no_grad():
+            return model.compute_ll(x)
+
+    for _ in range(args.warmup):
+        step()
+    lib.umnn_profile_enable(1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ll, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_n, k_fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+    lib.umnn_profile_read(ctypes.byref(k_ms), ctypes.byref(k_n), ctypes.byref(k_fl))
+    lib.umnn_profile_enable(0)
+    assert torch.isfinite(ll).all()
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        value = world * cfg["rows"] * args.steps / elapsed
+        avg_kernel_ms = k_ms.value / max(1, k_n.value)
+        achieved = k_fl.value / max(k_ms.value, 1e-9) / 1e9            # TFLOP/s over the quadrature launches
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "umnn_maf_log_density_evals_per_s", "value": value, "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["desc"], "rows_per_gpu": cfg["rows"], "dim": cfg["d"], "n_steps": cfg["n"],
+                       "nb_flow": cfg["nb_flow"], "embedding": cfg["E"], "integrand": cfg["hd"], "made": cfg["he"],
+                       "sharding": f"batch x{world}, no forward collective",
+                       "integrals_per_s": value * cfg["d"] * cfg["nb_flow"]},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "kernel": lib.umnn_last_kernel_name().decode(), "avg_launch_ms": avg_kernel_ms,
+                         "launches": k_n.value,
+                         "flops_per_launch": k_fl.value / max(1, k_n.value),
+                         "kernel_share_of_step": k_ms.value / (1e3 * elapsed)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, model)
+            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+/*
+ * umnn_cc.h -- C ABI of the MI355X (gfx950) Clenshaw-Curtis neural-integration library.
+ *
+ * The reference (AWehenkel/UMNN, pure Python) has no FFI; its operator boundary for this
+ * path is the Python call
+ *
+ *     ParallelNeuralIntegral.apply(x0, x, integrand, flat_params, h, nb_steps, inv_f)
+ *         models/UMNN/ParallelNeuralIntegral.py:97-123   (forward :100-108, backward :110-123)
+ *     NeuralIntegral.apply(x0, x, integrand, flat_params, h, nb_steps)
+ *         models/UMNN/NeuralIntegral.py:78-99
+ *     integrate(x0, nb_steps, step_sizes, integrand, h, compute_grad, x_tot, inv_f, cc_weights, steps)
+ *         models/UMNN/ParallelNeuralIntegral.py:37-80,  models/UMNN/NeuralIntegral.py:37-66
+ *     compute_cc_weights(nb_steps)
+ *         models/UMNN/ParallelNeuralIntegral.py:14-34
+ *
+ * and, one level up, the per-block flow arithmetic of models/UMNN/UMNNMAF.py:76-139
+ * (z = exp(scaling) * (integral + h[:,0,:]),  log_jac = log(f(x;h) + 1e-10) + scaling).
+ *
+ * Each entry point below replaces one of those calls when the integrand is an MLP
+ * (models/UMNN/UMNNMAF.py:235-284 IntegrandNetwork, models/UMNN/MonotonicNN.py:12-27
+ * IntegrandNN).  Plain pointers and sizes only: every pointer is a DEVICE pointer to fp32
+ * data owned by the caller (PyTorch's caching allocator in the shipped host code) unless the
+ * name ends in _host.  Work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
+ * the default stream) and the call returns without synchronising.
+ *
+ * Layouts (identical to the reference tensors, contiguous, row-major):
+ *     x0, x, F, f_x, f_x0, g, dx, dx0, z, log_jac   [B, d]
+ *     h, dh                                         [B, E*d], element (b, e*d + i)  (UMNNMAF.py:279-281)
+ *     W[l]  [widths[l+1], widths[l]]   b[l]  [widths[l+1]]     (torch.nn.Linear layout)
+ *     cc_w, cc_s                                    [nb_steps+1]
+ *
+ * Return value: 0 on success, otherwise a negative UMNN_E* code or a positive hipError_t;
+ * umnn_last_error() gives the message (thread-local).
+ */
+#ifndef UMNN_CC_H
+#define UMNN_CC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UMNN_MAX_LINEAR 8            /* Linear layers in the integrand MLP (hidden layers + 1) */
+#define UMNN_MAX_HIDDEN_WIDTH 127    /* widest hidden layer the LDS-resident kernels accept */
+
+#define UMNN_ACT_LEAKY_RELU 0        /* nn.LeakyReLU(0.01): IntegrandNetwork, UMNNMAF.py:247 */
+#define UMNN_ACT_RELU 1              /* nn.ReLU: IntegrandNN, MonotonicNN.py:20 */
+#define UMNN_OUT_ELU_PLUS_ONE 0      /* ELU(.)+1: ELUPlus UMNNMAF.py:11-16 / MonotonicNN.py:23,27 */
+#define UMNN_OUT_SIGMOID 1           /* nn.Sigmoid: dict_act_func UMNNMAF.py:19 */
+
+#define UMNN_EINVAL (-1)             /* bad argument (message says which) */
+#define UMNN_EUNSUPPORTED (-2)       /* shape outside what the kernels cover */
+#define UMNN_ENODEVICE (-3)          /* no gfx950 device / kernel image not loadable */
+
+typedef struct umnn_mlp {
+    int n_linear;                         /* number of Linear layers */
+    int widths[UMNN_MAX_LINEAR + 1];      /* [1+E, H1, ..., HL, 1] */
+    const float* W[UMNN_MAX_LINEAR];      /* device pointers */
+    const float* b[UMNN_MAX_LINEAR];
+    int hidden_act;                       /* UMNN_ACT_* */
+    int out_act;                          /* UMNN_OUT_* */
+} umnn_mlp;
+
+/* Replaces integrate(..., compute_grad=False) -- ParallelNeuralIntegral.py:49-65 and
+ * NeuralIntegral.py:53-66 (both solvers are the same arithmetic; the kernel never
+ * materialises the node axis).  Quadrature node 0 is x and node n is x0, so the same pass
+ * also yields f(x;h) and f(x0;h) (what backward's Leibniz terms :117-118 and
+ * UMNNMAF.compute_log_jac :138 re-evaluate in the reference).
+ *   x0     may be NULL (= zeros, the only value UMNNMAF/MonotonicNN ever pass)
+ *   inv_f  != 0 integrates 1/f (ParallelNeuralIntegral.py:58-59)
+ *   f_x, f_x0 may be NULL. */
+int umnn_cc_forward(const umnn_mlp* net, const float* x0, const float* x, const float* h,
+                    const float* cc_w, const float* cc_s, int nb_steps,
+                    long long B, int d, int E, int inv_f,
+                    float* F, float* f_x, float* f_x0, void* stream);
+
+/* Replaces one UMNNMAF block's arithmetic after the conditioner (UMNNMAF.py:80-83,134,138-139):
+ *   z = exp(scaling_i) * (int_0^x f + h[b, 0*d+i]),  log_jac = log(f(x;h) + 1e-10) + scaling_i.
+ * f_x / f_x0 (nullable) are also written so the autograd wrapper need not recompute them. */
+int umnn_flow_block_forward(const umnn_mlp* net, const float* x, const float* h, const float* scaling,
+                            const float* cc_w, const float* cc_s, int nb_steps,
+                            long long B, int d, int E,
+                            float* z, float* log_jac, float* f_x, float* f_x0, void* stream);
+
+/* Replaces integrate(..., compute_grad=True) + the Leibniz terms -- ParallelNeuralIntegral.py:66-94,
+ * 110-123 (NeuralIntegral.py:47-58,69-75,90-99).  g is grad_output [B,d] (cotangent of F).
+ *   g_fx    nullable [B,d]: cotangent of the f_x output of umnn_cc_forward.  The reference gets this
+ *           term from ordinary autograd through `self.net.forward(x)` (UMNNMAF.py:138,143,148); here it
+ *           is one more VJP at quadrature node 0, including d f/d x.
+ *   dtheta  [n_params] in integrand.parameters() order (W0,b0,W1,b1,...); OVERWRITTEN
+ *   dh      [B,E*d]; dx, dx0 [B,d]  (dx = f(x;h)*g [+ g_fx * df/dx], dx0 = -f(x0;h)*g); each nullable.
+ *   workspace: device scratch of at least umnn_cc_backward_workspace_bytes() bytes. */
+int umnn_cc_backward(const umnn_mlp* net, const float* x0, const float* x, const float* h,
+                     const float* g, const float* g_fx,
+                     const float* cc_w, const float* cc_s, int nb_steps,
+                     long long B, int d, int E,
+                     float* dx0, float* dx, float* dh, float* dtheta,
+                     void* workspace, long long workspace_bytes, void* stream);
+long long umnn_cc_backward_workspace_bytes(const umnn_mlp* net, long long B, int d, int E);
+
+/* Replaces compute_cc_weights -- ParallelNeuralIntegral.py:14-34: writes nb_steps+1 fp32
+ * weights and nodes into HOST buffers (float64 arithmetic, cast at the end). */
+int umnn_cc_tables_host(int nb_steps, float* w_host, float* s_host);
+
+/* Algorithmic FLOPs of one forward integral, SURVEY 8(d):
+ *   2*[(n+1)*(H1 + sum H_l*H_{l+1} + H_L) + E*H1]. */
+double umnn_cc_forward_flops_per_integral(const umnn_mlp* net, int nb_steps);
+
+/* Introspection used by tests, the smoke test and the bench. */
+const char* umnn_last_error(void);
+int umnn_version(void);
+long long umnn_launch_count(void);          /* HIP kernels launched by this process so far */
+const char* umnn_last_kernel_name(void);    /* variant picked by the last forward/backward */
+/* Times `reps` back-to-back umnn_cc_forward launches with hipEvents recorded on `stream`
+ * (the stream the kernels run on) and returns the average milliseconds per launch in *ms. */
+int umnn_cc_forward_timed(const umnn_mlp* net, const float* x0, const float* x, const float* h,
+                          const float* cc_w, const float* cc_s, int nb_steps,
+                          long long B, int d, int E, float* F, float* f_x, float* f_x0,
+                          int reps, float* ms, void* stream);
+
+/* Per-launch timing: while enabled, every forward/backward launch is bracketed by hipEvents recorded on its own
+ * launch stream.  umnn_profile_read synchronises on them and returns the summed kernel milliseconds, the number of
+ * launches and the summed algorithmic FLOPs (forward launches only carry FLOPs).  enable(0/1) clears the records. */
+int umnn_profile_enable(int on);
+int umnn_profile_read(double* total_ms, long long* launches, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMNN_CC_H */

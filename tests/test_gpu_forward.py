@@ -1,0 +1,221 @@
+"""Parity of the HIP forward path (through the C ABI) against the CPU oracle and the reference's golden vectors.
+
+Tolerance (SURVEY 8d / north_star): max |d|/max(|ref|,1) <= 1e-4 on F and f(x); log-det compared as
+|d log f| <= 1e-4 * max(1, |log f|).  Measured noise is ~1e-6 (fp32 MFMA is an exact fmaf chain; the only
+differences are summation order and v_exp_f32).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cc_oracle as O
+from tests import _util as U
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def build_integrand(G, dev):
+    from umnn_amd import IntegrandNetwork
+    hid = [int(v) for v in G["hidden"]]
+    net = IntegrandNetwork(int(G["d"]), 1 + int(G["E"]), hid, 1, act_func=str(G["act"]))
+    lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        for l, m in enumerate(lin):
+            m.weight.copy_(torch.from_numpy(G[f"W{l}"]))
+            m.bias.copy_(torch.from_numpy(G[f"b{l}"]))
+    return net.to(dev)
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("name", U.g2_names())
+def test_forward_matches_golden_and_oracle(name, dev):
+    from umnn_amd import integral as I, _lib
+    from umnn_amd.nets import mlp_spec
+    G = U.load(name)
+    net = build_integrand(G, dev)
+    spec = mlp_spec(net)
+    assert spec is not None
+    n = int(G["n"])
+    before = _lib.lib().umnn_launch_count()
+    F, fx, fx0 = I.hip_forward(spec, t(G["x0"], dev), t(G["x"], dev), t(G["h"], dev), n)
+    torch.cuda.synchronize()
+    assert _lib.lib().umnn_launch_count() == before + 1
+    assert U.rel_err(F.cpu().numpy(), G["F_par"]) < TOL
+    assert U.rel_err(F.cpu().numpy(), G["F_seq"]) < TOL
+    assert U.rel_err(fx.cpu().numpy(), G["f_x"]) < TOL
+    assert U.rel_err(fx0.cpu().numpy(), G["f_x0"]) < TOL
+    lf, lref = np.log(fx.cpu().numpy() + 1e-10), np.log(G["f_x"] + 1e-10)
+    assert np.all(np.abs(lf - lref) <= TOL * np.maximum(1.0, np.abs(lref)))
+    Finv, _, _ = I.hip_forward(spec, t(G["x0"], dev), t(G["x"], dev), t(G["h"], dev), n, inv_f=True)
+    assert U.rel_err(Finv.cpu().numpy(), G["F_inv"]) < TOL
+    # fp64 oracle: how far from the exact quadrature of the same weights
+    net64 = U.net_from_g2(G, np.float64)
+    F64 = O.integrate_parallel(net64, G["x0"].astype(np.float64), G["x"].astype(np.float64),
+                               G["h"].astype(np.float64), n)
+    assert U.rel_err(F.cpu().numpy(), F64) < 2e-5
+
+
+@pytest.mark.parametrize("P,NS", [(1, 1), (2, 1), (1, 2), (1, 4), (2, 4), (2, 2)])
+@pytest.mark.parametrize("name", ["g2_power_d6_w2", "g2_toy_d2_w2", "g2_mnist_mixed_d8", "g2_odd_n_d3"])
+def test_every_kernel_variant_agrees(name, P, NS, dev, monkeypatch):
+    """Point tiles per wave (P) and node-split factor (NS) are launch heuristics: all must give the same answer."""
+    from umnn_amd import integral as I, _lib
+    from umnn_amd.nets import mlp_spec
+    monkeypatch.setenv("UMNN_FWD_P", str(P))
+    monkeypatch.setenv("UMNN_FWD_NS", str(NS))
+    G = U.load(name)
+    net = build_integrand(G, dev)
+    F, fx, fx0 = I.hip_forward(mlp_spec(net), t(G["x0"], dev), t(G["x"], dev), t(G["h"], dev), int(G["n"]))
+    assert f"P={P}" in _lib.lib().umnn_last_kernel_name().decode()
+    assert U.rel_err(F.cpu().numpy(), G["F_par"]) < TOL
+    assert U.rel_err(fx.cpu().numpy(), G["f_x"]) < TOL
+    assert U.rel_err(fx0.cpu().numpy(), G["f_x0"]) < TOL
+
+
+@pytest.mark.parametrize("B,d,E,hid,n,relu", [
+    (1, 1, 2, [100, 100, 100], 50, True),      # MonotonicNN shape, a single integral
+    (37, 3, 1, [20, 20], 20, False),           # ragged: 111 integrals, not a multiple of 16
+    (5, 63, 30, [50] * 4, 100, False),
+    (3, 7, 4, [127], 9, False),                # widest supported layer, odd node count
+    (9, 2, 10, [31, 63, 15], 33, True),        # mixed widths on tile boundaries
+    (4, 5, 2, [8, 8, 8, 8, 8, 8, 8], 12, False),   # deepest supported MLP
+])
+def test_ragged_shapes_against_oracle(B, d, E, hid, n, relu, dev):
+    from umnn_amd import integral as I
+    from umnn_amd.nets import MlpSpec
+    from umnn_amd import _lib
+    rng = np.random.RandomState(B * 131 + d)
+    sizes = [1 + E] + hid + [1]
+    Ws = [(rng.randn(sizes[i + 1], sizes[i]) * (1.6 / np.sqrt(sizes[i]))).astype(np.float32) for i in range(len(sizes) - 1)]
+    bs = [(rng.randn(sizes[i + 1]) * 0.3).astype(np.float32) for i in range(len(sizes) - 1)]
+    lin = []
+    for W, b in zip(Ws, bs):
+        m = torch.nn.Linear(W.shape[1], W.shape[0])
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(W))
+            m.bias.copy_(torch.from_numpy(b))
+        lin.append(m.to(dev))
+    spec = MlpSpec(lin, _lib.ACT_RELU if relu else _lib.ACT_LEAKY_RELU, _lib.OUT_ELU_PLUS_ONE)
+    x = (rng.randn(B, d) * 2).astype(np.float32)
+    x0 = (rng.randn(B, d) * 0.5).astype(np.float32)
+    h = rng.randn(B, E * d).astype(np.float32)
+    net = O.Net(Ws, bs, O.RELU if relu else O.LEAKY, O.ELU1)
+    F, fx, fx0 = I.hip_forward(spec, t(x0, dev), t(x, dev), t(h, dev), n)
+    assert U.rel_err(F.cpu().numpy(), O.integrate_parallel(net, x0, x, h, n)) < TOL
+    assert U.rel_err(fx.cpu().numpy(), O.integrand(net, x, h)) < TOL
+    assert U.rel_err(fx0.cpu().numpy(), O.integrand(net, x0, h)) < TOL
+    # x0 = None means zeros
+    F0, _, _ = I.hip_forward(spec, None, t(x, dev), t(h, dev), n)
+    assert U.rel_err(F0.cpu().numpy(), O.integrate_parallel(net, np.zeros_like(x), x, h, n)) < TOL
+
+
+def test_empty_batch(dev):
+    from umnn_amd import integral as I, IntegrandNetwork
+    from umnn_amd.nets import mlp_spec
+    net = IntegrandNetwork(3, 2, [16, 16], 1).to(dev)
+    F, fx, fx0 = I.hip_forward(mlp_spec(net), None, torch.zeros(0, 3, device=dev), torch.zeros(0, 3, device=dev), 10)
+    assert F.shape == (0, 3)
+
+
+@pytest.mark.parametrize("name", U.g4_names())
+def test_fused_flow_block_epilogue(name, dev):
+    """z = exp(s)(F + h_0) and log_jac = log(f+1e-10)+s from the fused entry point, block by block vs the oracle."""
+    from umnn_amd import integral as I, _lib
+    from umnn_amd.nets import MlpSpec
+    G = U.load(name)
+    blocks = U.blocks_from_g4(G)
+    x = G["x"]
+    ctx = G.get("context")
+    n = int(G["n"])
+    for i, blk in enumerate(blocks):
+        blk.scaling = (np.linspace(-0.3, 0.4, x.shape[1])).astype(np.float32)      # exercise exp(s), + s
+        z_ref, h = O.block_forward(blk, x, n, context=ctx)
+        lj_ref = O.block_log_jac(blk, x, h)
+        lin = []
+        for W, b in zip(blk.net.Ws, blk.net.bs):
+            m = torch.nn.Linear(W.shape[1], W.shape[0])
+            with torch.no_grad():
+                m.weight.copy_(torch.from_numpy(W))
+                m.bias.copy_(torch.from_numpy(b))
+            lin.append(m.to(dev))
+        spec = MlpSpec(lin, _lib.ACT_LEAKY_RELU, _lib.OUT_ELU_PLUS_ONE)
+        z, lj, fx, fx0 = I.hip_flow_block(spec, t(x, dev), t(h, dev), t(blk.scaling, dev), n)
+        assert U.rel_err(z.cpu().numpy(), z_ref) < TOL
+        assert np.all(np.abs(lj.cpu().numpy() - lj_ref) <= TOL * np.maximum(1.0, np.abs(lj_ref)))
+        x = z_ref[:, ::-1].copy()
+
+
+@pytest.mark.parametrize("name", U.g4_names())
+def test_flow_module_eval_matches_reference(name, dev):
+    """The nn.Module API on the GPU (HIP path) reproduces the reference's compute_ll / forward / log-jac."""
+    import umnn_amd
+    G = U.load(name)
+    m = umnn_amd.UMNNMAFFlow(nb_flow=int(G["nb_flow"]), nb_in=int(G["d"]),
+                             hidden_derivative=[int(v) for v in G["hidden_derivative"]],
+                             hidden_embedding=[int(v) for v in G["hidden_embedding"]], embedding_s=int(G["E"]),
+                             nb_steps=int(G["n"]), solver=str(G["solver"]), cond_in=int(G["cond_in"]))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in U.state_dict_of(G).items()})
+    m.to(dev).eval()
+    x = t(G["x"], dev)
+    ctx = t(G["context"], dev) if "context" in G else None
+    with torch.no_grad():
+        ll, z = m.compute_ll(x, context=ctx)
+        assert umnn_amd.path_taken() == "hip"
+        zb, lj = m.compute_log_jac_bis(x, context=ctx)
+        fwd = m.forward(x, context=ctx)
+        bpp, _, _ = m.compute_bpp(x, context=ctx)
+    assert U.rel_err(ll.cpu().numpy(), G["ll_eval"]) < TOL
+    assert U.rel_err(z.cpu().numpy(), G["z_eval"]) < TOL
+    assert U.rel_err(zb.cpu().numpy(), G["z_bis_eval"]) < TOL
+    assert U.rel_err(lj.cpu().numpy(), G["log_jac_bis_eval"]) < TOL
+    assert U.rel_err(fwd.cpu().numpy(), G["fwd_eval"]) < TOL
+    assert U.rel_err(bpp.cpu().numpy(), G["bpp_eval"]) < TOL
+
+
+def test_full_size_properties_bsds300_shard(dev):
+    """BASELINE config C3 at one GPU's share (8192 x 63, n=100, 31-50^4-1): too big for the oracle in full, so
+    check (a) a random sample of rows against the oracle (rows are independent), (b) shard consistency: the
+    result of the full batch equals the concatenation of two half batches bit-for-bit, (c) F(x0=x) = 0,
+    (d) monotonicity in x, (e) determinism."""
+    from umnn_amd import integral as I, IntegrandNetwork
+    from umnn_amd.nets import mlp_spec
+    torch.manual_seed(0)
+    B, d, E, n = 8192, 63, 30, 100
+    net = IntegrandNetwork(d, 1 + E, [50] * 4, 1)
+    with torch.no_grad():
+        for m in net.net:
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(1.7)
+    lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    onet = O.Net([m.weight.detach().numpy() for m in lin], [m.bias.detach().numpy() for m in lin], O.LEAKY, O.ELU1)
+    net.to(dev)
+    spec = mlp_spec(net)
+    x = torch.randn(B, d)
+    h = torch.randn(B, E * d)
+    xg, hg = x.to(dev), h.to(dev)
+    F, fx, fx0 = I.hip_forward(spec, None, xg, hg, n)
+    rows = np.random.RandomState(1).choice(B, 48, replace=False)
+    Fo = O.integrate_parallel(onet, np.zeros((48, d), np.float32), x.numpy()[rows], h.numpy()[rows], n)
+    assert U.rel_err(F.cpu().numpy()[rows], Fo) < TOL
+    assert U.rel_err(fx.cpu().numpy()[rows], O.integrand(onet, x.numpy()[rows], h.numpy()[rows])) < TOL
+    Fa, _, _ = I.hip_forward(spec, None, xg[:B // 2].contiguous(), hg[:B // 2].contiguous(), n)
+    Fb, _, _ = I.hip_forward(spec, None, xg[B // 2:].contiguous(), hg[B // 2:].contiguous(), n)
+    assert torch.equal(torch.cat([Fa, Fb]), F)
+    Fz, _, _ = I.hip_forward(spec, xg, xg, hg, n)
+    assert float(Fz.abs().max()) == 0.0
+    Fup, _, _ = I.hip_forward(spec, None, xg + 0.25, hg, n)
+    assert bool((Fup > F - 1e-4).all()) and float((Fup > F).float().mean()) > 0.999   # f > 0 => F increasing in x
+    F2, _, _ = I.hip_forward(spec, None, xg, hg, n)
+    assert torch.equal(F2, F)

@@ -124,3 +124,28 @@ def test_kat_various_functions(fn, a, b, true):
     # reference tests/test_numerical_validation.py:319-402: error < 1e-3 at 100 steps
     for n in (20, 50, 100):
         assert abs(_quad(fn, a, b, n) - true) < 1e-3
+
+
+# ---- the timed CPU baseline (torch port of the materialise-all-nodes algorithm) is the same function ----
+@pytest.mark.parametrize("name", ["g2_power_d6_w2", "g2_bsds_d63", "g2_toy_d2_w2", "g2_sigmoid_d4"])
+def test_torch_port_matches_reference(name):
+    import torch
+    from oracle import torch_port as TP
+    G = U.load(name)
+    L = len(G["hidden"]) + 1
+    Ws = [torch.from_numpy(G[f"W{l}"]) for l in range(L)]
+    bs = [torch.from_numpy(G[f"b{l}"]) for l in range(L)]
+    sig = str(G["act"]) == "Sigmoid"
+    x0, x, h = (torch.from_numpy(G[k]) for k in ("x0", "x", "h"))
+    assert U.rel_err(TP.integrate_parallel(Ws, bs, x0, x, h, int(G["n"]), sig).numpy(), G["F_par"]) < 2e-6
+    assert U.rel_err(TP.integrate_sequential(Ws, bs, x0, x, h, int(G["n"]), sig).numpy(), G["F_seq"]) < 2e-6
+
+
+def test_torch_port_flow_matches_reference():
+    import torch
+    from oracle import torch_port as TP
+    G = U.load("g4_flow1_power")
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in U.state_dict_of(G).items()}
+    ll, z = TP.flow_compute_ll(TP.blocks_from_state_dict(sd, 1), torch.from_numpy(G["x"]), int(G["n"]))
+    assert U.rel_err(ll.numpy(), G["ll_eval"]) < 1e-5
+    assert U.rel_err(z.numpy(), G["z_eval"]) < 1e-5

@@ -1,0 +1,13 @@
+"""umnn_amd -- MI355X-native (gfx950) neural-integration hot path of UMNN behind the reference's module API.
+
+Import surface mirrors models/UMNN/__init__.py:1-6 of the reference.
+"""
+from .flow import UMNNMAFFlow, UMNNMAF, EmbeddingNetwork, IntegrandNetwork, ListModule
+from .monotonic import MonotonicNN, IntegrandNN
+from .made import MADE, ConditionnalMADE, MaskedLinear
+from .integral import NeuralIntegral, ParallelNeuralIntegral, IntegralWithJacobian, integrate, path_taken
+from .quadrature import compute_cc_weights
+
+__all__ = ["UMNNMAFFlow", "UMNNMAF", "EmbeddingNetwork", "IntegrandNetwork", "ListModule", "MonotonicNN",
+           "IntegrandNN", "MADE", "ConditionnalMADE", "MaskedLinear", "NeuralIntegral", "ParallelNeuralIntegral",
+           "IntegralWithJacobian", "integrate", "compute_cc_weights", "path_taken"]

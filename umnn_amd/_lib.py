@@ -1,0 +1,86 @@
+"""ctypes binding of libumnn_cc.so (the C ABI declared in include/umnn_cc.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950).  There is
+no fallback: if it cannot be loaded, every HIP-path call raises.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libumnn_cc.so")
+
+MAX_LINEAR = 8
+ACT_LEAKY_RELU, ACT_RELU = 0, 1
+OUT_ELU_PLUS_ONE, OUT_SIGMOID = 0, 1
+
+_fp = ctypes.c_void_p          # device pointers travel as integers
+_ll = ctypes.c_longlong
+
+
+class MlpDesc(ctypes.Structure):
+    """struct umnn_mlp"""
+    _fields_ = [
+        ("n_linear", ctypes.c_int),
+        ("widths", ctypes.c_int * (MAX_LINEAR + 1)),
+        ("W", ctypes.c_void_p * MAX_LINEAR),
+        ("b", ctypes.c_void_p * MAX_LINEAR),
+        ("hidden_act", ctypes.c_int),
+        ("out_act", ctypes.c_int),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/umnn_cc.h declares
+SIGNATURES = {
+    "umnn_cc_forward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                       _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]),
+    "umnn_flow_block_forward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                               _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp]),
+    "umnn_cc_backward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                        _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _ll, _fp]),
+    "umnn_cc_backward_workspace_bytes": (_ll, [ctypes.POINTER(MlpDesc), _ll, ctypes.c_int, ctypes.c_int]),
+    "umnn_cc_tables_host": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                                           ctypes.POINTER(ctypes.c_float)]),
+    "umnn_cc_forward_flops_per_integral": (ctypes.c_double, [ctypes.POINTER(MlpDesc), ctypes.c_int]),
+    "umnn_last_error": (ctypes.c_char_p, []),
+    "umnn_version": (ctypes.c_int, []),
+    "umnn_launch_count": (_ll, []),
+    "umnn_last_kernel_name": (ctypes.c_char_p, []),
+    "umnn_cc_forward_timed": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                             _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int,
+                                             ctypes.POINTER(ctypes.c_float), _fp]),
+    "umnn_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "umnn_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_ll),
+                                         ctypes.POINTER(ctypes.c_double)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises HipLibraryMissing loudly if absent."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise HipLibraryMissing(
+                        f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950).  umnn_amd has no non-HIP path for MLP integrands on GPU.")
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.restype, fn.argtypes = res, args
+                _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().umnn_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

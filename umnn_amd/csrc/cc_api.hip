@@ -1,0 +1,197 @@
+// C-ABI plumbing of libumnn_cc.so: argument validation, error reporting, introspection, and the
+// host-side Clenshaw-Curtis tables (reference: models/UMNN/ParallelNeuralIntegral.py:14-34).
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "cc_host.h"
+
+static thread_local char g_err[512] = "";
+static thread_local const char* g_last_kernel = "";
+static std::atomic<long long> g_launches{0};
+
+int umnn_fail(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+int umnn_check(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+void umnn_note_launch(const char* kernel_name) {
+    g_last_kernel = kernel_name;
+    g_launches.fetch_add(1, std::memory_order_relaxed);
+}
+
+int umnn_num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+int umnn_allow_lds(const void* fn, size_t bytes) {
+    // raising the dynamic-LDS cap is per (device, function); cache what we already granted
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> granted[16];
+    int dev = 0;
+    if (int rc = umnn_check(hipGetDevice(&dev), "hipGetDevice")) return rc;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& tab = granted[dev & 15];
+    auto it = tab.find(fn);
+    if (it != tab.end() && it->second >= bytes) return 0;
+    if (int rc = umnn_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
+        return rc;
+    tab[fn] = bytes;
+    return 0;
+}
+
+long long umnn_param_count(const umnn_mlp* net) {
+    long long n = 0;
+    for (int l = 0; l < net->n_linear; ++l) n += (long long)net->widths[l + 1] * net->widths[l] + net->widths[l + 1];
+    return n;
+}
+
+int umnn_prepare_mlp(const umnn_mlp* net, int E, MlpDev* out, int* tmax, int* ksu) {
+    if (!net) return umnn_fail(UMNN_EINVAL, "net is null");
+    const int nl = net->n_linear;
+    if (nl < 2 || nl > UMNN_MAX_LINEAR)
+        return umnn_fail(UMNN_EUNSUPPORTED, "integrand MLP must have between 1 and UMNN_MAX_LINEAR-1 hidden layers");
+    if (E < 0 || net->widths[0] != 1 + E)
+        return umnn_fail(UMNN_EINVAL, "widths[0] must equal 1 + E (integration variable + embedding)");
+    if (net->widths[nl] != 1) return umnn_fail(UMNN_EINVAL, "integrand output width must be 1");
+    if (net->hidden_act != UMNN_ACT_LEAKY_RELU && net->hidden_act != UMNN_ACT_RELU)
+        return umnn_fail(UMNN_EINVAL, "unknown hidden_act");
+    if (net->out_act != UMNN_OUT_ELU_PLUS_ONE && net->out_act != UMNN_OUT_SIGMOID)
+        return umnn_fail(UMNN_EINVAL, "unknown out_act");
+    memset(out, 0, sizeof(*out));
+    out->n_linear = nl;
+    out->hidden_act = net->hidden_act;
+    out->out_act = net->out_act;
+    for (int l = 0; l <= nl; ++l) out->width[l] = net->widths[l];
+    for (int l = 0; l < nl; ++l) {
+        if (!net->W[l] || !net->b[l]) return umnn_fail(UMNN_EINVAL, "null weight or bias pointer");
+        out->W[l] = net->W[l];
+        out->b[l] = net->b[l];
+    }
+    const int L = nl - 1;
+    int tm = 0, ks_common = -1;
+    for (int l = 1; l <= L; ++l) {
+        const int H = net->widths[l];
+        if (H < 1 || H > UMNN_MAX_HIDDEN_WIDTH)
+            return umnn_fail(UMNN_EUNSUPPORTED, "hidden width must be in [1, UMNN_MAX_HIDDEN_WIDTH]");
+        out->t_out[l] = (H + 1 + 15) / 16;
+        out->ks_in[l] = (H + 1 + 3) / 4;
+        if (out->t_out[l] > tm) tm = out->t_out[l];
+        if (ks_common == -1) ks_common = out->ks_in[l];
+        else if (ks_common != out->ks_in[l]) ks_common = 0;
+    }
+    int off = 0;
+    for (int l = 1; l < L; ++l) {
+        out->lds_off[l] = off;
+        off += out->t_out[l + 1] * out->ks_in[l] * 64;
+    }
+    out->lds_off[L] = off;   // end of the images = start of kernel scratch
+    // an "exact" variant additionally needs every layer to fill the same number of tiles
+    for (int l = 1; l <= L; ++l)
+        if (out->t_out[l] != tm) ks_common = 0;
+    *tmax = tm;
+    *ksu = ks_common > 0 ? ks_common : 0;
+    return 0;
+}
+
+// ---- per-launch timing with hipEvents on the launch stream -------------------------------------
+struct ProfRec { hipEvent_t a, b; double flops; };
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof;
+static bool g_prof_on = false;
+static thread_local hipEvent_t g_prof_open = nullptr;
+
+void umnn_prof_begin(hipStream_t stream) {
+    if (!g_prof_on) return;
+    hipEvent_t a;
+    if (hipEventCreate(&a) != hipSuccess) return;
+    (void)hipEventRecord(a, stream);
+    g_prof_open = a;
+}
+
+void umnn_prof_end(hipStream_t stream, double flops) {
+    if (!g_prof_on || !g_prof_open) return;
+    hipEvent_t b;
+    if (hipEventCreate(&b) != hipSuccess) return;
+    (void)hipEventRecord(b, stream);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back({g_prof_open, b, flops});
+    g_prof_open = nullptr;
+}
+
+extern "C" int umnn_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return 0;
+}
+
+extern "C" int umnn_profile_read(double* total_ms, long long* launches, double* total_flops) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double ms = 0.0, fl = 0.0;
+    for (auto& r : g_prof) {
+        if (int rc = umnn_check(hipEventSynchronize(r.b), "hipEventSynchronize")) return rc;
+        float t = 0.f;
+        if (int rc = umnn_check(hipEventElapsedTime(&t, r.a, r.b), "hipEventElapsedTime")) return rc;
+        ms += t;
+        fl += r.flops;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = (long long)g_prof.size();
+    if (total_flops) *total_flops = fl;
+    return 0;
+}
+
+extern "C" const char* umnn_last_error(void) { return g_err; }
+extern "C" int umnn_version(void) { return 100; }
+extern "C" long long umnn_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
+extern "C" const char* umnn_last_kernel_name(void) { return g_last_kernel; }
+
+extern "C" double umnn_cc_forward_flops_per_integral(const umnn_mlp* net, int nb_steps) {
+    if (!net || net->n_linear < 2) return 0.0;
+    const int L = net->n_linear - 1;
+    double node = net->widths[1] + net->widths[L];
+    for (int l = 1; l < L; ++l) node += (double)net->widths[l] * net->widths[l + 1];
+    const double once = (double)(net->widths[0] - 1) * net->widths[1];
+    return 2.0 * ((nb_steps + 1) * node + once);
+}
+
+extern "C" int umnn_cc_tables_host(int nb_steps, float* w_host, float* s_host) {
+    if (nb_steps < 1 || !w_host || !s_host) return umnn_fail(UMNN_EINVAL, "tables: nb_steps >= 1, non-null outputs");
+    const int n = nb_steps;
+    std::vector<double> Wj(n + 1);
+    for (int j = 0; j <= n; ++j) Wj[j] = (j % 2) ? 0.0 : 2.0 / (1.0 - (double)j * j);
+    Wj[0] = 1.0;
+    for (int k = 0; k <= n; ++k) {
+        // w_k = sum_j lam[j][k] * W_j with lam[j][k] = cos(jk pi/n) * 2/n, column 0 := .5*2/n, column n halved
+        double acc = 0.0;
+        for (int j = 0; j <= n; ++j) {
+            double lam = std::cos((double)j * k * M_PI / n);
+            if (k == 0) lam = .5;
+            else if (k == n) lam = .5 * lam;
+            acc += lam * 2 / n * Wj[j];
+        }
+        w_host[k] = (float)acc;
+        s_host[k] = (float)std::cos((double)k * M_PI / n);
+    }
+    return 0;
+}

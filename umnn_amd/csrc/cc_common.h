@@ -1,0 +1,106 @@
+// Shared device/host definitions for the gfx950 Clenshaw-Curtis kernels.
+//
+// Register / LDS conventions used by every kernel in this directory
+// ------------------------------------------------------------------
+// All hidden-layer GEMMs run on v_mfma_f32_16x16x4_f32 (exact fp32, 32 cycles per SIMD) in the
+// orientation  D[feature][point] += A[feature][k] * B[k][point]:
+//   * a wave owns P "point tiles" of 16 integrals each; lane = 16*g + p  (g = lane>>4, p = lane&15)
+//     holds point p of the tile in every MFMA B operand and in every accumulator;
+//   * an activation vector of one hidden layer lives in registers act[tile t][r] (f32x4 per tile):
+//     lane (g,p), tile t, component r  <->  feature f = 16*t + 4*r + g  of point p.
+//     With that numbering the accumulator of output tile t *is already* the B operand of K-step
+//     s = 4*t + r of the next layer (features 4*s .. 4*s+3 on lane groups g = 0..3): layers chain
+//     through registers with no cross-lane movement and no LDS round trip;
+//   * the A operand of (output tile t, K-step s) is 64 floats, lane l -> W[f_out][f_in] with
+//     f_out = 16*t + 4*(rho&3) + (rho>>2), rho = l&15  and  f_in = 4*s + (l>>4); it is staged once
+//     per workgroup in LDS as img[(t*KS + s)*64 + l] and read with a conflict-free ds_read_b32;
+//   * every hidden layer carries one extra constant-one feature (index H_l): the bias of the next
+//     layer is the weight column of that feature, and the row H_{l+1} of the next image is
+//     e_{H_l}, so the constant propagates.  Accumulators therefore start at zero and no bias
+//     registers are needed.  Padding features beyond H_l+1 are exact zeros.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/umnn_cc.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define UMNN_WAVES_PER_BLOCK 4
+#define UMNN_BLOCK (64 * UMNN_WAVES_PER_BLOCK)
+
+struct MlpDev {
+    const float* W[UMNN_MAX_LINEAR];
+    const float* b[UMNN_MAX_LINEAR];
+    int width[UMNN_MAX_LINEAR + 1];   // [1+E, H1..HL, 1]
+    int n_linear;
+    int t_out[UMNN_MAX_LINEAR];       // t_out[l]  = ceil((H_l+1)/16): tiles of hidden layer l (l = 1..L)
+    int ks_in[UMNN_MAX_LINEAR];       // ks_in[l]  = ceil((H_l+1)/4):  K-steps when layer l is the input
+    int lds_off[UMNN_MAX_LINEAR];     // float offset of image l (hidden l -> hidden l+1), l = 1..L-1
+    int hidden_act;
+    int out_act;
+};
+
+// feature index held by lane group g in component r of tile t
+__device__ __forceinline__ int feat_of(int t, int r, int g) { return 16 * t + 4 * r + g; }
+// output feature of accumulator row rho (= lane&15 in an A operand) of tile t
+__device__ __forceinline__ int fout_of(int t, int rho) { return 16 * t + 4 * (rho & 3) + (rho >> 2); }
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// hidden activation: LeakyReLU(0.01) (slope = 0.01) or ReLU (slope = 0) as max(v, slope*v)
+__device__ __forceinline__ float hidden_act_f(float v, float slope) { return fmaxf(v, slope * v); }
+__device__ __forceinline__ float hidden_grad_f(float v, float slope) { return v > 0.f ? 1.f : slope; }
+
+__device__ __forceinline__ float out_act_f(float v, int kind) {
+    if (kind == UMNN_OUT_ELU_PLUS_ONE) return v > 0.f ? v + 1.f : __expf(v);   // ELU(v)+1 = exp(v) for v<=0
+    return 1.f / (1.f + __expf(-v));
+}
+__device__ __forceinline__ float out_grad_f(float v, int kind) {
+    if (kind == UMNN_OUT_ELU_PLUS_ONE) return v > 0.f ? 1.f : __expf(v);
+    const float s = 1.f / (1.f + __expf(-v));
+    return s * (1.f - s);
+}
+
+// sum over the four lane groups (lanes p, p+16, p+32, p+48); every lane gets the total
+__device__ __forceinline__ float group_allreduce(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// Stage the hidden->hidden weight images (see header comment) into LDS.  Called by all threads
+// of the workgroup; caller issues the __syncthreads().
+__device__ __forceinline__ void stage_hidden_images(const MlpDev& m, float* lds, int tid, int nthreads) {
+    const int L = m.n_linear - 1;
+    for (int l = 1; l < L; ++l) {
+        const int Hin = m.width[l], Hout = m.width[l + 1];
+        const int ks = m.ks_in[l], to = m.t_out[l + 1];
+        const float* __restrict__ W = m.W[l];
+        const float* __restrict__ b = m.b[l];
+        float* img = lds + m.lds_off[l];
+        const int total = to * ks * 64;
+        for (int idx = tid; idx < total; idx += nthreads) {
+            const int ln = idx & 63, ts = idx >> 6;
+            const int s = ts % ks, t = ts / ks;
+            const int fo = fout_of(t, ln & 15), fi = 4 * s + (ln >> 4);
+            float v = 0.f;
+            if (fo < Hout) {
+                if (fi < Hin) v = W[fo * Hin + fi];
+                else if (fi == Hin) v = b[fo];
+            } else if (fo == Hout && fi == Hin) {
+                v = 1.f;
+            }
+            img[idx] = v;
+        }
+    }
+}
+
+// Bijective XCD-aware remap: hardware places workgroup b on XCD b % 8; give each XCD a
+// contiguous chunk of the tile space so neighbouring tiles (which share h cache lines) share an L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8, j = bid / 8;
+    const unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + j;
+}

@@ -1,0 +1,352 @@
+// Forward Clenshaw-Curtis quadrature of the integrand MLP, fused: one pass emits
+//   F(x) = (x-x0)/2 * sum_k w_k f(t_k; h),   f(x; h) (node 0)   and   f(x0; h) (node n)
+// and optionally the UMNNMAF block epilogue z = exp(s)(F + h_0), log_jac = log(f(x)+1e-10) + s.
+//
+// Replaces (reference, never materialising the node axis):
+//   models/UMNN/ParallelNeuralIntegral.py:49-65  integrate(compute_grad=False)
+//   models/UMNN/NeuralIntegral.py:53-66          sequential variant (same arithmetic)
+//   models/UMNN/UMNNMAF.py:263-284               IntegrandNetwork.forward on every node
+//   models/UMNN/UMNNMAF.py:80-83,134,138-139     block epilogue (flow entry point)
+//
+// Work decomposition: a wave owns P tiles of 16 integrals (lane&15 = integral within the tile) and
+// walks a contiguous range of quadrature nodes; the node sum is a per-lane register accumulation.
+// NS in {1,2,4} waves of a workgroup may share one tile group and split the node range (small
+// problems), their partial sums meeting in LDS.  Per node: layer 1 is one FMA per feature (the
+// node-invariant part W1[:,1:]*h + b1 is hoisted and computed once per integral, itself on MFMA);
+// hidden layers are 16x16x4 fp32 MFMAs against LDS-resident weight images; the scalar output layer
+// is a per-lane dot product plus a 4-lane-group all-reduce.  See cc_common.h for the layouts.
+#include "cc_common.h"
+
+struct FwdArgs {
+    MlpDev m;
+    const float* x0;   // nullable
+    const float* x;
+    const float* h;
+    const float* ccw;
+    const float* ccs;
+    float* F;          // nullable when flow epilogue is used
+    float* fx;         // nullable
+    float* fx0;        // nullable
+    const float* scaling;  // flow epilogue (nullable => plain integral)
+    float* z;
+    float* logjac;
+    long long NI;      // B*d integrals
+    int d, E, n, ns, inv_f;
+    unsigned ngroups;  // tile groups (of 16*P integrals)
+};
+
+template <int TMAX, int KSC, int P>
+__global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_kernel(const FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MlpDev& m = a.m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, p = lane & 15;
+    const int L = m.n_linear - 1;             // hidden layers
+    const int H1 = m.width[1], HL = m.width[L];
+    const int E = a.E, d = a.d, n = a.n;
+    const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
+
+    stage_hidden_images(m, lds, tid, UMNN_BLOCK);
+    __syncthreads();
+
+    // ---- which tile group / node range does this wave own?
+    const int ns = a.ns;                                      // 1, 2 or 4
+    const int sub = wid / ns, part = wid % ns;
+    const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;           // tile groups per workgroup
+    const unsigned grp = xcd_remap(blockIdx.x, gridDim.x) * gpb + sub;
+    const bool live = grp < a.ngroups;
+    const int k_lo = (int)(((long long)part * (n + 1)) / ns);
+    const int k_hi = (int)(((long long)(part + 1) * (n + 1)) / ns);
+
+    float Facc[P], fxv[P], fx0v[P], xv[P], x0v[P], dxv[P];
+    bool ok[P];
+    long long qv[P];
+#pragma unroll
+    for (int pt = 0; pt < P; ++pt) { Facc[pt] = 0.f; fxv[pt] = 0.f; fx0v[pt] = 0.f; }
+
+    if (live) {
+        const float* hb[P];
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            const long long q = ((long long)grp * P + pt) * 16 + p;
+            ok[pt] = q < a.NI;
+            const long long qq = ok[pt] ? q : a.NI - 1;
+            qv[pt] = qq;
+            xv[pt] = a.x[qq];
+            x0v[pt] = a.x0 ? a.x0[qq] : 0.f;
+            dxv[pt] = xv[pt] - x0v[pt];
+            const long long bi = qq / d;
+            hb[pt] = a.h + bi * ((long long)E * d) + (qq - bi * d);
+        }
+
+        // ---- per-lane constants: first-layer x-column and output-layer row (+ its bias)
+        float w1x[TMAX][4], wout[TMAX][4];
+        {
+            const float* __restrict__ W0 = m.W[0];
+            const float* __restrict__ WL = m.W[L];
+            const float bL = m.b[L][0];
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = feat_of(t, r, g);
+                    w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
+                    wout[t][r] = f < HL ? WL[f] : (f == HL ? bL : 0.f);
+                }
+        }
+
+        // ---- hoisted first-layer term c = W1[:,1:] h + b1 (and the constant-one feature), on MFMA
+        f32x4 c[P][TMAX];
+        {
+            const float* __restrict__ W0 = m.W[0];
+            const float* __restrict__ b0 = m.b[0];
+            const int t1 = KSC ? TMAX : m.t_out[1];
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) {
+                f32x4 init;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = feat_of(t, r, g);
+                    init[r] = f < H1 ? b0[f] : (f == H1 ? 1.f : 0.f);
+                }
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt) c[pt][t] = init;
+            }
+            for (int se = 0; se < (E + 3) / 4; ++se) {
+                const int e = 4 * se + g;
+                float hv[P];
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt) hv[pt] = e < E ? hb[pt][(long long)e * d] : 0.f;
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t) {
+                    if (t < t1) {
+                        const int fo = fout_of(t, p);
+                        const float A = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
+#pragma unroll
+                        for (int pt = 0; pt < P; ++pt) c[pt][t] = mfma16(A, hv[pt], c[pt][t]);
+                    }
+                }
+            }
+        }
+
+        // ---- walk the quadrature nodes
+        for (int k = k_lo; k < k_hi; ++k) {
+            const float u = a.ccs[k] + 1.f;
+            const float wk = a.ccw[k];
+            f32x4 act[P][TMAX];
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) {
+                // t_k = x0 + (x-x0)*(s_k+1)/2 in the reference's rounding order; node 0 is x itself
+                const float tk = k == 0 ? xv[pt] : __fadd_rn(x0v[pt], __fmul_rn(dxv[pt], u) * 0.5f);
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        act[pt][t][r] = hidden_act_f(fmaf(w1x[t][r], tk, c[pt][t][r]), slope);
+            }
+
+            for (int l = 1; l < L; ++l) {
+                const int ks = KSC ? KSC : m.ks_in[l];
+                const int to = KSC ? TMAX : m.t_out[l + 1];
+                const float* img = lds + m.lds_off[l] + lane;
+                f32x4 acc[P][TMAX];
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) acc[pt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4 * TMAX; ++s) {
+                    if (KSC ? (s < KSC) : (s < ks)) {
+#pragma unroll
+                        for (int t = 0; t < TMAX; ++t) {
+                            if (KSC || t < to) {
+                                const float A = img[(t * ks + s) * 64];
+#pragma unroll
+                                for (int pt = 0; pt < P; ++pt)
+                                    acc[pt][t] = mfma16(A, act[pt][s >> 2][s & 3], acc[pt][t]);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            act[pt][t][r] = (KSC || t < to) ? hidden_act_f(acc[pt][t][r], slope) : 0.f;
+            }
+
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s = fmaf(wout[t][r], act[pt][t][r], s);
+                s = group_allreduce(s);
+                const float f = out_act_f(s, m.out_act);
+                Facc[pt] = fmaf(wk, a.inv_f ? 1.f / f : f, Facc[pt]);
+                if (k == 0) fxv[pt] = f;
+                if (k == n) fx0v[pt] = f;
+            }
+        }
+    }
+
+    // ---- combine node-range partials of the NS waves sharing this tile group
+    if (ns > 1) {
+        float* red = lds + m.lds_off[L];      // [waves][3][P*16]
+        if (live && g == 0) {
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) {
+                float* rw = red + wid * (3 * P * 16) + pt * 16 + p;
+                rw[0] = Facc[pt];
+                rw[P * 16] = fxv[pt];
+                rw[2 * P * 16] = fx0v[pt];
+            }
+        }
+        __syncthreads();
+        if (live && part == 0 && g == 0) {
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) {
+                float s = 0.f;
+                for (int j = 0; j < ns; ++j) s += red[(wid + j) * (3 * P * 16) + pt * 16 + p];
+                Facc[pt] = s;
+                fx0v[pt] = red[(wid + ns - 1) * (3 * P * 16) + 2 * P * 16 + pt * 16 + p];
+            }
+        }
+    }
+
+    if (live && part == 0 && g == 0) {
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            if (!ok[pt]) continue;
+            const long long q = qv[pt];
+            const float Fv = Facc[pt] * dxv[pt] * 0.5f;
+            if (a.F) a.F[q] = Fv;
+            if (a.fx) a.fx[q] = fxv[pt];
+            if (a.fx0) a.fx0[q] = fx0v[pt];
+            if (a.scaling) {
+                const long long bi = q / d;
+                const int i = (int)(q - bi * d);
+                const float sc = a.scaling[i];
+                const float z0 = a.h[bi * ((long long)E * d) + i];
+                a.z[q] = __expf(sc) * (Fv + z0);
+                a.logjac[q] = __logf(fxv[pt] + 1e-10f) + sc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+#include "cc_host.h"
+
+typedef void (*fwd_kernel_t)(const FwdArgs);
+
+struct FwdVariant { int tmax, ksc, p; fwd_kernel_t fn; const char* name; };
+
+#define FWD_VARIANT(T, K, PP) { T, K, PP, cc_fwd_kernel<T, K, PP>, "cc_fwd<T=" #T ",KS=" #K ",P=" #PP ">" }
+static const FwdVariant kFwdVariants[] = {
+    FWD_VARIANT(4, 13, 1), FWD_VARIANT(4, 13, 2),     // hidden width 50 (UCI / VAE nets)
+    FWD_VARIANT(7, 26, 1), FWD_VARIANT(7, 26, 2),     // hidden width 100 (toy / MonotonicMLP nets)
+    FWD_VARIANT(2, 0, 1),  FWD_VARIANT(2, 0, 2),      // generic, hidden widths <= 31
+    FWD_VARIANT(4, 0, 1),  FWD_VARIANT(4, 0, 2),      // generic, <= 63
+    FWD_VARIANT(8, 0, 1),  FWD_VARIANT(8, 0, 2),      // generic, <= 127
+};
+
+static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, const float* h,
+                          const float* scaling, const float* cc_w, const float* cc_s, int nb_steps,
+                          long long B, int d, int E, int inv_f,
+                          float* F, float* f_x, float* f_x0, float* z, float* log_jac, hipStream_t stream) {
+    FwdArgs a;
+    int tmax = 0, ksu = 0;
+    if (int rc = umnn_prepare_mlp(net, E, &a.m, &tmax, &ksu)) return rc;
+    if (!x || !h || !cc_w || !cc_s) return umnn_fail(UMNN_EINVAL, "forward: x, h, cc_w, cc_s must be non-null");
+    if (nb_steps < 1) return umnn_fail(UMNN_EINVAL, "forward: nb_steps must be >= 1");
+    if (B < 0 || d < 1) return umnn_fail(UMNN_EINVAL, "forward: B must be >= 0 and d >= 1");
+    if (!scaling && !F) return umnn_fail(UMNN_EINVAL, "forward: F must be non-null");
+    if (scaling && (!z || !log_jac)) return umnn_fail(UMNN_EINVAL, "flow forward: z and log_jac must be non-null");
+    if (B == 0) return 0;
+
+    a.x0 = x0; a.x = x; a.h = h; a.ccw = cc_w; a.ccs = cc_s;
+    a.F = F; a.fx = f_x; a.fx0 = f_x0; a.scaling = scaling; a.z = z; a.logjac = log_jac;
+    a.NI = B * (long long)d; a.d = d; a.E = E; a.n = nb_steps; a.inv_f = inv_f;
+
+    // ---- choose the variant: exact (compile-time K-steps) when all hidden layers share a width we
+    // instantiated, otherwise the smallest generic tile count that fits
+    const long long tiles16 = (a.NI + 15) / 16;
+    const int simd_slots = umnn_num_cus() * 4;
+    int P = tiles16 >= 8LL * simd_slots ? 2 : 1;
+    int ns = 1;
+    if (tiles16 < 2LL * simd_slots) ns = tiles16 * 2 <= 2LL * simd_slots ? 4 : 2;
+    if (ns > nb_steps + 1) ns = 1;
+    if (const char* ev = getenv("UMNN_FWD_P")) P = atoi(ev) == 2 ? 2 : 1;
+    if (const char* ev = getenv("UMNN_FWD_NS")) { int v = atoi(ev); if (v == 1 || v == 2 || v == 4) ns = v; }
+
+    const FwdVariant* pick = nullptr;
+    for (const FwdVariant& v : kFwdVariants)
+        if (v.ksc && v.ksc == ksu && v.tmax == tmax && v.p == P) { pick = &v; break; }
+    if (!pick)
+        for (const FwdVariant& v : kFwdVariants)
+            if (!v.ksc && v.tmax >= tmax && v.p == P) { pick = &v; break; }
+    if (!pick) return umnn_fail(UMNN_EUNSUPPORTED, "forward: hidden width above UMNN_MAX_HIDDEN_WIDTH");
+
+    const int L = a.m.n_linear - 1;
+    const size_t lds_floats = (size_t)a.m.lds_off[L] + (ns > 1 ? UMNN_WAVES_PER_BLOCK * 3 * P * 16 : 0);
+    const size_t lds_bytes = lds_floats * sizeof(float);
+    if (lds_bytes > 160 * 1024) return umnn_fail(UMNN_EUNSUPPORTED, "forward: weight images exceed 160 KiB of LDS");
+    if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
+
+    a.ns = ns;
+    a.ngroups = (unsigned)((a.NI + 16 * P - 1) / (16 * P));
+    const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
+    const unsigned nblk = (a.ngroups + gpb - 1) / gpb;
+    umnn_prof_begin(stream);
+    hipLaunchKernelGGL(pick->fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, a);
+    umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * (double)a.NI);
+    umnn_note_launch(pick->name);
+    return umnn_check(hipGetLastError(), "cc_fwd launch");
+}
+
+extern "C" int umnn_cc_forward(const umnn_mlp* net, const float* x0, const float* x, const float* h,
+                               const float* cc_w, const float* cc_s, int nb_steps,
+                               long long B, int d, int E, int inv_f,
+                               float* F, float* f_x, float* f_x0, void* stream) {
+    return launch_forward(net, x0, x, h, nullptr, cc_w, cc_s, nb_steps, B, d, E, inv_f, F, f_x, f_x0,
+                          nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int umnn_flow_block_forward(const umnn_mlp* net, const float* x, const float* h, const float* scaling,
+                                       const float* cc_w, const float* cc_s, int nb_steps,
+                                       long long B, int d, int E,
+                                       float* z, float* log_jac, float* f_x, float* f_x0, void* stream) {
+    if (!scaling) return umnn_fail(UMNN_EINVAL, "flow forward: scaling must be non-null");
+    return launch_forward(net, nullptr, x, h, scaling, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr, f_x, f_x0,
+                          z, log_jac, (hipStream_t)stream);
+}
+
+extern "C" int umnn_cc_forward_timed(const umnn_mlp* net, const float* x0, const float* x, const float* h,
+                                     const float* cc_w, const float* cc_s, int nb_steps,
+                                     long long B, int d, int E, float* F, float* f_x, float* f_x0,
+                                     int reps, float* ms, void* stream) {
+    if (reps < 1 || !ms) return umnn_fail(UMNN_EINVAL, "forward_timed: reps >= 1 and ms non-null");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (int rc = umnn_check(hipEventCreate(&e0), "hipEventCreate")) return rc;
+    if (int rc = umnn_check(hipEventCreate(&e1), "hipEventCreate")) return rc;
+    int rc = umnn_cc_forward(net, x0, x, h, cc_w, cc_s, nb_steps, B, d, E, 0, F, f_x, f_x0, stream);   // warm
+    if (!rc) rc = umnn_check(hipEventRecord(e0, st), "hipEventRecord");
+    for (int i = 0; i < reps && !rc; ++i)
+        rc = umnn_cc_forward(net, x0, x, h, cc_w, cc_s, nb_steps, B, d, E, 0, F, f_x, f_x0, stream);
+    if (!rc) rc = umnn_check(hipEventRecord(e1, st), "hipEventRecord");
+    if (!rc) rc = umnn_check(hipEventSynchronize(e1), "hipEventSynchronize");
+    float t = 0.f;
+    if (!rc) rc = umnn_check(hipEventElapsedTime(&t, e0, e1), "hipEventElapsedTime");
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *ms = t / reps;
+    return rc;
+}

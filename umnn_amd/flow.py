@@ -1,0 +1,317 @@
+"""UMNN-MAF flow modules: EmbeddingNetwork, UMNNMAF (one block) and UMNNMAFFlow (the stack).
+
+The nn.Module API (constructor arguments, method names, ``.to`` returning self, state_dict keys
+``Flow{i}.net.made.net.*``, ``Flow{i}.net.parallel_nets.net.*``, ``Flow{i}.{scaling,pi,cc_weights,cc_steps}``, ``pi``)
+is the reference's: models/UMNN/UMNNMAF.py:37-232,304-329 and models/UMNN/UMNNMAFFlow.py:8-151.
+
+What is different underneath (MI355X-first, results unchanged):
+  * one block = ONE conditioner pass + ONE fused HIP launch giving both z and log|dz/dx| (quadrature node 0 is x,
+    so f(x;h) falls out of the integral; the reference runs MADE twice and the integrand once more,
+    UMNNMAFFlow.py:113-114 / UMNNMAF.py:136-139);
+  * the node axis is never materialised, so "CC" and "CCParallel" are the same kernel;
+  * training goes through ``IntegralWithJacobian`` (HIP forward + HIP backward with the reference's gradient
+    convention); inference through the fully fused block epilogue.
+Names the reference's scripts call but the reference never defines exist here as aliases.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import integral as _I
+from .integral import NeuralIntegral, ParallelNeuralIntegral, IntegralWithJacobian, _flatten
+from .made import MADE, ConditionnalMADE
+from .nets import ELUPlus, IntegrandNetwork, compute_lipschitz_linear, mlp_spec  # noqa: F401  (re-exported)
+from .quadrature import compute_cc_weights
+
+_SOLVERS = {"CC": NeuralIntegral, "CCParallel": ParallelNeuralIntegral}
+
+
+class EmbeddingNetwork(nn.Module):
+    """Conditioner (MADE) + the shared integrand MLP of one block."""
+
+    def __init__(self, in_d, hiddens_embedding=[50, 50, 50, 50], hiddens_integrand=[50, 50, 50, 50], out_made=1,
+                 cond_in=0, act_func='ELU', device="cpu"):
+        super().__init__()
+        self.m_embeding = None
+        self.device = device
+        self.in_d = in_d
+        if cond_in > 0:
+            self.made = ConditionnalMADE(in_d, cond_in, hiddens_embedding, (in_d + cond_in) * out_made, num_masks=1,
+                                         natural_ordering=True).to(device)
+        else:
+            self.made = MADE(in_d, hiddens_embedding, in_d * out_made, num_masks=1, natural_ordering=True).to(device)
+        self.parallel_nets = IntegrandNetwork(in_d, 1 + out_made, hiddens_integrand, 1, act_func=act_func,
+                                              device=device)
+
+    def to(self, device):
+        self.device = device
+        self.made.to(device)
+        self.parallel_nets.to(device)
+        return self
+
+    def make_embeding(self, x_made, context=None):
+        # .raw(): the masked MLP itself.  (The reference calls MADE.forward, whose nout==2 "Gaussian" branch
+        # breaks the d=2/E=1 and d=1/E=2 flows, made.py:114-118; the embedding never wants that branch.)
+        if isinstance(self.made, ConditionnalMADE):
+            self.m_embeding = self.made.raw(x_made, context)
+        else:
+            self.m_embeding = self.made.raw(x_made)
+        return self.m_embeding
+
+    def forward(self, x_t):
+        return self.parallel_nets.forward(x_t, self.m_embeding)
+
+
+class UMNNMAF(nn.Module):
+    def __init__(self, net, input_size, nb_steps=100, device="cpu", solver="CC"):
+        super().__init__()
+        self.net = net.to(device)
+        self.device = device
+        self.input_size = input_size
+        self.nb_steps = nb_steps
+        self.solver = solver
+        self.register_buffer("pi", torch.tensor(math.pi))
+        w, s = compute_cc_weights(nb_steps)
+        self.register_buffer("cc_weights", w.clone())
+        self.register_buffer("cc_steps", s.clone())
+        self.scaling = nn.Parameter(torch.zeros(input_size, device=self.device), requires_grad=False)
+
+    def to(self, device):
+        self.device = device
+        super().to(device)
+        return self
+
+    # ------------------------------------------------------------------ core: one pass, both outputs
+    def _transform(self, x, context=None, x0=None, want_jac=True):
+        """-> (z, log_jac or None).  One conditioner pass, one quadrature launch."""
+        if self.solver not in _SOLVERS:
+            return None, None
+        integrand = self.net.parallel_nets
+        h = self.net.make_embeding(x, context)
+        d = x.shape[1]
+        z0 = h.view(h.shape[0], -1, d)[:, 0, :]
+        spec = mlp_spec(integrand)
+        no_graph = (not torch.is_grad_enabled()) or ((not self.training) and (not x.requires_grad))
+        if _I._use_hip(spec, x):
+            if no_graph and x0 is None:
+                z, log_jac, _, _ = _I.hip_flow_block(spec, x, h, self.scaling, self.nb_steps)
+                return z, log_jac
+            x0 = x0.to(x.device) if x0 is not None else torch.zeros_like(x)
+            if no_graph:
+                F, fx, _ = _I.hip_forward(spec, x0, x, h, self.nb_steps)
+            else:
+                F, fx = IntegralWithJacobian.apply(x0, x, integrand, _flatten(integrand.parameters()), h,
+                                                   self.nb_steps)
+        else:
+            x0 = x0.to(x.device) if x0 is not None else torch.zeros_like(x)
+            if no_graph:
+                with torch.no_grad():
+                    F = _I.aten_forward(integrand, x0, x, h, self.nb_steps)
+            else:
+                F = _SOLVERS[self.solver].apply(x0, x, integrand, _flatten(integrand.parameters()), h, self.nb_steps)
+            fx = integrand(x, h) if want_jac else None
+        z = torch.exp(self.scaling).unsqueeze(0) * (F + z0)
+        log_jac = torch.log(fx + 1e-10) + self.scaling.unsqueeze(0) if want_jac else None
+        return z, log_jac
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, x, method=None, x0=None, context=None):
+        return self._transform(x, context, x0, want_jac=False)[0]
+
+    def compute_log_jac(self, x, context=None):
+        h = self.net.make_embeding(x, context)
+        jac = self.net.parallel_nets(x, h)
+        return torch.log(jac + 1e-10) + self.scaling.unsqueeze(0).expand(x.shape[0], -1)
+
+    def compute_log_jac_bis(self, x, context=None):
+        return self._transform(x, context)
+
+    def compute_ll(self, x, context=None):
+        z, log_jac = self._transform(x, context)
+        z.clamp_(-10., 10.)
+        log_prob_gauss = -.5 * (torch.log(self.pi * 2) + z ** 2).sum(1)
+        return log_prob_gauss + log_jac.sum(1), z
+
+    def compute_ll_bis(self, x, context=None):
+        z, log_jac = self._transform(x, context)
+        z.clamp_(-10., 10.)
+        return log_jac, z
+
+    def compute_bpp(self, x, alpha=1e-6, context=None):
+        d = x.shape[1]
+        ll, z = self.compute_ll(x, context=context)
+        bpp = -ll / (d * np.log(2)) - np.log2(1 - 2 * alpha) + 8 \
+            + 1 / d * (torch.log2(torch.sigmoid(x)) + torch.log2(1 - torch.sigmoid(x))).sum(1)
+        z.clamp_(-10., 10.)
+        return bpp, ll, z
+
+    def set_steps_nb(self, nb_steps):
+        self.nb_steps = nb_steps
+        # keep the registered tables in step (the reference leaves them stale and then crashes in
+        # eval + CCParallel, UMNNMAF.py:48-50,104-106,172-173)
+        w, s = compute_cc_weights(nb_steps)
+        self.cc_weights = w.clone().to(self.cc_weights.device)
+        self.cc_steps = s.clone().to(self.cc_steps.device)
+
+    def compute_lipschitz(self, nb_iter=10):
+        return self.net.parallel_nets.compute_lipschitz(nb_iter)
+
+    def force_lipschitz(self, L=1.5):
+        self.net.parallel_nets.force_lipschitz(L)
+
+    computeLL = compute_ll
+    computell = compute_ll
+    computeLipshitz = compute_lipschitz
+    forceLipshitz = force_lipschitz
+    forcei_lpschitz = force_lipschitz
+
+    # ------------------------------------------------------------------ inversion (sampling), row f3
+    def _conditional_integral(self, cand, h_j):
+        """int_0^cand f(t; h_j) dt for one dimension: cand [R,1], h_j [R,E] -> [R,1]."""
+        integrand = self.net.parallel_nets
+        spec = mlp_spec(integrand)
+        if _I._use_hip(spec, cand):
+            return _I.hip_forward(spec, None, cand, h_j, self.nb_steps)[0]
+        with torch.no_grad():
+            return _I.aten_forward(lambda t, hh: integrand.independant_forward(torch.cat((t, hh), 1)),
+                                   torch.zeros_like(cand), cand, h_j, self.nb_steps)
+
+    def invert(self, z, iter=10, context=None):
+        """Dimension-by-dimension bracket search: 10 candidates per round on [left,right] (starting at +-50), keep
+        the sub-interval next to the candidate whose image is closest to the target (UMNNMAF.py:182-232)."""
+        K = 10
+        B, d = z.shape
+        dev = z.device
+        frac = torch.linspace(0., 1., K, device=dev).view(K, 1)
+        x_inv = torch.zeros(B, d, device=dev)
+        scale = torch.exp(self.scaling)
+        rows = torch.arange(B, device=dev)
+        with torch.no_grad():
+            for j in range(self.input_size):
+                h = self.net.make_embeding(x_inv, context)
+                h3 = h.view(B, -1, d)
+                h_j = h3[:, :, j]                                   # [B,E]; row 0 doubles as the offset
+                offset = h_j[:, 0]
+                h_rep = h_j.unsqueeze(0).expand(K, -1, -1).reshape(K * B, -1)
+                left = torch.full((B,), -50., device=dev)
+                right = torch.full((B,), 50., device=dev)
+                best = torch.zeros(B, device=dev)
+                for _ in range(iter):
+                    cand = frac * (right - left).unsqueeze(0) + left.unsqueeze(0)          # [K,B]
+                    F = self._conditional_integral(cand.reshape(-1, 1), h_rep).view(K, B)
+                    z_est = scale[j] * (offset.unsqueeze(0) + F)
+                    m = torch.abs(z_est - z[:, j].unsqueeze(0)).argmin(0)                  # [B]
+                    below = z_est[m, rows] < z[:, j]
+                    lo = cand[(m - 1).clamp(min=0), rows]
+                    hi = cand[(m + 1).clamp(max=K - 1), rows]
+                    best = cand[m, rows]
+                    left = torch.where(below, best, lo)
+                    right = torch.where(below, hi, best)
+                x_inv[:, j] = best
+        return x_inv
+
+
+class ListModule(object):
+    """Registers modules on ``module`` as attributes ``prefix0, prefix1, ...`` and indexes them like a list."""
+
+    def __init__(self, module, prefix, *args):
+        self.module, self.prefix, self.num_module = module, prefix, 0
+        for m in args:
+            self.append(m)
+
+    def append(self, new_module):
+        if not isinstance(new_module, nn.Module):
+            raise ValueError('Not a Module')
+        self.module.add_module(self.prefix + str(self.num_module), new_module)
+        self.num_module += 1
+
+    def __len__(self):
+        return self.num_module
+
+    def __getitem__(self, i):
+        if not 0 <= i < self.num_module:
+            raise IndexError('Out of bound')
+        return getattr(self.module, self.prefix + str(i))
+
+
+class UMNNMAFFlow(nn.Module):
+    def __init__(self, nb_flow=1, nb_in=1, hidden_derivative=[50, 50, 50, 50], hidden_embedding=[50, 50, 50, 50],
+                 embedding_s=20, nb_steps=50, act_func='ELU', solver="CC", cond_in=0, device="cpu"):
+        super().__init__()
+        self.device = device
+        self.register_buffer("pi", torch.tensor(math.pi))
+        self.nets = ListModule(self, "Flow")
+        for _ in range(nb_flow):
+            emb = EmbeddingNetwork(nb_in, hidden_embedding, hidden_derivative, embedding_s, act_func=act_func,
+                                   device=device, cond_in=cond_in).to(device)
+            self.nets.append(UMNNMAF(emb, nb_in, nb_steps, device, solver=solver).to(device))
+
+    def to(self, device):
+        for net in self.nets:
+            net.to(device)
+        self.device = device
+        super().to(device)
+        return self
+
+    def _stack(self, x, context, want_jac):
+        """Run the blocks with the dimension reversal between them -> (z in original order, summed log_jac)."""
+        log_jac = 0.
+        for net in self.nets:
+            z, lj = net._transform(x, context, want_jac=want_jac)
+            if want_jac:
+                log_jac = log_jac + lj
+            x = torch.flip(z, [1])
+        return torch.flip(x, [1]), log_jac
+
+    def forward(self, x, context=None):
+        return self._stack(x, context, False)[0]
+
+    def invert(self, z, iter=10, context=None):
+        z = torch.flip(z, [1])
+        for i in range(len(self.nets) - 1, -1, -1):
+            z = self.nets[i].invert(torch.flip(z, [1]), iter, context=context)
+        return z
+
+    def compute_log_jac(self, x, context=None):
+        return self._stack(x, context, True)[1]
+
+    def compute_log_jac_bis(self, x, context=None):
+        return self._stack(x, context, True)
+
+    def compute_ll(self, x, context=None):
+        z, log_jac = self._stack(x, context, True)
+        log_prob_gauss = -.5 * (torch.log(self.pi * 2) + z ** 2).sum(1)
+        return log_jac.sum(1) + log_prob_gauss, z
+
+    def compute_ll_bis(self, x, context=None):
+        z, log_jac = self._stack(x, context, True)
+        return log_jac + -.5 * (torch.log(self.pi * 2) + z ** 2), z
+
+    def compute_bpp(self, x, alpha=1e-6, context=None):
+        d = x.shape[1]
+        ll, z = self.compute_ll(x, context=context)
+        bpp = -ll / (d * np.log(2)) - np.log2(1 - 2 * alpha) + 8 \
+            + 1 / d * (torch.log2(torch.sigmoid(x)) + torch.log2(1 - torch.sigmoid(x))).sum(1)
+        return bpp, ll, z
+
+    def set_steps_nb(self, nb_steps):
+        for net in self.nets:
+            net.set_steps_nb(nb_steps)
+
+    def compute_lipschitz(self, nb_iter=10):
+        L = 1.
+        for net in self.nets:
+            L *= net.compute_lipschitz(nb_iter)
+        return L
+
+    def force_lipschitz(self, L=1.5):
+        for net in self.nets:
+            net.force_lipschitz(L)
+
+    computell = compute_ll
+    computeLL = compute_ll
+    computeLipshitz = compute_lipschitz
+    forceLipshitz = force_lipschitz
+    forcei_lpschitz = force_lipschitz

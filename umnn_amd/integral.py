@@ -1,0 +1,333 @@
+"""The quadrature operator: ``integrate``, ``ParallelNeuralIntegral`` and ``NeuralIntegral``.
+
+Same names, argument order and gradient convention as the reference
+(models/UMNN/ParallelNeuralIntegral.py:37-123, models/UMNN/NeuralIntegral.py:37-99):
+
+    ParallelNeuralIntegral.apply(x0, x, integrand, flat_params, h, nb_steps=20, inv_f=False)
+    NeuralIntegral.apply(x0, x, integrand, flat_params, h, nb_steps=20)
+    integrate(x0, nb_steps, step_sizes, integrand, h, compute_grad=False, x_tot=None, inv_f=False, ...)
+
+backward returns (-f(x0;h)*g, f(x;h)*g, None, d_theta, d_h, None[, None]) -- the Leibniz derivatives for the
+limits and the VJP of the integrand over the nodes for theta and h, exactly the reference's formulas.
+
+Two execution paths, chosen per call, never silently:
+  * HIP: the integrand is an MLP ``nets.mlp_spec`` recognises and the tensors live on a GPU.  One fused gfx950
+    kernel per direction through the C ABI (include/umnn_cc.h).  If libumnn_cc.so is missing this raises.
+    Both solvers ("CC" sequential, "CCParallel" materialised) are the same arithmetic, so both classes land on the
+    same kernels; the node axis is never materialised.
+  * generic ATen: arbitrary callables (lambdas, custom modules -- reference tests/test_numerical_validation.py:33-41,
+    UMNNMAF.invert :207) cannot be compiled; they are integrated with torch ops on whatever device they live on,
+    in node chunks so memory stays bounded.  MLP integrands on host tensors also take this path (the kernels
+    need device memory); ``path_taken()`` reports which path the last call used so tests can assert on it.
+"""
+import ctypes
+import threading
+import warnings
+
+import torch
+
+from . import _lib
+from .nets import mlp_spec
+from .quadrature import compute_cc_weights, device_tables
+
+_state = threading.local()
+_force_generic = False
+_warned_host = False
+
+
+def path_taken():
+    """'hip' or 'aten': which path the calling thread's most recent forward/backward used."""
+    return getattr(_state, "path", None)
+
+
+class force_generic:
+    """Context manager: integrate MLP integrands with the generic ATen path too (A/B comparisons)."""
+
+    def __enter__(self):
+        global _force_generic
+        self._old, _force_generic = _force_generic, True
+
+    def __exit__(self, *exc):
+        global _force_generic
+        _force_generic = self._old
+
+
+def _flatten(sequence):
+    flat = [p.contiguous().view(-1) for p in sequence]
+    return torch.cat(flat) if len(flat) > 0 else torch.tensor([])
+
+
+# ----------------------------------------------------------------------------------------------
+# HIP path
+# ----------------------------------------------------------------------------------------------
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _desc(spec):
+    """struct umnn_mlp for the current weights (read live: optimizer steps / force_lipschitz are seen)."""
+    d = _lib.MlpDesc()
+    d.n_linear = len(spec.linears)
+    d.widths[0] = spec.linears[0].in_features
+    keep = []
+    for l, lin in enumerate(spec.linears):
+        w, b = lin.weight.detach(), lin.bias.detach()
+        if not w.is_contiguous():
+            w = w.contiguous()
+        if not b.is_contiguous():
+            b = b.contiguous()
+        keep += [w, b]
+        d.widths[l + 1] = lin.out_features
+        d.W[l], d.b[l] = w.data_ptr(), b.data_ptr()
+    d.hidden_act, d.out_act = spec.hidden_act, spec.out_act
+    return d, keep
+
+
+def _use_hip(spec, x):
+    global _warned_host
+    if spec is None or _force_generic:
+        return False
+    if not x.is_cuda:
+        if not _warned_host:
+            warnings.warn("umnn_amd: MLP integrand on host tensors -> generic ATen quadrature "
+                          "(the HIP kernels need GPU tensors; move the model and data to 'cuda').")
+            _warned_host = True
+        return False
+    if x.dtype != torch.float32:
+        return False
+    if spec.linears[0].weight.device != x.device:
+        raise RuntimeError("umnn_amd: integrand weights and inputs are on different devices")
+    return True
+
+
+def _shape(spec, x, h):
+    if x.dim() != 2 or h.dim() != 2 or h.shape[0] != x.shape[0]:
+        raise RuntimeError("umnn_amd: expected x [B,d] and h [B,E*d]")
+    B, d = x.shape
+    E = h.shape[1] // d
+    if E * d != h.shape[1] or spec.linears[0].in_features != 1 + E:
+        raise RuntimeError(f"umnn_amd: h has {h.shape[1]} columns; the integrand expects (in_features-1)*d = "
+                           f"{(spec.linears[0].in_features - 1) * d}")
+    return B, d, E
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def hip_forward(spec, x0, x, h, nb_steps, inv_f=False):
+    """-> (F, f_x, f_x0), each [B,d].  x0 may be None (zeros)."""
+    lib = _lib.lib()
+    B, d, E = _shape(spec, x, h)
+    x, h = _f32c(x), _f32c(h)
+    x0 = _f32c(x0) if x0 is not None else None
+    w, s = device_tables(nb_steps, x.device)
+    F, fx, fx0 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    desc, keep = _desc(spec)
+    with torch.cuda.device(x.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        rc = lib.umnn_cc_forward(ctypes.byref(desc), _ptr(x0), _ptr(x), _ptr(h), _ptr(w), _ptr(s), int(nb_steps),
+                                 B, d, E, int(bool(inv_f)), _ptr(F), _ptr(fx), _ptr(fx0), stream)
+    _lib.check(rc, "umnn_cc_forward")
+    _state.path = "hip"
+    return F, fx, fx0
+
+
+def hip_flow_block(spec, x, h, scaling, nb_steps):
+    """Fused block epilogue -> (z, log_jac, f_x, f_x0)."""
+    lib = _lib.lib()
+    B, d, E = _shape(spec, x, h)
+    x, h, scaling = _f32c(x), _f32c(h), _f32c(scaling)
+    w, s = device_tables(nb_steps, x.device)
+    z, lj, fx, fx0 = (torch.empty_like(x) for _ in range(4))
+    desc, keep = _desc(spec)
+    with torch.cuda.device(x.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        rc = lib.umnn_flow_block_forward(ctypes.byref(desc), _ptr(x), _ptr(h), _ptr(scaling), _ptr(w), _ptr(s),
+                                         int(nb_steps), B, d, E, _ptr(z), _ptr(lj), _ptr(fx), _ptr(fx0), stream)
+    _lib.check(rc, "umnn_flow_block_forward")
+    _state.path = "hip"
+    return z, lj, fx, fx0
+
+
+def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True)):
+    """-> (dx0, dx, dh, dtheta_flat); entries are None where need[...] is False."""
+    lib = _lib.lib()
+    B, d, E = _shape(spec, x, h)
+    x, h, g = _f32c(x), _f32c(h), _f32c(g)
+    x0 = _f32c(x0) if x0 is not None else None
+    g_fx = _f32c(g_fx) if g_fx is not None else None
+    w, s = device_tables(nb_steps, x.device)
+    dx0 = torch.empty_like(x) if need[0] else None
+    dx = torch.empty_like(x) if need[1] else None
+    dh = torch.empty_like(h) if need[2] else None
+    n_params = sum(l.weight.numel() + l.bias.numel() for l in spec.linears)
+    dtheta = torch.empty(n_params, device=x.device, dtype=torch.float32) if need[3] else None
+    desc, keep = _desc(spec)
+    with torch.cuda.device(x.device):
+        nbytes = lib.umnn_cc_backward_workspace_bytes(ctypes.byref(desc), B, d, E)
+        ws = torch.empty(max(int(nbytes), 4), device=x.device, dtype=torch.uint8)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        rc = lib.umnn_cc_backward(ctypes.byref(desc), _ptr(x0), _ptr(x), _ptr(h), _ptr(g), _ptr(g_fx),
+                                  _ptr(w), _ptr(s), int(nb_steps), B, d, E,
+                                  _ptr(dx0), _ptr(dx), _ptr(dh), _ptr(dtheta), _ptr(ws), int(nbytes), stream)
+    _lib.check(rc, "umnn_cc_backward")
+    _state.path = "hip"
+    return dx0, dx, dh, dtheta
+
+
+# ----------------------------------------------------------------------------------------------
+# generic ATen path (arbitrary callables; any device)
+# ----------------------------------------------------------------------------------------------
+_CHUNK_ELEMS = 1 << 24      # cap on rows*columns of the largest temporary per chunk of nodes
+
+
+def _node_chunks(nb_steps, rows, cols):
+    per = max(1, min(nb_steps + 1, _CHUNK_ELEMS // max(1, rows * cols)))
+    return [(a, min(a + per, nb_steps + 1)) for a in range(0, nb_steps + 1, per)]
+
+
+def _eval_chunk(integrand, x0, span, h, u):
+    """Evaluate the integrand at nodes t = x0 + span*u_c/2 for a chunk of C nodes -> ([C,B,dout], h_rep)."""
+    C, B = u.shape[0], x0.shape[0]
+    t = (x0.unsqueeze(0) + span.unsqueeze(0) * u.view(C, 1, 1) / 2).reshape(C * B, -1)
+    h_rep = h.unsqueeze(0).expand(C, -1, -1).reshape(C * B, -1)
+    return t, h_rep
+
+
+def aten_forward(integrand, x0, x, h, nb_steps, inv_f=False):
+    w, s = device_tables(nb_steps, x.device)
+    w, u = w.to(x.dtype), s.to(x.dtype) + 1
+    span = x - x0
+    total = torch.zeros_like(x)
+    B = x.shape[0]
+    for a, b in _node_chunks(nb_steps, B, h.shape[1] + x.shape[1]):
+        t, h_rep = _eval_chunk(integrand, x0, span, h, u[a:b])
+        f = integrand(t, h_rep)
+        if inv_f:
+            f = 1 / f
+        total = total + (f.view(b - a, B, -1) * w[a:b].view(-1, 1, 1)).sum(0)
+    _state.path = "aten"
+    return total * span / 2
+
+
+def aten_backward(integrand, x0, x, h, g, nb_steps, inv_f=False):
+    """d_theta (flat, parameters() order) and d_h: VJP of f over all nodes with cotangent g*(x-x0)/2*w_k."""
+    w, s = device_tables(nb_steps, x.device)
+    w, u = w.to(x.dtype), s.to(x.dtype) + 1
+    span = x - x0
+    cot = g * span / 2
+    params = [p for p in integrand.parameters()] if isinstance(integrand, torch.nn.Module) else []
+    g_params = [torch.zeros_like(p) for p in params]
+    g_h = torch.zeros_like(h)
+    B = x.shape[0]
+    for a, b in _node_chunks(nb_steps, B, h.shape[1] + x.shape[1]):
+        t, h_rep = _eval_chunk(integrand, x0, span, h, u[a:b])
+        h_rep = h_rep.detach().requires_grad_(True)
+        with torch.enable_grad():
+            f = integrand(t.detach(), h_rep)
+            if inv_f:
+                f = 1 / f
+            cot_c = (cot.unsqueeze(0) * w[a:b].view(-1, 1, 1)).reshape(f.shape)
+            grads = torch.autograd.grad(f, params + [h_rep], cot_c, allow_unused=True)
+        for acc, gr in zip(g_params, grads[:-1]):
+            if gr is not None:
+                acc += gr
+        if grads[-1] is not None:
+            g_h += grads[-1].view(b - a, B, -1).sum(0)
+    _state.path = "aten"
+    return (_flatten(g_params) if params else None), g_h
+
+
+# ----------------------------------------------------------------------------------------------
+# reference-shaped public API
+# ----------------------------------------------------------------------------------------------
+def integrate(x0, nb_steps, step_sizes, integrand, h, compute_grad=False, x_tot=None, inv_f=False,
+              cc_weights=None, steps=None):
+    """Clenshaw-Curtis quadrature of ``integrand`` from x0 to x0 + nb_steps*step_sizes.
+
+    compute_grad=False -> the integral [B,d].  compute_grad=True -> (d_theta_flat, d_h) for cotangent ``x_tot``
+    (what the reference's backward consumes).  ``cc_weights``/``steps`` are accepted for signature parity; the
+    tables are a pure function of nb_steps and come from the per-device cache."""
+    x = x0 + nb_steps * step_sizes
+    spec = mlp_spec(integrand)
+    if not compute_grad:
+        if _use_hip(spec, x):
+            return hip_forward(spec, x0, x, h, nb_steps, inv_f)[0]
+        with torch.no_grad():
+            return aten_forward(integrand, x0, x, h, nb_steps, inv_f)
+    if _use_hip(spec, x) and not inv_f:
+        _, _, dh, dtheta = hip_backward(spec, x0, x, h, x_tot, None, nb_steps, need=(False, False, True, True))
+        return dtheta, dh
+    return aten_backward(integrand, x0, x, h, x_tot, nb_steps, inv_f)
+
+
+def _op_forward(ctx, x0, x, integrand, h, nb_steps, inv_f):
+    ctx.integrand, ctx.nb_steps, ctx.inv_f = integrand, nb_steps, inv_f
+    spec = mlp_spec(integrand)
+    ctx.spec = spec
+    # clones: callers mutate their tensors in place after the call (UMNNMAF.compute_ll clamps z, :150)
+    ctx.save_for_backward(x0.clone(), x.clone(), h)
+    if _use_hip(spec, x):
+        return hip_forward(spec, x0, x, h, nb_steps, inv_f)[0]
+    return aten_forward(integrand, x0, x, h, nb_steps, inv_f)
+
+
+def _op_backward(ctx, grad_output):
+    x0, x, h = ctx.saved_tensors
+    integrand, nb_steps, inv_f, spec = ctx.integrand, ctx.nb_steps, ctx.inv_f, ctx.spec
+    if _use_hip(spec, x) and not inv_f:
+        need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[4], ctx.needs_input_grad[3])
+        dx0, dx, dh, dtheta = hip_backward(spec, x0, x, h, grad_output, None, nb_steps, need)
+        return dx0, dx, dtheta, dh
+    dtheta, dh = aten_backward(integrand, x0, x, h, grad_output, nb_steps, inv_f)
+    with torch.no_grad():
+        dx = integrand(x, h) * grad_output
+        dx0 = -integrand(x0, h) * grad_output
+    return dx0, dx, dtheta, dh.view(h.shape)
+
+
+class ParallelNeuralIntegral(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x, integrand, flat_params, h, nb_steps=20, inv_f=False):
+        return _op_forward(ctx, x0, x, integrand, h, nb_steps, inv_f)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        dx0, dx, dtheta, dh = _op_backward(ctx, grad_output)
+        return dx0, dx, None, dtheta, dh, None, None
+
+
+class NeuralIntegral(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x, integrand, flat_params, h, nb_steps=20):
+        return _op_forward(ctx, x0, x, integrand, h, nb_steps, False)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        dx0, dx, dtheta, dh = _op_backward(ctx, grad_output)
+        return dx0, dx, None, dtheta, dh, None
+
+
+class IntegralWithJacobian(torch.autograd.Function):
+    """(F, f_x) = (int_{x0}^{x} f, f(x;h)) in one kernel pass, differentiable in both outputs.
+
+    This is what a UMNNMAF block needs (z from F, log-det from f_x); the reference obtains f_x from a second
+    integrand evaluation and a second MADE pass (UMNNMAF.py:136-139).  HIP path only."""
+
+    @staticmethod
+    def forward(ctx, x0, x, integrand, flat_params, h, nb_steps):
+        spec = mlp_spec(integrand)
+        if not _use_hip(spec, x):
+            raise RuntimeError("IntegralWithJacobian needs an MLP integrand on a GPU")
+        ctx.spec, ctx.nb_steps = spec, nb_steps
+        ctx.save_for_backward(x0.clone(), x.clone(), h)
+        F, fx, _ = hip_forward(spec, x0, x, h, nb_steps, False)
+        return F, fx
+
+    @staticmethod
+    def backward(ctx, gF, gfx):
+        x0, x, h = ctx.saved_tensors
+        need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[4], ctx.needs_input_grad[3])
+        dx0, dx, dh, dtheta = hip_backward(ctx.spec, x0, x, h, gF, gfx, ctx.nb_steps, need)
+        return dx0, dx, None, dtheta, dh, None

@@ -1,0 +1,68 @@
+"""Batch sharding across the GPUs of one node: one process per GPU, contiguous row shards, replicated
+weights.  The forward integral needs NO collective -- every (sample, dimension) integral is independent given h,
+and h depends only on that sample.  Training adds exactly one flattened all-reduce of the parameter gradients
+(RCCL over xGMI through torch.distributed's "nccl" backend; "gloo" in the CPU tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Join the process group torchrun described in the environment.  Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world,
+                                **({"device_id": device} if use_gpu else {}))
+    return rank, world, device
+
+
+def shard_bounds(n_rows, rank, world):
+    """Contiguous [lo, hi) of the rows rank owns; shards differ by at most one row."""
+    base, extra = divmod(n_rows, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_rows(t, rank, world):
+    lo, hi = shard_bounds(t.shape[0], rank, world)
+    return t[lo:hi]
+
+
+def allreduce_gradients(module, world=None, average=True):
+    """One flattened all-reduce(SUM) over every trainable gradient (a few MB: latency-bound on xGMI, so one
+    message is the right shape), then scatter back.  Call after backward and BEFORE gradient clipping so that
+    clipping sees the same global gradient a single process would (UCIExperiments.py:143)."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return
+    params = [p for p in module.parameters() if p.requires_grad]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= world
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p))
+        off += n
+
+
+def broadcast_parameters(module, src=0):
+    """Make every replica start from rank src's weights (and buffers)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
