@@ -323,3 +323,25 @@ def monotonic_forward(integrand_net, cond_Ws, cond_bs, x, h, nb_steps):
     offset, scaling = a[:, [0]], np.exp(a[:, [1]])
     F = integrate_parallel(integrand_net, np.zeros_like(x), x, h, nb_steps)
     return scaling * F + offset
+
+
+def integrand_vjp(net, x, h, cot):
+    """VJP of f(x;h) [B,d] with cotangent ``cot``: what plain autograd through IntegrandNetwork.forward gives the
+    reference for the log-det term (UMNNMAF.py:138,143,148).  -> (dx, dh, flat dtheta)."""
+    B, d = x.shape
+    E = h.shape[1] // d
+    rows = rows_from(x, h, d)
+    _, pres, acts = mlp_rows(net, rows, keep=True)
+    L = len(net.Ws)
+    delta = (cot.reshape(-1) * _out_grad(pres[-1][:, 0], net.out_act))[:, None]
+    dWs, dbs = [None] * L, [None] * L
+    for l in range(L - 1, -1, -1):
+        dWs[l] = delta.T @ acts[l]
+        dbs[l] = delta.sum(0)
+        if l > 0:
+            delta = (delta @ net.Ws[l]) * _hidden_grad(pres[l - 1], net.hidden_act)
+    d_rows = delta @ net.Ws[0]                       # [B*d, 1+E], rows ordered (b, i)
+    dx = d_rows[:, 0].reshape(B, d)
+    dh = d_rows[:, 1:].reshape(B, d, E).transpose(0, 2, 1).reshape(B, E * d)
+    flat = np.concatenate([np.concatenate([dW.reshape(-1), db.reshape(-1)]) for dW, db in zip(dWs, dbs)])
+    return dx, dh, flat

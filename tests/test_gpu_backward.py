@@ -1,0 +1,165 @@
+"""Parity of the HIP backward path against the reference's custom-backward gradients (golden) and the oracle.
+
+Gradient tensors span many magnitudes, so d_h and d_theta are compared as max|d| / max|ref| <= 1e-4 (the
+reference's own noise between its two solvers is ~1e-6 on these vectors); d_x, d_x0 use the F criterion.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cc_oracle as O
+from tests import _util as U
+from tests.test_gpu_forward import build_integrand, t
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("name", U.g2_names())
+def test_backward_matches_golden(name, dev):
+    from umnn_amd import integral as I, _lib
+    from umnn_amd.nets import mlp_spec
+    G = U.load(name)
+    net = build_integrand(G, dev)
+    spec = mlp_spec(net)
+    dx0, dx, dh, dth = I.hip_backward(spec, t(G["x0"], dev), t(G["x"], dev), t(G["h"], dev), t(G["g"], dev), None,
+                                      int(G["n"]))
+    torch.cuda.synchronize()
+    assert "cc_bwd" in _lib.lib().umnn_last_kernel_name().decode()
+    assert U.rel_err(dx0.cpu().numpy(), G["dx0_par"]) < TOL
+    assert U.rel_err(dx.cpu().numpy(), G["dx_par"]) < TOL
+    assert U.scaled_err(dh.cpu().numpy(), G["dh_par"]) < TOL
+    assert U.scaled_err(dth.cpu().numpy(), G["dtheta_par"]) < TOL
+    assert U.scaled_err(dth.cpu().numpy(), G["dtheta_seq"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["g2_power_d6_w2", "g2_toy_d2_w2", "g2_sigmoid_d4", "g2_mnist_mixed_d8", "g2_odd_n_d3"])
+def test_backward_with_jacobian_cotangent(name, dev):
+    """g_fx (cotangent of the f(x;h) output): VJP at node 0 incl. d f/d x, against the oracle's manual backprop."""
+    from umnn_amd import integral as I
+    from umnn_amd.nets import mlp_spec
+    G = U.load(name)
+    net = build_integrand(G, dev)
+    onet = U.net_from_g2(G)
+    rng = np.random.RandomState(7)
+    gfx = rng.randn(*G["x"].shape).astype(np.float32)
+    n = int(G["n"])
+    dx0, dx, dh, dth = I.hip_backward(mlp_spec(net), t(G["x0"], dev), t(G["x"], dev), t(G["h"], dev), t(G["g"], dev),
+                                      t(gfx, dev), n)
+    rdx0, rdx, rdh, _, _, rflat = O.integrate_backward(onet, G["x0"], G["x"], G["h"], n, G["g"])
+    jdx, jdh, jflat = O.integrand_vjp(onet, G["x"], G["h"], gfx)
+    assert U.rel_err(dx0.cpu().numpy(), rdx0) < TOL
+    assert U.scaled_err(dx.cpu().numpy(), rdx + jdx) < TOL
+    assert U.scaled_err(dh.cpu().numpy(), rdh + jdh) < TOL
+    assert U.scaled_err(dth.cpu().numpy(), rflat + jflat) < TOL
+
+
+def test_backward_ragged_and_deep(dev):
+    """Tile-ragged batch (111 integrals), 7 hidden layers (two dW passes), ReLU."""
+    from umnn_amd import integral as I, _lib
+    from umnn_amd.nets import MlpSpec
+    rng = np.random.RandomState(3)
+    B, d, E, n = 37, 3, 2, 12
+    sizes = [1 + E] + [24, 16, 40, 8, 33, 20, 12] + [1]
+    Ws = [(rng.randn(sizes[i + 1], sizes[i]) * (1.5 / np.sqrt(sizes[i]))).astype(np.float32) for i in range(len(sizes) - 1)]
+    bs = [(rng.randn(sizes[i + 1]) * 0.3).astype(np.float32) for i in range(len(sizes) - 1)]
+    lin = []
+    for W, b in zip(Ws, bs):
+        m = torch.nn.Linear(W.shape[1], W.shape[0])
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(W))
+            m.bias.copy_(torch.from_numpy(b))
+        lin.append(m.to(dev))
+    spec = MlpSpec(lin, _lib.ACT_RELU, _lib.OUT_ELU_PLUS_ONE)
+    x = (rng.randn(B, d) * 2).astype(np.float32)
+    x0 = (rng.randn(B, d) * 0.5).astype(np.float32)
+    h = rng.randn(B, E * d).astype(np.float32)
+    g = rng.randn(B, d).astype(np.float32)
+    onet = O.Net(Ws, bs, O.RELU, O.ELU1)
+    dx0, dx, dh, dth = I.hip_backward(spec, t(x0, dev), t(x, dev), t(h, dev), t(g, dev), None, n)
+    rdx0, rdx, rdh, _, _, rflat = O.integrate_backward(onet, x0, x, h, n, g)
+    assert U.rel_err(dx0.cpu().numpy(), rdx0) < TOL and U.rel_err(dx.cpu().numpy(), rdx) < TOL
+    assert U.scaled_err(dh.cpu().numpy(), rdh) < TOL
+    assert U.scaled_err(dth.cpu().numpy(), rflat) < TOL
+
+
+def test_autograd_function_matches_reference_api(dev):
+    """ParallelNeuralIntegral.apply / NeuralIntegral.apply through autograd (reference tests/test_jit.py:12-86 shape)."""
+    import umnn_amd
+    G = U.load("g2_jit_d5")
+    net = build_integrand(G, dev)
+    for Fn, extra, tag in ((umnn_amd.ParallelNeuralIntegral, (False,), "par"), (umnn_amd.NeuralIntegral, (), "seq")):
+        net.zero_grad()
+        x0 = t(G["x0"], dev).requires_grad_()
+        x = t(G["x"], dev).requires_grad_()
+        h = t(G["h"], dev).requires_grad_()
+        flat = torch.cat([p.contiguous().view(-1) for p in net.parameters()])
+        out = Fn.apply(x0, x, net, flat, h, int(G["n"]), *extra)
+        assert umnn_amd.path_taken() == "hip"
+        out.backward(t(G["g"], dev))
+        assert U.rel_err(out.detach().cpu().numpy(), G[f"Fapply_{tag}"]) < TOL
+        assert U.rel_err(x.grad.cpu().numpy(), G[f"dx_{tag}"]) < TOL
+        assert U.rel_err(x0.grad.cpu().numpy(), G[f"dx0_{tag}"]) < TOL
+        assert U.scaled_err(h.grad.cpu().numpy(), G[f"dh_{tag}"]) < TOL
+        got = torch.cat([p.grad.view(-1) for p in net.parameters()]).cpu().numpy()
+        assert U.scaled_err(got, G[f"dtheta_{tag}"]) < TOL
+
+
+@pytest.mark.parametrize("name", U.g4_names())
+def test_flow_training_gradients_match_reference(name, dev):
+    """-mean(ll).backward() through the module API on the GPU vs the reference's gradients for every parameter."""
+    import umnn_amd
+    G = U.load(name)
+    m = umnn_amd.UMNNMAFFlow(nb_flow=int(G["nb_flow"]), nb_in=int(G["d"]),
+                             hidden_derivative=[int(v) for v in G["hidden_derivative"]],
+                             hidden_embedding=[int(v) for v in G["hidden_embedding"]], embedding_s=int(G["E"]),
+                             nb_steps=int(G["n"]), solver=str(G["solver"]), cond_in=int(G["cond_in"]))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in U.state_dict_of(G).items()})
+    m.to(dev).train()
+    x = t(G["x"], dev).requires_grad_()
+    ctx = t(G["context"], dev) if "context" in G else None
+    ll, z = m.compute_ll(x, context=ctx)
+    assert umnn_amd.path_taken() == "hip"
+    (-ll.mean()).backward()
+    assert U.rel_err(ll.detach().cpu().numpy(), G["ll_train"]) < TOL
+    assert U.scaled_err(x.grad.cpu().numpy(), G["grad/x"]) < 2e-4
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if p.grad is not None and ("grad/" + k) in G:
+            worst = max(worst, U.scaled_err(p.grad.cpu().numpy(), G["grad/" + k]))
+    assert worst < 2e-4, worst
+
+
+@pytest.mark.parametrize("n", [50, 100])
+def test_monotonic_nn_matches_reference(n, dev):
+    import umnn_amd
+    G = U.load(f"g5_monotonic_n{n}")
+    m = umnn_amd.MonotonicNN(3, [100, 100, 100], nb_steps=n, dev=dev)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in U.state_dict_of(G).items()})
+    m.to(dev)
+    x = t(G["x"], dev).requires_grad_()
+    y = m(x, t(G["h"], dev))
+    assert umnn_amd.path_taken() == "hip"
+    (y ** 2).mean().backward()
+    assert U.rel_err(y.detach().cpu().numpy(), G["y"]) < TOL
+    assert U.scaled_err(x.grad.cpu().numpy(), G["grad/x"]) < 2e-4
+    for k, p in m.named_parameters():
+        assert U.scaled_err(p.grad.cpu().numpy(), G["grad/" + k]) < 2e-4, k
+
+
+def test_backward_deterministic(dev):
+    from umnn_amd import integral as I
+    from umnn_amd.nets import mlp_spec
+    G = U.load("g2_power_d6_w2")
+    net = build_integrand(G, dev)
+    args = (mlp_spec(net), t(G["x0"], dev), t(G["x"], dev), t(G["h"], dev), t(G["g"], dev), None, int(G["n"]))
+    a = I.hip_backward(*args)
+    b = I.hip_backward(*args)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

@@ -1,14 +1,629 @@
-// placeholder until the backward kernels land (next commit)
+// Backward of the Clenshaw-Curtis quadrature of the integrand MLP (the reference's gradient convention).
+//
+// Replaces (reference):
+//   models/UMNN/ParallelNeuralIntegral.py:66-94   integrate(compute_grad=True) + computeIntegrand:
+//        VJP of f at every node with cotangent g*(x-x0)/2*w_k  ->  d_theta (flat), d_h (summed over nodes)
+//   models/UMNN/ParallelNeuralIntegral.py:110-123 Leibniz terms d_x = f(x;h) g, d_x0 = -f(x0;h) g
+//   (NeuralIntegral.py:47-58,69-75,90-99 is the same arithmetic, node by node)
+// plus, for the fused flow block, the VJP of the extra output f_x = f(x;h) (cotangent g_fx) that the
+// reference obtains from plain autograd through IntegrandNetwork.forward (UMNNMAF.py:138,143,148).
+//
+// Structure (one launch of cc_bwd_kernel per "pass", then three small finishing kernels):
+//   * persistent waves (one per SIMD, the whole 512-register file): each wave walks tiles of 16 integrals and,
+//     per quadrature node, recomputes the forward chain on MFMA (weights: row-major padded LDS images, used for
+//     both W and W^T fragments), keeps only the SIGN BITS of the activations, back-propagates delta through
+//     W^T on MFMA, and accumulates dW_l += delta_{l+1} (x) a_l on MFMA.  That last product contracts over the
+//     16 points of the tile, which sit on the wrong lane axis, so delta and a take one trip through a
+//     wave-private LDS tile (written [feature][point], read back as b128 rows = "feature on lane&15, points on
+//     (lane>>4, r)").  dW accumulators for up to NACC hidden layers live in registers for the whole kernel;
+//   * what depends on an integral only once (not per node) leaves the kernel as dc[q][f] = sum_k delta_1: the
+//     finishing kernels turn it into d_h = W1h^T dc and dW1[:,1:], db1;
+//   * every wave writes its partial d_theta to its own slice of the workspace; a last kernel sums the slices
+//     (deterministic, no atomics).
 #include "cc_host.h"
 
-extern "C" long long umnn_cc_backward_workspace_bytes(const umnn_mlp* net, long long B, int d, int E) {
-    (void)net; (void)B; (void)d; (void)E;
+struct BwdArgs {
+    MlpDev m;
+    int ld[UMNN_MAX_LINEAR];        // row stride (floats) of the row-major image of hidden layer l -> l+1
+    int roff[UMNN_MAX_LINEAR];      // float offset of that image in LDS
+    int poffW[UMNN_MAX_LINEAR];     // offset of W_l / b_l in the flat theta vector
+    int poffb[UMNN_MAX_LINEAR];
+    const float* x0;
+    const float* x;
+    const float* h;
+    const float* g;
+    const float* gfx;               // nullable
+    const float* ccw;
+    const float* ccs;
+    float* dx0;                     // nullable
+    float* dx;                      // nullable
+    float* dc;                      // [NI][H1] (EDGE pass)
+    float* partials;                // [nwaves][n_params]
+    long long NI;
+    int d, E, n;
+    unsigned ngroups;               // tiles of 16 integrals
+    int l_lo;                       // this pass accumulates dW for hidden layers l_lo .. l_lo+NACC-1
+    int n_params;
+    int scratch_off;                // float offset of the per-wave scratch region in LDS
+    int scratch_per_wave;           // floats
+};
+
+// permutation that turns an accumulator row (lane&15 in an A operand) into a feature offset inside a tile
+__device__ __forceinline__ int perm16(int rho) { return 4 * (rho & 3) + (rho >> 2); }
+
+__device__ __forceinline__ void stage_rowmajor_images(const BwdArgs& a, float* lds, int tid, int nthreads) {
+    const MlpDev& m = a.m;
+    const int L = m.n_linear - 1;
+    for (int l = 1; l < L; ++l) {
+        const int Hin = m.width[l], Hout = m.width[l + 1];
+        const int rows = 16 * m.t_out[l + 1], LD = a.ld[l];
+        const float* __restrict__ W = m.W[l];
+        const float* __restrict__ b = m.b[l];
+        float* img = lds + a.roff[l];
+        for (int idx = tid; idx < rows * LD; idx += nthreads) {
+            const int fo = idx / LD, fi = idx - fo * LD;
+            float v = 0.f;
+            if (fo < Hout) {
+                if (fi < Hin) v = W[fo * Hin + fi];
+                else if (fi == Hin) v = b[fo];
+            } else if (fo == Hout && fi == Hin) {
+                v = 1.f;
+            }
+            img[idx] = v;
+        }
+    }
+}
+
+// out[t] = sum_s W-fragment(t, s) * in[s]   (forward orientation; image row = output feature)
+template <int TMAX>
+__device__ __forceinline__ void layer_fwd(const float* wf, int LD, int ks, int to, const f32x4 (&in)[TMAX],
+                                          f32x4 (&out)[TMAX]) {
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) out[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4 * TMAX; ++s) {
+        if (s < ks) {
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < to) out[t] = mfma16(wf[16 * t * LD + 4 * s], in[s >> 2][s & 3], out[t]);
+        }
+    }
+}
+
+// out[t] = sum_s W^T-fragment(t, s) * in[s]   (backward orientation; image row = K index)
+template <int TMAX>
+__device__ __forceinline__ void layer_bwd(const float* wt, int LD, int ks, int to, const f32x4 (&in)[TMAX],
+                                          f32x4 (&out)[TMAX]) {
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) out[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4 * TMAX; ++s) {
+        if (s < ks) {
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < to) out[t] = mfma16(wt[4 * s * LD + 16 * t], in[s >> 2][s & 3], out[t]);
+        }
+    }
+}
+
+template <int TMAX>
+__device__ __forceinline__ unsigned sign_bits(const f32x4 (&v)[TMAX]) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bits |= (v[t][r] > 0.f ? 1u : 0u) << (4 * t + r);
+    return bits;
+}
+
+template <int TMAX, int NACC, bool EDGE>
+__global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MlpDev& m = a.m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, p = lane & 15;
+    const int L = m.n_linear - 1;
+    const int H1 = m.width[1], HL = m.width[L];
+    const int E = a.E, d = a.d, n = a.n;
+    const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
+    constexpr int NA = NACC > 0 ? NACC : 1;
+
+    stage_rowmajor_images(a, lds, tid, UMNN_BLOCK);
+    __syncthreads();
+
+    float* scratch = lds + a.scratch_off + wid * a.scratch_per_wave;   // [NACC a-tiles | 1 delta tile] x (TMAX*256)
+    float* s_delta = scratch + NACC * (TMAX * 256);
+    const int wr_off = g * 16 + p;                 // + (16t+4r)*16 : standard-layout write
+    const int rd_off = (lane & 15) * 16 + 4 * g;   // + 16t*16      : transposed b128 read
+
+    // per-lane constants
+    float w1x[TMAX][4], wout[TMAX][4];
+    {
+        const float* __restrict__ W0 = m.W[0];
+        const float* __restrict__ WL = m.W[L];
+        const float bL = m.b[L][0];
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = feat_of(t, r, g);
+                w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
+                wout[t][r] = f < HL ? WL[f] : (f == HL ? bL : 0.f);
+            }
+    }
+
+    // accumulators that live for the whole kernel
+    f32x4 dW[NA][TMAX][TMAX];
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+#pragma unroll
+        for (int to = 0; to < TMAX; ++to)
+#pragma unroll
+            for (int ti = 0; ti < TMAX; ++ti) dW[j][to][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 dW1x[TMAX], dwo[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) { dW1x[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dwo[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const unsigned wave_global = blockIdx.x * UMNN_WAVES_PER_BLOCK + wid;
+    const unsigned nwaves = gridDim.x * UMNN_WAVES_PER_BLOCK;
+
+    for (unsigned grp = wave_global; grp < a.ngroups; grp += nwaves) {
+        const long long q = (long long)grp * 16 + p;
+        const bool ok = q < a.NI;
+        const long long qq = ok ? q : a.NI - 1;
+        const float xv = a.x[qq];
+        const float x0v = a.x0 ? a.x0[qq] : 0.f;
+        const float dxv = xv - x0v;
+        const float gv = ok ? a.g[qq] : 0.f;                       // dead lanes contribute nothing
+        const float gfxv = (ok && a.gfx) ? a.gfx[qq] : 0.f;
+        const float cotbase = gv * dxv * 0.5f;
+        const long long bi = qq / d;
+        const float* hb = a.h + bi * ((long long)E * d) + (qq - bi * d);
+
+        // hoisted first-layer term (same as the forward kernel)
+        f32x4 c[TMAX];
+        {
+            const float* __restrict__ W0 = m.W[0];
+            const float* __restrict__ b0 = m.b[0];
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = feat_of(t, r, g);
+                    c[t][r] = f < H1 ? b0[f] : (f == H1 ? 1.f : 0.f);
+                }
+            for (int se = 0; se < (E + 3) / 4; ++se) {
+                const int e = 4 * se + g;
+                const float hv = e < E ? hb[(long long)e * d] : 0.f;
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t) {
+                    if (t < m.t_out[1]) {
+                        const int fo = fout_of(t, p);
+                        const float A = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
+                        c[t] = mfma16(A, hv, c[t]);
+                    }
+                }
+            }
+        }
+
+        f32x4 dcs[TMAX];
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float fxv = 0.f, fx0v = 0.f, dfdt = 0.f;
+
+        for (int k = 0; k <= n; ++k) {
+            const float u = a.ccs[k] + 1.f;
+            const float wk = a.ccw[k];
+            const float tk = k == 0 ? xv : __fadd_rn(x0v, __fmul_rn(dxv, u) * 0.5f);
+            unsigned bits[UMNN_MAX_LINEAR];          // bits[l]: sign bits of hidden layer l's activation
+            f32x4 act[TMAX];
+            // ---------------- forward recompute ----------------
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) act[t][r] = hidden_act_f(fmaf(w1x[t][r], tk, c[t][r]), slope);
+            bits[1] = sign_bits<TMAX>(act);
+            for (int l = 1; l < L; ++l) {
+                // a_l is the input of image l: park it for the dW product if this pass owns layer l
+#pragma unroll
+                for (int j = 0; j < NACC; ++j)
+                    if (l == a.l_lo + j) {
+#pragma unroll
+                        for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) scratch[j * (TMAX * 256) + (16 * t + 4 * r) * 16 + wr_off] = act[t][r];
+                    }
+                f32x4 acc[TMAX];
+                layer_fwd<TMAX>(lds + a.roff[l] + perm16(p) * a.ld[l] + g, a.ld[l], m.ks_in[l], m.t_out[l + 1], act, acc);
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) act[t][r] = t < m.t_out[l + 1] ? hidden_act_f(acc[t][r], slope) : 0.f;
+                bits[l + 1] = sign_bits<TMAX>(act);
+            }
+            float sdot = 0.f;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sdot = fmaf(wout[t][r], act[t][r], sdot);
+            sdot = group_allreduce(sdot);
+            const float f = out_act_f(sdot, m.out_act);
+            const float fp = out_grad_f(sdot, m.out_act);
+            if (k == 0) fxv = f;
+            if (k == n) fx0v = f;
+
+            // ---------------- tangent pass at node 0: d f / d x for the g_fx term ----------------
+            if (EDGE && k == 0 && a.gfx) {
+                f32x4 ta[TMAX];
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ta[t][r] = w1x[t][r] * ((bits[1] >> (4 * t + r)) & 1u ? 1.f : slope);
+                for (int l = 1; l < L; ++l) {
+                    f32x4 tz[TMAX];
+                    layer_fwd<TMAX>(lds + a.roff[l] + perm16(p) * a.ld[l] + g, a.ld[l], m.ks_in[l], m.t_out[l + 1], ta, tz);
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            ta[t][r] = t < m.t_out[l + 1] ? tz[t][r] * ((bits[l + 1] >> (4 * t + r)) & 1u ? 1.f : slope) : 0.f;
+                }
+                float ds = 0.f;
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds = fmaf(wout[t][r], ta[t][r], ds);
+                dfdt = fp * group_allreduce(ds);
+            }
+
+            // ---------------- backward sweep ----------------
+            const float cot = fmaf(cotbase, wk, k == 0 ? gfxv : 0.f);
+            const float dout = cot * fp;
+            f32x4 delta[TMAX];
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (EDGE) dwo[t][r] = fmaf(dout, act[t][r], dwo[t][r]);
+                    delta[t][r] = dout * wout[t][r] * ((bits[L] >> (4 * t + r)) & 1u ? 1.f : slope);
+                }
+            for (int l = L - 1; l >= 1; --l) {
+                // dW_l += delta_{l+1} (x) a_l  (contract over the 16 points through the LDS transpose)
+#pragma unroll
+                for (int j = 0; j < NACC; ++j)
+                    if (l == a.l_lo + j) {
+#pragma unroll
+                        for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s_delta[(16 * t + 4 * r) * 16 + wr_off] = delta[t][r];
+                        f32x4 dT[TMAX], aT[TMAX];
+#pragma unroll
+                        for (int t = 0; t < TMAX; ++t) {
+                            dT[t] = *reinterpret_cast<const f32x4*>(s_delta + 16 * t * 16 + rd_off);
+                            aT[t] = *reinterpret_cast<const f32x4*>(scratch + j * (TMAX * 256) + 16 * t * 16 + rd_off);
+                        }
+#pragma unroll
+                        for (int to = 0; to < TMAX; ++to)
+                            if (to < m.t_out[l + 1]) {
+#pragma unroll
+                                for (int ti = 0; ti < TMAX; ++ti)
+                                    if (ti < m.t_out[l]) {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r)
+                                            dW[j][to][ti] = mfma16(dT[to][r], aT[ti][r], dW[j][to][ti]);
+                                    }
+                            }
+                    }
+                // delta_l = (W_l^T delta_{l+1}) * act'(z_l)
+                f32x4 nd[TMAX];
+                layer_bwd<TMAX>(lds + a.roff[l] + g * a.ld[l] + perm16(p), a.ld[l], m.ks_in[l + 1], m.t_out[l], delta, nd);
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        delta[t][r] = t < m.t_out[l] ? nd[t][r] * ((bits[l] >> (4 * t + r)) & 1u ? 1.f : slope) : 0.f;
+            }
+            if (EDGE) {
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dcs[t][r] += delta[t][r];
+                        dW1x[t][r] = fmaf(delta[t][r], tk, dW1x[t][r]);
+                    }
+            }
+        }
+
+        if (EDGE && ok) {
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = feat_of(t, r, g);
+                    if (f < H1) a.dc[q * H1 + f] = dcs[t][r];
+                }
+            if (g == 0) {
+                if (a.dx) a.dx[q] = fmaf(gfxv, dfdt, fxv * gv);
+                if (a.dx0) a.dx0[q] = -fx0v * gv;
+            }
+        }
+    }
+
+    // ---------------- write this wave's partial d_theta ----------------
+    float* part = a.partials + (size_t)wave_global * a.n_params;
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) {
+        const int l = a.l_lo + j;
+        if (l < L) {
+            const int Hin = m.width[l], Hout = m.width[l + 1];
+#pragma unroll
+            for (int to = 0; to < TMAX; ++to)
+#pragma unroll
+                for (int ti = 0; ti < TMAX; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int fo = 16 * to + 4 * g + r, fi = 16 * ti + (lane & 15);
+                        if (fo < Hout) {
+                            if (fi < Hin) part[a.poffW[l] + fo * Hin + fi] = dW[j][to][ti][r];
+                            else if (fi == Hin) part[a.poffb[l] + fo] = dW[j][to][ti][r];
+                        }
+                    }
+        }
+    }
+    if (EDGE) {
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v1 = dW1x[t][r], v2 = dwo[t][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { v1 += __shfl_xor(v1, o); v2 += __shfl_xor(v2, o); }
+                const int f = feat_of(t, r, g);
+                if (p == 0) {
+                    if (f < H1) part[a.poffW[0] + f * (1 + E)] = v1;
+                    if (f < HL) part[a.poffW[L] + f] = v2;
+                    else if (f == HL) part[a.poffb[L]] = v2;
+                }
+            }
+    }
+}
+
+// d_h[b, e*d+i] = sum_f W1[f][1+e] dc[q][f]
+__global__ __launch_bounds__(256) void cc_bwd_dh_kernel(const float* __restrict__ dc, const float* __restrict__ W0,
+                                                        float* __restrict__ dh, long long NI, int d, int E, int H1) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sW = sm;                       // [H1][E]
+    float* sdc = sm + H1 * E;             // [64][H1+1]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < H1 * E; i += 256) { const int f = i / E, e = i - f * E; sW[i] = W0[f * (1 + E) + 1 + e]; }
+    const long long q0 = (long long)blockIdx.x * 64;
+    const int nq = (int)min((long long)64, NI - q0);
+    for (int i = tid; i < nq * H1; i += 256) { const int ql = i / H1, f = i - ql * H1; sdc[ql * (H1 + 1) + f] = dc[q0 * H1 + i]; }
+    __syncthreads();
+    for (int o = tid; o < nq * E; o += 256) {
+        const int e = o / nq, ql = o - e * nq;      // ql fastest: consecutive threads -> consecutive i
+        float s = 0.f;
+        for (int f = 0; f < H1; ++f) s = fmaf(sW[f * E + e], sdc[ql * (H1 + 1) + f], s);
+        const long long q = q0 + ql, bi = q / d;
+        dh[bi * ((long long)E * d) + (long long)e * d + (q - bi * d)] = s;
+    }
+}
+
+// partial[blk][f][e] = sum_{q in chunk} dc[q][f] * hext[q][e],  hext[q][E] = 1  (-> dW1[:,1:], db1)
+__global__ __launch_bounds__(256) void cc_bwd_dw0_kernel(const float* __restrict__ dc, const float* __restrict__ h,
+                                                         float* __restrict__ partial, long long NI, int d, int E,
+                                                         int H1, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sdc = sm;                          // [chunk][H1]
+    float* sh = sm + chunk * H1;              // [chunk][E+1]
+    const int tid = threadIdx.x;
+    const long long q0 = (long long)blockIdx.x * chunk;
+    const int nq = (int)min((long long)chunk, NI - q0);
+    for (int i = tid; i < nq * H1; i += 256) sdc[i] = dc[q0 * H1 + i];
+    for (int i = tid; i < nq * (E + 1); i += 256) {
+        const int e = i / nq, ql = i - e * nq;
+        const long long q = q0 + ql, bi = q / d;
+        sh[ql * (E + 1) + e] = e < E ? h[bi * ((long long)E * d) + (long long)e * d + (q - bi * d)] : 1.f;
+    }
+    __syncthreads();
+    const int nout = H1 * (E + 1);
+    for (int o = tid; o < nout; o += 256) {
+        const int f = o / (E + 1), e = o - f * (E + 1);
+        float s = 0.f;
+        for (int ql = 0; ql < nq; ++ql) s = fmaf(sdc[ql * H1 + f], sh[ql * (E + 1) + e], s);
+        partial[(size_t)blockIdx.x * nout + o] = s;
+    }
+}
+
+// dtheta[i] = sum_w partials[w][i]  (+ first-layer slices from the dw0 partials)
+__global__ __launch_bounds__(256) void cc_bwd_reduce_kernel(const float* __restrict__ partials, int nparts, int n_params,
+                                                            const float* __restrict__ p0, int nparts0, int E, int H1,
+                                                            int poffW0, int poffb0, float* __restrict__ dtheta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_params) return;
+    float s = 0.f;
+    for (int w = 0; w < nparts; ++w) s += partials[(size_t)w * n_params + i];
+    // is i an entry of W0[:,1:] or b0 ?  those come from the dw0 partials
+    int o = -1;
+    if (i >= poffW0 && i < poffW0 + H1 * (1 + E)) {
+        const int f = (i - poffW0) / (1 + E), col = (i - poffW0) - f * (1 + E);
+        if (col >= 1) o = f * (E + 1) + (col - 1);
+    } else if (i >= poffb0 && i < poffb0 + H1) {
+        o = (i - poffb0) * (E + 1) + E;
+    }
+    if (o >= 0) {
+        const int nout = H1 * (E + 1);
+        for (int w = 0; w < nparts0; ++w) s += p0[(size_t)w * nout + o];
+    }
+    dtheta[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+typedef void (*bwd_kernel_t)(const BwdArgs);
+struct BwdVariant { int tmax, nacc, edge; bwd_kernel_t fn; const char* name; };
+#define BWD_VARIANT(T, N, E) { T, N, E, cc_bwd_kernel<T, N, (E) != 0>, "cc_bwd<T=" #T ",NACC=" #N ",EDGE=" #E ">" }
+static const BwdVariant kBwdVariants[] = {
+    BWD_VARIANT(2, 3, 1), BWD_VARIANT(2, 3, 0),
+    BWD_VARIANT(4, 3, 1), BWD_VARIANT(4, 3, 0),
+    BWD_VARIANT(7, 0, 1), BWD_VARIANT(7, 1, 0),
+    BWD_VARIANT(8, 0, 1), BWD_VARIANT(8, 1, 0),
+};
+
+static int pick_tmax_bwd(int tmax) { return tmax <= 2 ? 2 : tmax <= 4 ? 4 : tmax <= 7 ? 7 : 8; }
+
+// row stride for the row-major image: >= cols, minimising bank conflicts of both fragment shapes
+// (forward: 16 rows x 2 adjacent cols per half-wave; backward: 2 adjacent rows x 16 cols)
+static int pick_ld(int cols) {
+    int best = cols, best_cost = 1 << 30;
+    for (int ld = cols; ld < cols + 33; ++ld) {
+        int cost = 0;
+        for (int pattern = 0; pattern < 2; ++pattern) {
+            int cnt[32] = {0};
+            for (int a16 = 0; a16 < 16; ++a16)
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    const int addr = pattern == 0 ? a16 * ld + b2 : b2 * ld + a16;
+                    cnt[((addr % 32) + 32) % 32]++;
+                }
+            int worst = 0;
+            for (int b = 0; b < 32; ++b) worst = cnt[b] > worst ? cnt[b] : worst;
+            cost += worst;
+        }
+        if (cost < best_cost) { best_cost = cost; best = ld; }
+    }
+    return best;
+}
+
+struct BwdPlan {
+    BwdArgs a;
+    int tmax;          // template tile count
+    int nwaves, nblocks;
+    size_t lds_bytes_for(int nacc) const { return (size_t)(a.scratch_off + UMNN_WAVES_PER_BLOCK * (nacc + 1) * tmax * 256) * sizeof(float); }
+    long long ws_partials, ws_dc, ws_p0;   // byte offsets in the workspace
+    long long ws_total;
+    int nparts0, chunk0;
+};
+
+static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan* pl) {
+    int tmax = 0, ksu = 0;
+    if (int rc = umnn_prepare_mlp(net, E, &pl->a.m, &tmax, &ksu)) return rc;
+    BwdArgs& a = pl->a;
+    const int L = a.m.n_linear - 1;
+    pl->tmax = pick_tmax_bwd(tmax);
+    int off = 0;
+    for (int l = 1; l < L; ++l) {
+        a.ld[l] = pick_ld(4 * a.m.ks_in[l]);
+        a.roff[l] = off;
+        off += 16 * a.m.t_out[l + 1] * a.ld[l];
+        off = (off + 3) & ~3;
+    }
+    a.scratch_off = off;
+    int po = 0;
+    for (int l = 0; l <= L; ++l) {
+        a.poffW[l] = po; po += net->widths[l + 1] * net->widths[l];
+        a.poffb[l] = po; po += net->widths[l + 1];
+    }
+    a.n_params = po;
+    a.NI = B * (long long)d; a.d = d; a.E = E;
+    a.ngroups = (unsigned)((a.NI + 15) / 16);
+    pl->nblocks = umnn_num_cus();
+    if ((long long)pl->nblocks * UMNN_WAVES_PER_BLOCK > (long long)a.ngroups)
+        pl->nblocks = (int)((a.ngroups + UMNN_WAVES_PER_BLOCK - 1) / UMNN_WAVES_PER_BLOCK);
+    if (pl->nblocks < 1) pl->nblocks = 1;
+    pl->nwaves = pl->nblocks * UMNN_WAVES_PER_BLOCK;
+    const int H1 = net->widths[1];
+    pl->chunk0 = 256;
+    while (pl->chunk0 > 16 && (size_t)pl->chunk0 * (H1 + E + 1) * sizeof(float) > 96 * 1024) pl->chunk0 /= 2;
+    pl->nparts0 = (int)((a.NI + pl->chunk0 - 1) / pl->chunk0);
+    long long o = 0;
+    pl->ws_partials = o; o += (long long)pl->nwaves * a.n_params * 4; o = (o + 255) & ~255LL;
+    pl->ws_dc = o; o += a.NI * H1 * 4; o = (o + 255) & ~255LL;
+    pl->ws_p0 = o; o += (long long)pl->nparts0 * H1 * (E + 1) * 4; o = (o + 255) & ~255LL;
+    pl->ws_total = o;
     return 0;
 }
 
-extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const float* x, const float* h, const float* g, const float* g_fx,
+extern "C" long long umnn_cc_backward_workspace_bytes(const umnn_mlp* net, long long B, int d, int E) {
+    BwdPlan pl;
+    if (B <= 0) return 0;
+    if (plan_backward(net, B, d, E, &pl)) return -1;
+    return pl.ws_total;
+}
+
+static const BwdVariant* find_bwd(int tmax, int nacc, int edge) {
+    for (const BwdVariant& v : kBwdVariants)
+        if (v.tmax == tmax && v.nacc == nacc && v.edge == edge) return &v;
+    return nullptr;
+}
+
+extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const float* x, const float* h,
+                                const float* g, const float* g_fx,
                                 const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
                                 float* dx0, float* dx, float* dh, float* dtheta,
-                                void* workspace, long long workspace_bytes, void* stream) {
-    return umnn_fail(UMNN_EUNSUPPORTED, "backward kernel not built yet");
+                                void* workspace, long long workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (B < 0 || d < 1) return umnn_fail(UMNN_EINVAL, "backward: B must be >= 0 and d >= 1");
+    if (nb_steps < 1) return umnn_fail(UMNN_EINVAL, "backward: nb_steps must be >= 1");
+    BwdPlan pl;
+    if (B == 0) {
+        if (!net) return umnn_fail(UMNN_EINVAL, "net is null");
+        if (dtheta) return umnn_check(hipMemsetAsync(dtheta, 0, umnn_param_count(net) * sizeof(float), stream), "memset");
+        return 0;
+    }
+    if (int rc = plan_backward(net, B, d, E, &pl)) return rc;
+    if (!x || !h || !g || !cc_w || !cc_s) return umnn_fail(UMNN_EINVAL, "backward: x, h, g, cc_w, cc_s must be non-null");
+    if (!workspace || workspace_bytes < pl.ws_total)
+        return umnn_fail(UMNN_EINVAL, "backward: workspace smaller than umnn_cc_backward_workspace_bytes()");
+    BwdArgs& a = pl.a;
+    const int L = a.m.n_linear - 1, H1 = net->widths[1];
+    char* ws = (char*)workspace;
+    a.x0 = x0; a.x = x; a.h = h; a.g = g; a.gfx = g_fx; a.ccw = cc_w; a.ccs = cc_s;
+    a.dx0 = dx0; a.dx = dx; a.n = nb_steps;
+    a.partials = (float*)(ws + pl.ws_partials);
+    a.dc = (float*)(ws + pl.ws_dc);
+    float* p0 = (float*)(ws + pl.ws_p0);
+    if (int rc = umnn_check(hipMemsetAsync(a.partials, 0, (size_t)pl.nwaves * a.n_params * 4, stream), "memset partials")) return rc;
+
+    // ---- passes: the EDGE pass (with as many dW layers as its variant holds), then the remaining layers
+    const int T = pl.tmax;
+    const int nacc_main = (T <= 4) ? 3 : 0;
+    const int nacc_rest = (T <= 4) ? 3 : 1;
+    int l_next = 1;
+    for (int pass = 0; pass == 0 || l_next < L; ++pass) {
+        const int nacc = pass == 0 ? nacc_main : nacc_rest;
+        const BwdVariant* v = find_bwd(T, nacc, pass == 0 ? 1 : 0);
+        if (!v) return umnn_fail(UMNN_EUNSUPPORTED, "backward: no kernel variant for this width");
+        a.l_lo = l_next;
+        a.scratch_per_wave = (nacc + 1) * T * 256;
+        const size_t lds_bytes = pl.lds_bytes_for(nacc);
+        if (lds_bytes > 160 * 1024) return umnn_fail(UMNN_EUNSUPPORTED, "backward: weight images exceed 160 KiB of LDS");
+        if (int rc = umnn_allow_lds((const void*)v->fn, lds_bytes)) return rc;
+        umnn_prof_begin(stream);
+        hipLaunchKernelGGL(v->fn, dim3(pl.nblocks), dim3(UMNN_BLOCK), lds_bytes, stream, a);
+        umnn_prof_end(stream, 0.0);
+        umnn_note_launch(v->name);
+        if (int rc = umnn_check(hipGetLastError(), "cc_bwd launch")) return rc;
+        l_next += nacc;
+    }
+
+    // ---- finishing kernels
+    if (dh) {
+        const size_t sm = ((size_t)H1 * E + 64 * (H1 + 1)) * sizeof(float);
+        const unsigned nb = (unsigned)((a.NI + 63) / 64);
+        if (int rc = umnn_allow_lds((const void*)cc_bwd_dh_kernel, sm)) return rc;
+        hipLaunchKernelGGL(cc_bwd_dh_kernel, dim3(nb), dim3(256), sm, stream, a.dc, net->W[0], dh, a.NI, d, E, H1);
+        umnn_note_launch("cc_bwd_dh");
+    }
+    if (dtheta) {
+        const size_t sm = (size_t)pl.chunk0 * (H1 + E + 1) * sizeof(float);
+        if (int rc = umnn_allow_lds((const void*)cc_bwd_dw0_kernel, sm)) return rc;
+        hipLaunchKernelGGL(cc_bwd_dw0_kernel, dim3(pl.nparts0), dim3(256), sm, stream, a.dc, h, p0, a.NI, d, E, H1, pl.chunk0);
+        hipLaunchKernelGGL(cc_bwd_reduce_kernel, dim3((a.n_params + 255) / 256), dim3(256), 0, stream,
+                           a.partials, pl.nwaves, a.n_params, p0, pl.nparts0, E, H1, a.poffW[0], a.poffb[0], dtheta);
+        umnn_note_launch("cc_bwd_reduce");
+    }
+    return umnn_check(hipGetLastError(), "cc_bwd finishing launch");
 }

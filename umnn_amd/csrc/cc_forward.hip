@@ -264,12 +264,12 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
     FwdArgs a;
     int tmax = 0, ksu = 0;
     if (int rc = umnn_prepare_mlp(net, E, &a.m, &tmax, &ksu)) return rc;
-    if (!x || !h || !cc_w || !cc_s) return umnn_fail(UMNN_EINVAL, "forward: x, h, cc_w, cc_s must be non-null");
     if (nb_steps < 1) return umnn_fail(UMNN_EINVAL, "forward: nb_steps must be >= 1");
     if (B < 0 || d < 1) return umnn_fail(UMNN_EINVAL, "forward: B must be >= 0 and d >= 1");
+    if (B == 0) return 0;      // empty batch: nothing to read or write (zero-size buffers may be null)
+    if (!x || !h || !cc_w || !cc_s) return umnn_fail(UMNN_EINVAL, "forward: x, h, cc_w, cc_s must be non-null");
     if (!scaling && !F) return umnn_fail(UMNN_EINVAL, "forward: F must be non-null");
     if (scaling && (!z || !log_jac)) return umnn_fail(UMNN_EINVAL, "flow forward: z and log_jac must be non-null");
-    if (B == 0) return 0;
 
     a.x0 = x0; a.x = x; a.h = h; a.ccw = cc_w; a.ccs = cc_s;
     a.F = F; a.fx = f_x; a.fx0 = f_x0; a.scaling = scaling; a.z = z; a.logjac = log_jac;
