@@ -1,0 +1,87 @@
+"""N>1 path on CPU: world_size-2 gloo.  Batch shards need no forward collective; training needs exactly one
+flattened gradient all-reduce, after which every replica holds the single-process gradient."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import umnn_amd
+from umnn_amd import sharding
+
+pytestmark = pytest.mark.filterwarnings("ignore")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _model():
+    torch.manual_seed(7)
+    return umnn_amd.UMNNMAFFlow(nb_flow=2, nb_in=3, hidden_derivative=[16, 16], hidden_embedding=[24, 24],
+                                embedding_s=4, nb_steps=12, solver="CCParallel")
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    r, w, device = sharding.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and device.type == "cpu"
+    model = _model()
+    if rank == 1:                                   # replicas start different; broadcast must fix that
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    sharding.broadcast_parameters(model, src=0)
+    torch.manual_seed(99)
+    x = torch.randn(10, 3)                          # the global batch, identical on every rank
+    xs = sharding.shard_rows(x, rank, world)
+    model.train()
+    ll, z = model.compute_ll(xs)                    # forward: no collective
+    (-ll.sum() / x.shape[0]).backward()             # shard's share of the global mean
+    sharding.allreduce_gradients(model, world, average=False)
+    grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    torch.save({"ll": ll.detach(), "z": z.detach(), "grads": grads, "bounds": sharding.shard_bounds(10, rank, world)},
+               os.path.join(outdir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shards_match_single_process():
+    world = 2
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        parts = [torch.load(os.path.join(out, f"r{r}.pt")) for r in range(world)]
+    model = _model()
+    torch.manual_seed(99)
+    x = torch.randn(10, 3)
+    model.train()
+    ll, z = model.compute_ll(x)
+    (-ll.mean()).backward()
+    assert [p["bounds"] for p in parts] == [(0, 5), (5, 10)]
+    assert torch.allclose(torch.cat([p["ll"] for p in parts]), ll.detach(), atol=1e-6)
+    assert torch.allclose(torch.cat([p["z"] for p in parts]), z.detach(), atol=1e-6)
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        for part in parts:                          # every replica holds the same, full gradient
+            assert torch.allclose(part["grads"][k], p.grad, atol=2e-6, rtol=1e-5), k
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 8, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            b = [sharding.shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1

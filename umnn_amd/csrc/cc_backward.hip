@@ -56,7 +56,10 @@ __device__ __forceinline__ void stage_rowmajor_images(const BwdArgs& a, float* l
     const int L = m.n_linear - 1;
     for (int l = 1; l < L; ++l) {
         const int Hin = m.width[l], Hout = m.width[l + 1];
-        const int rows = 16 * m.t_out[l + 1], LD = a.ld[l];
+        // rows: only the 4*ks_in[l+1] features the next layer consumes are stored.  Fragment reads of the rows
+        // (and, for W^T fragments, columns) beyond that run into the following image / the zero-initialised
+        // scratch: finite values that only ever reach padding features, whose results are never consumed.
+        const int rows = 4 * m.ks_in[l + 1], LD = a.ld[l];
         const float* __restrict__ W = m.W[l];
         const float* __restrict__ b = m.b[l];
         float* img = lds + a.roff[l];
@@ -129,7 +132,9 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
     const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
     constexpr int NA = NACC > 0 ? NACC : 1;
 
-    stage_rowmajor_images(a, lds, tid, UMNN_BLOCK);
+    const int nwb = blockDim.x >> 6;               // waves in this workgroup (1, 2 or 4: whatever fits in LDS)
+    stage_rowmajor_images(a, lds, tid, blockDim.x);
+    for (int i = tid; i < nwb * a.scratch_per_wave; i += blockDim.x) lds[a.scratch_off + i] = 0.f;
     __syncthreads();
 
     float* scratch = lds + a.scratch_off + wid * a.scratch_per_wave;   // [NACC a-tiles | 1 delta tile] x (TMAX*256)
@@ -165,8 +170,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) { dW1x[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dwo[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    const unsigned wave_global = blockIdx.x * UMNN_WAVES_PER_BLOCK + wid;
-    const unsigned nwaves = gridDim.x * UMNN_WAVES_PER_BLOCK;
+    const unsigned wave_global = blockIdx.x * nwb + wid;
+    const unsigned nwaves = gridDim.x * nwb;
 
     for (unsigned grp = wave_global; grp < a.ngroups; grp += nwaves) {
         const long long q = (long long)grp * 16 + p;
@@ -500,8 +505,8 @@ static int pick_ld(int cols) {
 struct BwdPlan {
     BwdArgs a;
     int tmax;          // template tile count
-    int nwaves, nblocks;
-    size_t lds_bytes_for(int nacc) const { return (size_t)(a.scratch_off + UMNN_WAVES_PER_BLOCK * (nacc + 1) * tmax * 256) * sizeof(float); }
+    int nwaves, nblocks, wpb;
+    size_t lds_bytes_for(int nacc, int waves) const { return (size_t)(a.scratch_off + waves * (nacc + 1) * tmax * 256) * sizeof(float); }
     long long ws_partials, ws_dc, ws_p0;   // byte offsets in the workspace
     long long ws_total;
     int nparts0, chunk0;
@@ -517,7 +522,7 @@ static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan
     for (int l = 1; l < L; ++l) {
         a.ld[l] = pick_ld(4 * a.m.ks_in[l]);
         a.roff[l] = off;
-        off += 16 * a.m.t_out[l + 1] * a.ld[l];
+        off += 4 * a.m.ks_in[l + 1] * a.ld[l];
         off = (off + 3) & ~3;
     }
     a.scratch_off = off;
@@ -529,11 +534,17 @@ static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan
     a.n_params = po;
     a.NI = B * (long long)d; a.d = d; a.E = E;
     a.ngroups = (unsigned)((a.NI + 15) / 16);
+    // waves per workgroup: as many (4, 2, 1) as leave room for the wave-private transpose tiles
+    const int nacc_max = pl->tmax <= 4 ? 3 : 1;
+    pl->wpb = 4;
+    while (pl->wpb > 1 && pl->lds_bytes_for(nacc_max, pl->wpb) > 160 * 1024) pl->wpb >>= 1;
+    if (pl->lds_bytes_for(nacc_max, pl->wpb) > 160 * 1024)
+        return umnn_fail(UMNN_EUNSUPPORTED, "backward: weight images exceed 160 KiB of LDS");
     pl->nblocks = umnn_num_cus();
-    if ((long long)pl->nblocks * UMNN_WAVES_PER_BLOCK > (long long)a.ngroups)
-        pl->nblocks = (int)((a.ngroups + UMNN_WAVES_PER_BLOCK - 1) / UMNN_WAVES_PER_BLOCK);
+    if ((long long)pl->nblocks * pl->wpb > (long long)a.ngroups)
+        pl->nblocks = (int)((a.ngroups + pl->wpb - 1) / pl->wpb);
     if (pl->nblocks < 1) pl->nblocks = 1;
-    pl->nwaves = pl->nblocks * UMNN_WAVES_PER_BLOCK;
+    pl->nwaves = pl->nblocks * pl->wpb;
     const int H1 = net->widths[1];
     pl->chunk0 = 256;
     while (pl->chunk0 > 16 && (size_t)pl->chunk0 * (H1 + E + 1) * sizeof(float) > 96 * 1024) pl->chunk0 /= 2;
@@ -598,11 +609,11 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
         if (!v) return umnn_fail(UMNN_EUNSUPPORTED, "backward: no kernel variant for this width");
         a.l_lo = l_next;
         a.scratch_per_wave = (nacc + 1) * T * 256;
-        const size_t lds_bytes = pl.lds_bytes_for(nacc);
+        const size_t lds_bytes = pl.lds_bytes_for(nacc, pl.wpb);
         if (lds_bytes > 160 * 1024) return umnn_fail(UMNN_EUNSUPPORTED, "backward: weight images exceed 160 KiB of LDS");
         if (int rc = umnn_allow_lds((const void*)v->fn, lds_bytes)) return rc;
         umnn_prof_begin(stream);
-        hipLaunchKernelGGL(v->fn, dim3(pl.nblocks), dim3(UMNN_BLOCK), lds_bytes, stream, a);
+        hipLaunchKernelGGL(v->fn, dim3(pl.nblocks), dim3(64 * pl.wpb), lds_bytes, stream, a);
         umnn_prof_end(stream, 0.0);
         umnn_note_launch(v->name);
         if (int rc = umnn_check(hipGetLastError(), "cc_bwd launch")) return rc;
