@@ -67,18 +67,24 @@ def test_forward_matches_golden_and_oracle(name, dev):
     assert U.rel_err(F.cpu().numpy(), F64) < 2e-5
 
 
+@pytest.mark.parametrize("TAIL", [0, 1])
 @pytest.mark.parametrize("P,NS", [(1, 1), (2, 1), (1, 2), (1, 4), (2, 4), (2, 2)])
-@pytest.mark.parametrize("name", ["g2_power_d6_w2", "g2_toy_d2_w2", "g2_mnist_mixed_d8", "g2_odd_n_d3"])
-def test_every_kernel_variant_agrees(name, P, NS, dev, monkeypatch):
-    """Point tiles per wave (P) and node-split factor (NS) are launch heuristics: all must give the same answer."""
+@pytest.mark.parametrize("name", ["g2_power_d6_w2", "g2_toy_d2_w2", "g2_mnist_mixed_d8", "g2_odd_n_d3", "g2_bsds_d63_w2"])
+def test_every_kernel_variant_agrees(name, P, NS, TAIL, dev, monkeypatch):
+    """Point tiles per wave (P), node-split factor (NS) and the VALU-tail variant are launch choices: all must give
+    the same answer."""
     from umnn_amd import integral as I, _lib
     from umnn_amd.nets import mlp_spec
     monkeypatch.setenv("UMNN_FWD_P", str(P))
     monkeypatch.setenv("UMNN_FWD_NS", str(NS))
+    monkeypatch.setenv("UMNN_FWD_TAIL", str(TAIL))
     G = U.load(name)
     net = build_integrand(G, dev)
     F, fx, fx0 = I.hip_forward(mlp_spec(net), t(G["x0"], dev), t(G["x"], dev), t(G["h"], dev), int(G["n"]))
-    assert f"P={P}" in _lib.lib().umnn_last_kernel_name().decode()
+    kname = _lib.lib().umnn_last_kernel_name().decode()
+    assert f"P={P}" in kname
+    if "power" in name or "bsds" in name:
+        assert f"TAIL={TAIL}" in kname
     assert U.rel_err(F.cpu().numpy(), G["F_par"]) < TOL
     assert U.rel_err(fx.cpu().numpy(), G["f_x"]) < TOL
     assert U.rel_err(fx0.cpu().numpy(), G["f_x0"]) < TOL

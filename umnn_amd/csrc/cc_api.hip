@@ -93,6 +93,7 @@ int umnn_prepare_mlp(const umnn_mlp* net, int E, MlpDev* out, int* tmax, int* ks
         if (H < 1 || H > UMNN_MAX_HIDDEN_WIDTH)
             return umnn_fail(UMNN_EUNSUPPORTED, "hidden width must be in [1, UMNN_MAX_HIDDEN_WIDTH]");
         out->t_out[l] = (H + 1 + 15) / 16;
+        out->t_mfma[l] = out->t_out[l];
         out->ks_in[l] = (H + 1 + 3) / 4;
         if (out->t_out[l] > tm) tm = out->t_out[l];
         if (ks_common == -1) ks_common = out->ks_in[l];

@@ -36,6 +36,9 @@ struct MlpDev {
     int t_out[UMNN_MAX_LINEAR];       // t_out[l]  = ceil((H_l+1)/16): tiles of hidden layer l (l = 1..L)
     int ks_in[UMNN_MAX_LINEAR];       // ks_in[l]  = ceil((H_l+1)/4):  K-steps when layer l is the input
     int lds_off[UMNN_MAX_LINEAR];     // float offset of image l (hidden l -> hidden l+1), l = 1..L-1
+    int t_mfma[UMNN_MAX_LINEAR];      // tiles of hidden layer l produced by MFMA (= t_out[l], or t_out[l]-1 in TAIL mode)
+    int tail_off;                     // TAIL mode: float offset of the tail-row weights [l-1][j][g][16] in LDS
+    int n_tail;                       // TAIL mode: real features in the last tile (computed on the VALU), 0..3
     int hidden_act;
     int out_act;
 };
@@ -49,8 +52,15 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// v_max_f32 without the canonicalising v_max(v,v) hipcc puts in front of fmaxf on MFMA results (fmaxf must quiet
+// signalling NaNs; the hardware instruction on already-finite data does not need it).  One VALU op instead of two.
+__device__ __forceinline__ float vmax_f32(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // hidden activation: LeakyReLU(0.01) (slope = 0.01) or ReLU (slope = 0) as max(v, slope*v)
-__device__ __forceinline__ float hidden_act_f(float v, float slope) { return fmaxf(v, slope * v); }
+__device__ __forceinline__ float hidden_act_f(float v, float slope) { return vmax_f32(v, slope * v); }
 __device__ __forceinline__ float hidden_grad_f(float v, float slope) { return v > 0.f ? 1.f : slope; }
 
 __device__ __forceinline__ float out_act_f(float v, int kind) {
@@ -63,11 +73,16 @@ __device__ __forceinline__ float out_grad_f(float v, int kind) {
     return s * (1.f - s);
 }
 
-// sum over the four lane groups (lanes p, p+16, p+32, p+48); every lane gets the total
+// sum over the four lane groups (lanes p, p+16, p+32, p+48); every lane gets the total.
+// gfx950 row/half swaps keep this on the VALU (no LDS-crossbar bpermute): permlane16_swap(v,v) returns
+// {rows (0,0,2,2), rows (1,1,3,3)} of v, permlane32_swap(v,v) returns {(lo,lo), (hi,hi)}.
 __device__ __forceinline__ float group_allreduce(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    const unsigned u = __float_as_uint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned w = __float_as_uint(s);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // Stage the hidden->hidden weight images (see header comment) into LDS.  Called by all threads
@@ -76,7 +91,7 @@ __device__ __forceinline__ void stage_hidden_images(const MlpDev& m, float* lds,
     const int L = m.n_linear - 1;
     for (int l = 1; l < L; ++l) {
         const int Hin = m.width[l], Hout = m.width[l + 1];
-        const int ks = m.ks_in[l], to = m.t_out[l + 1];
+        const int ks = m.ks_in[l], to = m.t_mfma[l + 1];
         const float* __restrict__ W = m.W[l];
         const float* __restrict__ b = m.b[l];
         float* img = lds + m.lds_off[l];
@@ -93,6 +108,20 @@ __device__ __forceinline__ void stage_hidden_images(const MlpDev& m, float* lds,
                 v = 1.f;
             }
             img[idx] = v;
+        }
+    }
+    // TAIL mode: rows of the last tile's real features, stored [l-1][j][g][16] so a lane reads its 4t..4t+3 as b128
+    if (m.n_tail > 0) {
+        for (int l = 1; l < L; ++l) {
+            const int Hin = m.width[l], Hout = m.width[l + 1];
+            const float* __restrict__ W = m.W[l];
+            const float* __restrict__ b = m.b[l];
+            float* tw = lds + m.tail_off + (l - 1) * (3 * 4 * 16);
+            for (int idx = tid; idx < m.n_tail * 64; idx += nthreads) {
+                const int s = idx & 15, gg = (idx >> 4) & 3, j = idx >> 6;
+                const int fo = Hout - m.n_tail + j, fi = 4 * s + gg;
+                tw[idx] = fi < Hin ? W[fo * Hin + fi] : (fi == Hin ? b[fo] : 0.f);
+            }
         }
     }
 }

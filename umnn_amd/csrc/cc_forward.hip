@@ -35,8 +35,64 @@ struct FwdArgs {
     unsigned ngroups;  // tile groups (of 16*P integrals)
 };
 
-template <int TMAX, int KSC, int P>
+// Combine the node-range partials of the NS waves sharing a tile group (through LDS), then write F, f(x), f(x0)
+// and, for the flow entry point, z and log_jac.  Called by every wave of the workgroup (it contains a barrier).
+template <int P>
+__device__ __forceinline__ void fwd_epilogue(const FwdArgs& a, float* lds, float (&Facc)[P], float (&fxv)[P],
+                                             float (&fx0v)[P], const bool (&ok)[P], const long long (&qv)[P],
+                                             const float (&dxv)[P], bool live, int part, int ns, int wid, int g, int p) {
+    const MlpDev& m = a.m;
+    const int L = m.n_linear - 1, d = a.d, E = a.E;
+    if (ns > 1) {
+        float* red = lds + m.lds_off[L];      // [waves][3][P*16]
+        if (live && g == 0) {
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) {
+                float* rw = red + wid * (3 * P * 16) + pt * 16 + p;
+                rw[0] = Facc[pt];
+                rw[P * 16] = fxv[pt];
+                rw[2 * P * 16] = fx0v[pt];
+            }
+        }
+        __syncthreads();
+        if (live && part == 0 && g == 0) {
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) {
+                float s = 0.f;
+                for (int j = 0; j < ns; ++j) s += red[(wid + j) * (3 * P * 16) + pt * 16 + p];
+                Facc[pt] = s;
+                fx0v[pt] = red[(wid + ns - 1) * (3 * P * 16) + 2 * P * 16 + pt * 16 + p];
+            }
+        }
+    }
+    if (live && part == 0 && g == 0) {
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            if (!ok[pt]) continue;
+            const long long q = qv[pt];
+            const float Fv = Facc[pt] * dxv[pt] * 0.5f;
+            if (a.F) a.F[q] = Fv;
+            if (a.fx) a.fx[q] = fxv[pt];
+            if (a.fx0) a.fx0[q] = fx0v[pt];
+            if (a.scaling) {
+                const long long bi = q / d;
+                const int i = (int)(q - bi * d);
+                const float sc = a.scaling[i];
+                const float z0 = a.h[bi * ((long long)E * d) + i];
+                a.z[q] = __expf(sc) * (Fv + z0);
+                a.logjac[q] = __logf(fxv[pt] + 1e-10f) + sc;
+            }
+        }
+    }
+}
+
+// TAIL = 1 (exact variants only): the last tile holds at most 4 features (<= 3 real ones + the constant), all
+// in component r = 0.  Giving that tile 13 or 26 MFMAs to produce 2-3 useful rows wastes a quarter of the
+// matrix pipe, so it is computed on the otherwise idle VALU instead: each lane dots its own K-slice of the
+// tail rows (weights broadcast from LDS as b128) and the four lane groups are summed with row/half swaps.
+template <int TMAX, int KSC, int P, int TAIL, int NT>
 __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_kernel(const FwdArgs a) {
+    constexpr int TT = TMAX - TAIL;            // tiles produced by MFMA; NT = real features of the VALU tail tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const MlpDev& m = a.m;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -63,7 +119,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_kernel(const FwdArgs a) {
     bool ok[P];
     long long qv[P];
 #pragma unroll
-    for (int pt = 0; pt < P; ++pt) { Facc[pt] = 0.f; fxv[pt] = 0.f; fx0v[pt] = 0.f; }
+    for (int pt = 0; pt < P; ++pt) { Facc[pt] = 0.f; fxv[pt] = 0.f; fx0v[pt] = 0.f; ok[pt] = false; qv[pt] = 0; dxv[pt] = 0.f; }
 
     if (live) {
         const float* hb[P];
@@ -143,13 +199,37 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_kernel(const FwdArgs a) {
                 for (int t = 0; t < TMAX; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        act[pt][t][r] = hidden_act_f(fmaf(w1x[t][r], tk, c[pt][t][r]), slope);
+                        act[pt][t][r] = (t < TT || r == 0) ? hidden_act_f(fmaf(w1x[t][r], tk, c[pt][t][r]), slope) : 0.f;
             }
 
             for (int l = 1; l < L; ++l) {
                 const int ks = KSC ? KSC : m.ks_in[l];
-                const int to = KSC ? TMAX : m.t_out[l + 1];
+                const int to = KSC ? TT : m.t_out[l + 1];
                 const float* img = lds + m.lds_off[l] + lane;
+                // tail rows first (VALU, reads the layer's INPUT activations; independent of the MFMAs below)
+                float tailv[P];
+                if constexpr (TAIL) {
+                    const float* wt = lds + m.tail_off + (l - 1) * (3 * 4 * 16) + g * 16;
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt) tailv[pt] = g == NT ? 1.f : 0.f;   // the constant feature
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        f32x4 w[TT];
+#pragma unroll
+                        for (int t = 0; t < TT; ++t) w[t] = *reinterpret_cast<const f32x4*>(wt + j * 64 + 4 * t);
+                        const float wl = wt[j * 64 + 4 * TT];
+#pragma unroll
+                        for (int pt = 0; pt < P; ++pt) {
+                            float dsum = wl * act[pt][TT][0];
+#pragma unroll
+                            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) dsum = fmaf(w[t][r], act[pt][t][r], dsum);
+                            dsum = group_allreduce(dsum);
+                            tailv[pt] = g == j ? hidden_act_f(dsum, slope) : tailv[pt];
+                        }
+                    }
+                }
                 f32x4 acc[P][TMAX];
 #pragma unroll
                 for (int pt = 0; pt < P; ++pt)
@@ -159,7 +239,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_kernel(const FwdArgs a) {
                 for (int s = 0; s < 4 * TMAX; ++s) {
                     if (KSC ? (s < KSC) : (s < ks)) {
 #pragma unroll
-                        for (int t = 0; t < TMAX; ++t) {
+                        for (int t = 0; t < TT; ++t) {
                             if (KSC || t < to) {
                                 const float A = img[(t * ks + s) * 64];
 #pragma unroll
@@ -174,8 +254,10 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_kernel(const FwdArgs a) {
 #pragma unroll
                     for (int t = 0; t < TMAX; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            act[pt][t][r] = (KSC || t < to) ? hidden_act_f(acc[pt][t][r], slope) : 0.f;
+                        for (int r = 0; r < 4; ++r) {
+                            if (t < TT) act[pt][t][r] = (KSC || t < to) ? hidden_act_f(acc[pt][t][r], slope) : 0.f;
+                            else act[pt][t][r] = r == 0 ? tailv[pt] : 0.f;
+                        }
             }
 
 #pragma unroll
@@ -184,7 +266,8 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_kernel(const FwdArgs a) {
 #pragma unroll
                 for (int t = 0; t < TMAX; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s = fmaf(wout[t][r], act[pt][t][r], s);
+                    for (int r = 0; r < 4; ++r)
+                        if (t < TT || r == 0) s = fmaf(wout[t][r], act[pt][t][r], s);
                 s = group_allreduce(s);
                 const float f = out_act_f(s, m.out_act);
                 Facc[pt] = fmaf(wk, a.inv_f ? 1.f / f : f, Facc[pt]);
@@ -194,50 +277,9 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_kernel(const FwdArgs a) {
         }
     }
 
-    // ---- combine node-range partials of the NS waves sharing this tile group
-    if (ns > 1) {
-        float* red = lds + m.lds_off[L];      // [waves][3][P*16]
-        if (live && g == 0) {
-#pragma unroll
-            for (int pt = 0; pt < P; ++pt) {
-                float* rw = red + wid * (3 * P * 16) + pt * 16 + p;
-                rw[0] = Facc[pt];
-                rw[P * 16] = fxv[pt];
-                rw[2 * P * 16] = fx0v[pt];
-            }
-        }
-        __syncthreads();
-        if (live && part == 0 && g == 0) {
-#pragma unroll
-            for (int pt = 0; pt < P; ++pt) {
-                float s = 0.f;
-                for (int j = 0; j < ns; ++j) s += red[(wid + j) * (3 * P * 16) + pt * 16 + p];
-                Facc[pt] = s;
-                fx0v[pt] = red[(wid + ns - 1) * (3 * P * 16) + 2 * P * 16 + pt * 16 + p];
-            }
-        }
-    }
-
-    if (live && part == 0 && g == 0) {
-#pragma unroll
-        for (int pt = 0; pt < P; ++pt) {
-            if (!ok[pt]) continue;
-            const long long q = qv[pt];
-            const float Fv = Facc[pt] * dxv[pt] * 0.5f;
-            if (a.F) a.F[q] = Fv;
-            if (a.fx) a.fx[q] = fxv[pt];
-            if (a.fx0) a.fx0[q] = fx0v[pt];
-            if (a.scaling) {
-                const long long bi = q / d;
-                const int i = (int)(q - bi * d);
-                const float sc = a.scaling[i];
-                const float z0 = a.h[bi * ((long long)E * d) + i];
-                a.z[q] = __expf(sc) * (Fv + z0);
-                a.logjac[q] = __logf(fxv[pt] + 1e-10f) + sc;
-            }
-        }
-    }
+    fwd_epilogue<P>(a, lds, Facc, fxv, fx0v, ok, qv, dxv, live, part, ns, wid, g, p);
 }
+
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -246,15 +288,16 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_kernel(const FwdArgs a) {
 
 typedef void (*fwd_kernel_t)(const FwdArgs);
 
-struct FwdVariant { int tmax, ksc, p; fwd_kernel_t fn; const char* name; };
+struct FwdVariant { int tmax, ksc, p, tail, nt; fwd_kernel_t fn; const char* name; };
 
-#define FWD_VARIANT(T, K, PP) { T, K, PP, cc_fwd_kernel<T, K, PP>, "cc_fwd<T=" #T ",KS=" #K ",P=" #PP ">" }
+#define FWD_VARIANT(T, K, PP, TL, NT) { T, K, PP, TL, NT, cc_fwd_kernel<T, K, PP, TL, NT>, "cc_fwd<T=" #T ",KS=" #K ",P=" #PP ",TAIL=" #TL ">" }
 static const FwdVariant kFwdVariants[] = {
-    FWD_VARIANT(4, 13, 1), FWD_VARIANT(4, 13, 2),     // hidden width 50 (UCI / VAE nets)
-    FWD_VARIANT(7, 26, 1), FWD_VARIANT(7, 26, 2),     // hidden width 100 (toy / MonotonicMLP nets)
-    FWD_VARIANT(2, 0, 1),  FWD_VARIANT(2, 0, 2),      // generic, hidden widths <= 31
-    FWD_VARIANT(4, 0, 1),  FWD_VARIANT(4, 0, 2),      // generic, <= 63
-    FWD_VARIANT(8, 0, 1),  FWD_VARIANT(8, 0, 2),      // generic, <= 127
+    FWD_VARIANT(4, 13, 1, 1, 2), FWD_VARIANT(4, 13, 2, 1, 2),   // hidden width 50 (UCI / VAE nets): VALU tail for 48,49
+    FWD_VARIANT(4, 13, 1, 0, 0), FWD_VARIANT(4, 13, 2, 0, 0),   // widths 48..51, all four tiles on MFMA
+    FWD_VARIANT(7, 26, 1, 0, 0), FWD_VARIANT(7, 26, 2, 0, 0),   // hidden width 100 (toy / MonotonicMLP nets)
+    FWD_VARIANT(2, 0, 1, 0, 0),  FWD_VARIANT(2, 0, 2, 0, 0),    // generic, hidden widths <= 31
+    FWD_VARIANT(4, 0, 1, 0, 0),  FWD_VARIANT(4, 0, 2, 0, 0),    // generic, <= 63
+    FWD_VARIANT(8, 0, 1, 0, 0),  FWD_VARIANT(8, 0, 2, 0, 0),    // generic, <= 127
 };
 
 static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, const float* h,
@@ -286,28 +329,45 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
     if (const char* ev = getenv("UMNN_FWD_P")) P = atoi(ev) == 2 ? 2 : 1;
     if (const char* ev = getenv("UMNN_FWD_NS")) { int v = atoi(ev); if (v == 1 || v == 2 || v == 4) ns = v; }
 
+    // TAIL is possible when every hidden layer has the same width H with 16(T-1) <= H <= 16(T-1)+3
+    const int H1w = net->widths[1];
+    int want_tail = (ksu && ksu == 4 * (tmax - 1) + 1 && H1w - 16 * (tmax - 1) >= 0 && H1w - 16 * (tmax - 1) <= 3) ? 1 : 0;
+    if (const char* ev = getenv("UMNN_FWD_TAIL")) want_tail = want_tail && atoi(ev) != 0;
     const FwdVariant* pick = nullptr;
-    for (const FwdVariant& v : kFwdVariants)
-        if (v.ksc && v.ksc == ksu && v.tmax == tmax && v.p == P) { pick = &v; break; }
+    for (int tl = want_tail; tl >= 0 && !pick; --tl)
+        for (const FwdVariant& v : kFwdVariants)
+            if (v.ksc && v.ksc == ksu && v.tmax == tmax && v.p == P && v.tail == tl &&
+                (!tl || v.nt == H1w - 16 * (tmax - 1))) { pick = &v; break; }
     if (!pick)
         for (const FwdVariant& v : kFwdVariants)
             if (!v.ksc && v.tmax >= tmax && v.p == P) { pick = &v; break; }
     if (!pick) return umnn_fail(UMNN_EUNSUPPORTED, "forward: hidden width above UMNN_MAX_HIDDEN_WIDTH");
+    const fwd_kernel_t kfn = pick->fn;
+    const char* kname = pick->name;
 
     const int L = a.m.n_linear - 1;
+    if (pick->tail) {       // re-lay the LDS plan: T-1 tiles per image, then the tail rows
+        int off = 0;
+        for (int l = 1; l <= L; ++l) a.m.t_mfma[l] = a.m.t_out[l] - 1;
+        for (int l = 1; l < L; ++l) { a.m.lds_off[l] = off; off += a.m.t_mfma[l + 1] * a.m.ks_in[l] * 64; }
+        a.m.tail_off = off;
+        a.m.n_tail = H1w - 16 * (tmax - 1);
+        off += (L - 1) * 3 * 4 * 16;
+        a.m.lds_off[L] = off;
+    }
     const size_t lds_floats = (size_t)a.m.lds_off[L] + (ns > 1 ? UMNN_WAVES_PER_BLOCK * 3 * P * 16 : 0);
     const size_t lds_bytes = lds_floats * sizeof(float);
     if (lds_bytes > 160 * 1024) return umnn_fail(UMNN_EUNSUPPORTED, "forward: weight images exceed 160 KiB of LDS");
-    if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
+    if (int rc = umnn_allow_lds((const void*)kfn, lds_bytes)) return rc;
 
     a.ns = ns;
     a.ngroups = (unsigned)((a.NI + 16 * P - 1) / (16 * P));
     const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
     const unsigned nblk = (a.ngroups + gpb - 1) / gpb;
     umnn_prof_begin(stream);
-    hipLaunchKernelGGL(pick->fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, a);
+    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, a);
     umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * (double)a.NI);
-    umnn_note_launch(pick->name);
+    umnn_note_launch(kname);
     return umnn_check(hipGetLastError(), "cc_fwd launch");
 }
 
