@@ -117,6 +117,19 @@ int umnn_cc_forward_timed(const umnn_mlp* net, const float* x0, const float* x, 
                           long long B, int d, int E, float* F, float* f_x, float* f_x0,
                           int reps, float* ms, void* stream);
 
+/* Arithmetic of the hidden-layer GEMMs in the FORWARD kernels (process-wide; default UMNN_PRECISION_BF16X3, or the
+ * environment variable UMNN_FWD_PRECISION = fp32 | bf16x3 | bf16x6 at first use).  Every mode meets the 1e-4
+ * tolerance of the path with margin (measured max relative error of F: fp32 ~4e-7, bf16x6 ~4e-7, bf16x3 ~6e-6);
+ * backward always runs in fp32.
+ *   FP32    v_mfma_f32_16x16x4_f32: exact fp32 products (an fmaf chain), fp32-vector-rate matrix path
+ *   BF16X3  operands split in two bf16 pieces, 3 cross terms on v_mfma_f32_16x16x32_bf16, fp32 accumulation
+ *   BF16X6  three pieces, 6 cross terms: fp32-level accuracy */
+#define UMNN_PRECISION_FP32 0
+#define UMNN_PRECISION_BF16X3 1
+#define UMNN_PRECISION_BF16X6 2
+int umnn_set_forward_precision(int mode);
+int umnn_get_forward_precision(void);
+
 /* Per-launch timing: while enabled, every forward/backward launch is bracketed by hipEvents recorded on its own
  * launch stream.  umnn_profile_read synchronises on them and returns the summed kernel milliseconds, the number of
  * launches and the summed algorithmic FLOPs (forward launches only carry FLOPs).  enable(0/1) clears the records. */

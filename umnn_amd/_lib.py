@@ -49,10 +49,14 @@ SIGNATURES = {
     "umnn_cc_forward_timed": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                              _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int,
                                              ctypes.POINTER(ctypes.c_float), _fp]),
+    "umnn_set_forward_precision": (ctypes.c_int, [ctypes.c_int]),
+    "umnn_get_forward_precision": (ctypes.c_int, []),
     "umnn_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "umnn_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_ll),
                                          ctypes.POINTER(ctypes.c_double)]),
 }
+
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}
 
 _lib = None
 _lock = threading.Lock()
@@ -84,3 +88,13 @@ def check(rc, what):
     if rc != 0:
         msg = lib().umnn_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def set_forward_precision(name):
+    """'fp32' (exact fp32 MFMA), 'bf16x3' (default: bf16 split, 3 cross terms) or 'bf16x6' (fp32-level accuracy)."""
+    check(lib().umnn_set_forward_precision(PRECISIONS[name]), "umnn_set_forward_precision")
+
+
+def get_forward_precision():
+    mode = lib().umnn_get_forward_precision()
+    return next(k for k, v in PRECISIONS.items() if v == mode)

@@ -15,76 +15,7 @@
 // node-invariant part W1[:,1:]*h + b1 is hoisted and computed once per integral, itself on MFMA);
 // hidden layers are 16x16x4 fp32 MFMAs against LDS-resident weight images; the scalar output layer
 // is a per-lane dot product plus a 4-lane-group all-reduce.  See cc_common.h for the layouts.
-#include "cc_common.h"
-
-struct FwdArgs {
-    MlpDev m;
-    const float* x0;   // nullable
-    const float* x;
-    const float* h;
-    const float* ccw;
-    const float* ccs;
-    float* F;          // nullable when flow epilogue is used
-    float* fx;         // nullable
-    float* fx0;        // nullable
-    const float* scaling;  // flow epilogue (nullable => plain integral)
-    float* z;
-    float* logjac;
-    long long NI;      // B*d integrals
-    int d, E, n, ns, inv_f;
-    unsigned ngroups;  // tile groups (of 16*P integrals)
-};
-
-// Combine the node-range partials of the NS waves sharing a tile group (through LDS), then write F, f(x), f(x0)
-// and, for the flow entry point, z and log_jac.  Called by every wave of the workgroup (it contains a barrier).
-template <int P>
-__device__ __forceinline__ void fwd_epilogue(const FwdArgs& a, float* lds, float (&Facc)[P], float (&fxv)[P],
-                                             float (&fx0v)[P], const bool (&ok)[P], const long long (&qv)[P],
-                                             const float (&dxv)[P], bool live, int part, int ns, int wid, int g, int p) {
-    const MlpDev& m = a.m;
-    const int L = m.n_linear - 1, d = a.d, E = a.E;
-    if (ns > 1) {
-        float* red = lds + m.lds_off[L];      // [waves][3][P*16]
-        if (live && g == 0) {
-#pragma unroll
-            for (int pt = 0; pt < P; ++pt) {
-                float* rw = red + wid * (3 * P * 16) + pt * 16 + p;
-                rw[0] = Facc[pt];
-                rw[P * 16] = fxv[pt];
-                rw[2 * P * 16] = fx0v[pt];
-            }
-        }
-        __syncthreads();
-        if (live && part == 0 && g == 0) {
-#pragma unroll
-            for (int pt = 0; pt < P; ++pt) {
-                float s = 0.f;
-                for (int j = 0; j < ns; ++j) s += red[(wid + j) * (3 * P * 16) + pt * 16 + p];
-                Facc[pt] = s;
-                fx0v[pt] = red[(wid + ns - 1) * (3 * P * 16) + 2 * P * 16 + pt * 16 + p];
-            }
-        }
-    }
-    if (live && part == 0 && g == 0) {
-#pragma unroll
-        for (int pt = 0; pt < P; ++pt) {
-            if (!ok[pt]) continue;
-            const long long q = qv[pt];
-            const float Fv = Facc[pt] * dxv[pt] * 0.5f;
-            if (a.F) a.F[q] = Fv;
-            if (a.fx) a.fx[q] = fxv[pt];
-            if (a.fx0) a.fx0[q] = fx0v[pt];
-            if (a.scaling) {
-                const long long bi = q / d;
-                const int i = (int)(q - bi * d);
-                const float sc = a.scaling[i];
-                const float z0 = a.h[bi * ((long long)E * d) + i];
-                a.z[q] = __expf(sc) * (Fv + z0);
-                a.logjac[q] = __logf(fxv[pt] + 1e-10f) + sc;
-            }
-        }
-    }
-}
+#include "cc_fwd_shared.h"
 
 // TAIL = 1 (exact variants only): the last tile holds at most 4 features (<= 3 real ones + the constant), all
 // in component r = 0.  Giving that tile 13 or 26 MFMAs to produce 2-3 useful rows wastes a quarter of the
@@ -284,6 +215,8 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_kernel(const FwdArgs a) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+#include <cstring>
+
 #include "cc_host.h"
 
 typedef void (*fwd_kernel_t)(const FwdArgs);
@@ -299,6 +232,29 @@ static const FwdVariant kFwdVariants[] = {
     FWD_VARIANT(4, 0, 1, 0, 0),  FWD_VARIANT(4, 0, 2, 0, 0),    // generic, <= 63
     FWD_VARIANT(8, 0, 1, 0, 0),  FWD_VARIANT(8, 0, 2, 0, 0),    // generic, <= 127
 };
+
+int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps, hipStream_t stream);
+
+// forward arithmetic: 0 = exact fp32 MFMA, 1 = bf16 split with 3 cross terms, 2 = bf16 split with 6 cross terms
+static int g_fwd_precision = -1;
+static int fwd_precision() {
+    if (g_fwd_precision < 0) {
+        int mode = UMNN_PRECISION_BF16X3;
+        if (const char* ev = getenv("UMNN_FWD_PRECISION")) {
+            if (!strcmp(ev, "fp32")) mode = UMNN_PRECISION_FP32;
+            else if (!strcmp(ev, "bf16x3")) mode = UMNN_PRECISION_BF16X3;
+            else if (!strcmp(ev, "bf16x6")) mode = UMNN_PRECISION_BF16X6;
+        }
+        g_fwd_precision = mode;
+    }
+    return g_fwd_precision;
+}
+extern "C" int umnn_set_forward_precision(int mode) {
+    if (mode < UMNN_PRECISION_FP32 || mode > UMNN_PRECISION_BF16X6) return umnn_fail(UMNN_EINVAL, "unknown precision mode");
+    g_fwd_precision = mode;
+    return 0;
+}
+extern "C" int umnn_get_forward_precision(void) { return fwd_precision(); }
 
 static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, const float* h,
                           const float* scaling, const float* cc_w, const float* cc_s, int nb_steps,
@@ -329,6 +285,14 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
     if (const char* ev = getenv("UMNN_FWD_P")) P = atoi(ev) == 2 ? 2 : 1;
     if (const char* ev = getenv("UMNN_FWD_NS")) { int v = atoi(ev); if (v == 1 || v == 2 || v == 4) ns = v; }
 
+    // bf16-split kernels (default): hidden GEMMs on the bf16 matrix cores; falls through to fp32 MFMA when the
+    // shape does not fit them (a single hidden layer has no hidden->hidden GEMM at all)
+    const int prec = fwd_precision();
+    if (prec != UMNN_PRECISION_FP32 && a.m.n_linear - 1 >= 2) {
+        a.ns = ns;
+        const int rc = umnn_launch_forward_bf16(a, net, prec == UMNN_PRECISION_BF16X3 ? 2 : 3, P, ns, nb_steps, stream);
+        if (rc != UMNN_EUNSUPPORTED) return rc;
+    }
     // TAIL is possible when every hidden layer has the same width H with 16(T-1) <= H <= 16(T-1)+3
     const int H1w = net->widths[1];
     int want_tail = (ksu && ksu == 4 * (tmax - 1) + 1 && H1w - 16 * (tmax - 1) >= 0 && H1w - 16 * (tmax - 1) <= 3) ? 1 : 0;

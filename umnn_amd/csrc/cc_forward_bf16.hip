@@ -1,0 +1,323 @@
+// Forward quadrature with the hidden-layer GEMMs on the bf16 matrix cores, fp32 accuracy recovered by splitting.
+//
+// Why: on gfx950 the fp32-input MFMA runs at the fp32 VECTOR rate and (measured) time-shares the
+// SIMD's fp32 lanes with ordinary VALU work, so the exact-fp32 kernel is bounded by 32 cycles per 16x16x4 MFMA
+// PLUS ~3 cycles per VALU instruction.  v_mfma_f32_16x16x32_bf16 has 16x the rate on a separate pipe.  Every fp32
+// operand is split into bf16 pieces x = hi + lo (+ lo2), each the round-to-nearest bf16 of the running remainder,
+// and the product W*a is formed from the significant cross terms, accumulated in fp32 inside the MFMA:
+//     NPARTS = 2 (3 terms):  Whi*ahi + Whi*alo + Wlo*ahi                 error ~2^-16 per product (F to ~5e-6)
+//     NPARTS = 3 (6 terms):  + Whi*alo2 + Wlo2*ahi + Wlo*alo             error ~2^-24: fp32-level (F to ~4e-7)
+// Layer 1 (one FMA per feature), the hoisted first-layer term, the output dot product, ELU and the quadrature sum
+// stay in fp32.  Same reference lines as cc_forward.hip.
+//
+// Layout: natural feature numbering, lane (g,p) / tile t / component r <-> feature 16t + 4g + r (the accumulator
+// row order of the 16x16 MFMAs).  One K-step of 16x16x32 consumes 32 features = two tiles (2s, 2s+1); lane group g
+// supplies k-slots 8g..8g+7 = its own 4 components of tile 2s followed by its 4 components of tile 2s+1 -- again
+// the accumulators of one layer ARE (after activation, splitting and packing) the B operands of the next, with no
+// cross-lane movement.  Weight fragments are pre-split and pre-permuted into LDS: fragment (tile t', K-step s, part)
+// is 64 lanes x 8 bf16 = 1 KiB, read with one ds_read_b128 per lane.
+#include "cc_fwd_shared.h"
+#include "cc_host.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned short bf16_rn_bits(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// (x0,x1) -> packed bf16 pairs of the NPARTS pieces (piece k of x0 in the low half of out[k], of x1 in the high half)
+template <int NPARTS>
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&out)[NPARTS]) {
+#pragma unroll
+    for (int k = 0; k < NPARTS; ++k) {
+        const bf16x2 h = __builtin_convertvector(f32x2{x0, x1}, bf16x2);      // v_cvt_pk_bf16_f32 (round to nearest even)
+        const unsigned bits = __builtin_bit_cast(unsigned, h);
+        out[k] = bits;
+        if (k + 1 < NPARTS) {
+            x0 -= __uint_as_float(bits << 16);
+            x1 -= __uint_as_float(bits & 0xffff0000u);
+        }
+    }
+}
+
+// Stage the pre-split, pre-permuted weight fragments.  img16 index: ((t'*ks + s)*NPARTS + part)*512 + lane*8 + j
+template <int NPARTS>
+__device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks32, const int* off16,
+                                                  unsigned short* lds16, int tid, int nthreads) {
+    const int L = m.n_linear - 1;
+    for (int l = 1; l < L; ++l) {
+        const int Hin = m.width[l], Hout = m.width[l + 1];
+        const int ks = ks32[l], to = m.t_out[l + 1];
+        const float* __restrict__ W = m.W[l];
+        const float* __restrict__ b = m.b[l];
+        unsigned short* img = lds16 + off16[l];
+        const int total = to * ks * 512;
+        for (int idx = tid; idx < total; idx += nthreads) {
+            const int j = idx & 7, ln = (idx >> 3) & 63, ts = idx >> 9;
+            const int s = ts % ks, t = ts / ks;
+            const int fo = 16 * t + (ln & 15);
+            const int fi = 16 * (2 * s + (j >> 2)) + 4 * (ln >> 4) + (j & 3);
+            float v = 0.f;
+            if (fo < Hout) {
+                if (fi < Hin) v = W[fo * Hin + fi];
+                else if (fi == Hin) v = b[fo];
+            } else if (fo == Hout && fi == Hin) {
+                v = 1.f;
+            }
+#pragma unroll
+            for (int part = 0; part < NPARTS; ++part) {
+                const unsigned short hb = bf16_rn_bits(v);
+                img[(ts * NPARTS + part) * 512 + ln * 8 + j] = hb;
+                v -= bf16_bits_to_f32(hb);
+            }
+        }
+    }
+}
+
+struct Bf16Plan {
+    int ks32[UMNN_MAX_LINEAR];     // K-steps of 32 features when hidden layer l is the input
+    int off16[UMNN_MAX_LINEAR];    // ushort offset of image l
+    int scratch_off_floats;        // float offset of the NS-reduction scratch (after the images)
+};
+
+struct FwdBf16Args {
+    FwdArgs f;
+    Bf16Plan pl;
+};
+
+// EXACT: every hidden layer fills exactly TMAX tiles, so tile / K-step counts are compile-time constants and the
+// wave-uniform guards (and the accumulator copies they force at every basic-block boundary) disappear.
+template <int TMAX, int NPARTS, int P, bool EXACT>
+__global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Args args) {
+    constexpr int KSM = TMAX / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const FwdArgs& a = args.f;
+    const MlpDev& m = a.m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, p = lane & 15;
+    const int L = m.n_linear - 1;
+    const int H1 = m.width[1], HL = m.width[L];
+    const int E = a.E, d = a.d, n = a.n;
+    const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
+    unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
+
+    stage_bf16_images<NPARTS>(m, args.pl.ks32, args.pl.off16, lds16, tid, UMNN_BLOCK);
+    __syncthreads();
+
+    const int ns = a.ns;
+    const int sub = wid / ns, part = wid % ns;
+    const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
+    const unsigned grp = xcd_remap(blockIdx.x, gridDim.x) * gpb + sub;
+    const bool live = grp < a.ngroups;
+    const int k_lo = (int)(((long long)part * (n + 1)) / ns);
+    const int k_hi = (int)(((long long)(part + 1) * (n + 1)) / ns);
+
+    float Facc[P], fxv[P], fx0v[P], xv[P], x0v[P], dxv[P];
+    bool ok[P];
+    long long qv[P];
+#pragma unroll
+    for (int pt = 0; pt < P; ++pt) { Facc[pt] = 0.f; fxv[pt] = 0.f; fx0v[pt] = 0.f; ok[pt] = false; qv[pt] = 0; dxv[pt] = 0.f; }
+
+    if (live) {
+        const float* hb[P];
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            const long long q = ((long long)grp * P + pt) * 16 + p;
+            ok[pt] = q < a.NI;
+            const long long qq = ok[pt] ? q : a.NI - 1;
+            qv[pt] = qq;
+            xv[pt] = a.x[qq];
+            x0v[pt] = a.x0 ? a.x0[qq] : 0.f;
+            dxv[pt] = xv[pt] - x0v[pt];
+            const long long bi = qq / d;
+            hb[pt] = a.h + bi * ((long long)E * d) + (qq - bi * d);
+        }
+
+        // per-lane constants and the hoisted first-layer term (fp32 MFMA, natural row order)
+        float w1x[TMAX][4], wout[TMAX][4];
+        f32x4 c[P][TMAX];
+        {
+            const float* __restrict__ W0 = m.W[0];
+            const float* __restrict__ b0 = m.b[0];
+            const float* __restrict__ WL = m.W[L];
+            const float bL = m.b[L][0];
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) {
+                f32x4 init;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * t + 4 * g + r;
+                    w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
+                    wout[t][r] = f < HL ? WL[f] : (f == HL ? bL : 0.f);
+                    init[r] = f < H1 ? b0[f] : (f == H1 ? 1.f : 0.f);
+                }
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt) c[pt][t] = init;
+            }
+            const int t1 = EXACT ? TMAX : m.t_out[1];
+            for (int se = 0; se < (E + 3) / 4; ++se) {
+                const int e = 4 * se + g;
+                float hv[P];
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt) hv[pt] = e < E ? hb[pt][(long long)e * d] : 0.f;
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t) {
+                    if (EXACT || t < t1) {
+                        const int fo = 16 * t + p;
+                        const float A = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
+#pragma unroll
+                        for (int pt = 0; pt < P; ++pt) c[pt][t] = mfma16(A, hv[pt], c[pt][t]);
+                    }
+                }
+            }
+        }
+
+        for (int k = k_lo; k < k_hi; ++k) {
+            const float u = a.ccs[k] + 1.f;
+            const float wk = a.ccw[k];
+            f32x4 act[P][TMAX];
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) {
+                const float tk = k == 0 ? xv[pt] : __fadd_rn(x0v[pt], __fmul_rn(dxv[pt], u) * 0.5f);
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        act[pt][t][r] = hidden_act_f(fmaf(w1x[t][r], tk, c[pt][t][r]), slope);
+            }
+
+            for (int l = 1; l < L; ++l) {
+                const int ks = EXACT ? KSM : args.pl.ks32[l], to = EXACT ? TMAX : m.t_out[l + 1];
+                const unsigned short* img = lds16 + args.pl.off16[l] + lane * 8;
+                // split + pack the activations into B fragments: K-step s <- tiles 2s, 2s+1
+                u32x4 bf[P][KSM][NPARTS];
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                    for (int s = 0; s < KSM; ++s) {
+                        unsigned q0[NPARTS], q1[NPARTS], q2[NPARTS], q3[NPARTS];
+                        split_pair<NPARTS>(act[pt][2 * s][0], act[pt][2 * s][1], q0);
+                        split_pair<NPARTS>(act[pt][2 * s][2], act[pt][2 * s][3], q1);
+                        split_pair<NPARTS>(act[pt][2 * s + 1][0], act[pt][2 * s + 1][1], q2);
+                        split_pair<NPARTS>(act[pt][2 * s + 1][2], act[pt][2 * s + 1][3], q3);
+#pragma unroll
+                        for (int k2 = 0; k2 < NPARTS; ++k2) bf[pt][s][k2] = u32x4{q0[k2], q1[k2], q2[k2], q3[k2]};
+                    }
+                f32x4 acc[P][TMAX];
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) acc[pt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KSM; ++s) {
+                    if (EXACT || s < ks) {
+                        u32x4 wf[TMAX][NPARTS];
+#pragma unroll
+                        for (int t = 0; t < TMAX; ++t)
+                            if (EXACT || t < to) {
+#pragma unroll
+                                for (int k2 = 0; k2 < NPARTS; ++k2)
+                                    wf[t][k2] = *reinterpret_cast<const u32x4*>(img + ((t * ks + s) * NPARTS + k2) * 512);
+                            }
+                        // cross terms in order of decreasing magnitude; consecutive MFMAs hit different accumulators
+#pragma unroll
+                        for (int wa = 0; wa < NPARTS; ++wa)
+#pragma unroll
+                            for (int ba = 0; ba < NPARTS; ++ba) {
+                                if (wa + ba >= NPARTS) continue;      // 2 parts: hh,hl,lh ; 3 parts: + h l2, l2 h, l l
+#pragma unroll
+                                for (int t = 0; t < TMAX; ++t)
+                                    if (EXACT || t < to) {
+#pragma unroll
+                                        for (int pt = 0; pt < P; ++pt)
+                                            acc[pt][t] = mfma_bf16(wf[t][wa], bf[pt][s][ba], acc[pt][t]);
+                                    }
+                            }
+                    }
+                }
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            act[pt][t][r] = (EXACT || t < to) ? hidden_act_f(acc[pt][t][r], slope) : 0.f;
+            }
+
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s = fmaf(wout[t][r], act[pt][t][r], s);
+                s = group_allreduce(s);
+                const float f = out_act_f(s, m.out_act);
+                Facc[pt] = fmaf(wk, a.inv_f ? 1.f / f : f, Facc[pt]);
+                if (k == 0) fxv[pt] = f;
+                if (k == n) fx0v[pt] = f;
+            }
+        }
+    }
+    fwd_epilogue<P>(a, lds, Facc, fxv, fx0v, ok, qv, dxv, live, part, ns, wid, g, p);
+}
+
+// ------------------------------------------------------------------------------------------
+typedef void (*fwd_bf16_kernel_t)(const FwdBf16Args);
+struct Bf16Variant { int tmax, nparts, p, exact; fwd_bf16_kernel_t fn; const char* name; };
+#define BF16_VARIANT(T, NP, PP, EX) { T, NP, PP, EX, cc_fwd_bf16_kernel<T, NP, PP, (EX) != 0>, "cc_fwd_bf16<T=" #T ",PARTS=" #NP ",P=" #PP ",EXACT=" #EX ">" }
+static const Bf16Variant kBf16Variants[] = {
+    BF16_VARIANT(4, 2, 1, 1), BF16_VARIANT(4, 2, 2, 1), BF16_VARIANT(4, 3, 1, 1), BF16_VARIANT(4, 3, 2, 1),   // widths 48..62
+    BF16_VARIANT(2, 2, 1, 0), BF16_VARIANT(2, 2, 2, 0), BF16_VARIANT(2, 3, 1, 0), BF16_VARIANT(2, 3, 2, 0),
+    BF16_VARIANT(4, 2, 1, 0), BF16_VARIANT(4, 2, 2, 0), BF16_VARIANT(4, 3, 1, 0), BF16_VARIANT(4, 3, 2, 0),
+    BF16_VARIANT(8, 2, 1, 0), BF16_VARIANT(8, 2, 2, 0),   // (8 tiles x 3 parts does not fit the register file: fp32 kernels instead)
+};
+
+// Returns 0 and launches, UMNN_EUNSUPPORTED (without setting the error text's prefix) if the shape does not fit
+// this kernel family (caller then uses the fp32-MFMA kernels), or another error code.
+int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps,
+                             hipStream_t stream) {
+    const int L = a.m.n_linear - 1;
+    int tmax = 0;
+    for (int l = 1; l <= L; ++l) tmax = a.m.t_out[l] > tmax ? a.m.t_out[l] : tmax;
+    const int T = tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8;
+    FwdBf16Args args;
+    args.f = a;
+    int off16 = 0;
+    for (int l = 1; l <= L; ++l) args.pl.ks32[l] = (a.m.t_out[l] + 1) / 2;
+    for (int l = 1; l < L; ++l) {
+        args.pl.off16[l] = off16;
+        off16 += a.m.t_out[l + 1] * args.pl.ks32[l] * nparts * 512;
+    }
+    const int img_floats = (off16 + 1) / 2;
+    args.f.m.lds_off[L] = (img_floats + 3) & ~3;          // NS-reduction scratch starts after the images
+    const size_t lds_bytes = ((size_t)args.f.m.lds_off[L] + (ns > 1 ? UMNN_WAVES_PER_BLOCK * 3 * P * 16 : 0)) * sizeof(float);
+    if (lds_bytes > 160 * 1024) return UMNN_EUNSUPPORTED;
+    int exact = 1;
+    for (int l = 1; l <= L; ++l) exact = exact && a.m.t_out[l] == T;
+    const Bf16Variant* pick = nullptr;
+    for (int ex = exact; ex >= 0 && !pick; --ex)
+        for (const Bf16Variant& v : kBf16Variants)
+            if (v.tmax == T && v.nparts == nparts && v.p == P && v.exact == ex) { pick = &v; break; }
+    if (!pick) return UMNN_EUNSUPPORTED;
+    if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
+    args.f.ns = ns;
+    args.f.ngroups = (unsigned)((a.NI + 16 * P - 1) / (16 * P));
+    const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
+    const unsigned nblk = (args.f.ngroups + gpb - 1) / gpb;
+    umnn_prof_begin(stream);
+    hipLaunchKernelGGL(pick->fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
+    umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * (double)a.NI);
+    umnn_note_launch(pick->name);
+    return umnn_check(hipGetLastError(), "cc_fwd_bf16 launch");
+}
