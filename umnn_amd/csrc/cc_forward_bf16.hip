@@ -310,14 +310,16 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
         for (const Bf16Variant& v : kBf16Variants)
             if (v.tmax == T && v.nparts == nparts && v.p == P && v.exact == ex) { pick = &v; break; }
     if (!pick) return UMNN_EUNSUPPORTED;
-    if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
+    fwd_bf16_kernel_t kfn = pick->fn;
+    const char* kname = pick->name;
+    if (int rc = umnn_allow_lds((const void*)kfn, lds_bytes)) return rc;
     args.f.ns = ns;
     args.f.ngroups = (unsigned)((a.NI + 16 * P - 1) / (16 * P));
     const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
     const unsigned nblk = (args.f.ngroups + gpb - 1) / gpb;
     umnn_prof_begin(stream);
-    hipLaunchKernelGGL(pick->fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
+    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
     umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * (double)a.NI);
-    umnn_note_launch(pick->name);
+    umnn_note_launch(kname);
     return umnn_check(hipGetLastError(), "cc_fwd_bf16 launch");
 }
