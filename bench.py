@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--workload", default="bsds300", choices=sorted(WORKLOADS))
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="eval", choices=["eval", "train"],
+                    help="eval: compute_ll forward (the headline metric). train: forward + backward + one flattened "
+                         "RCCL gradient all-reduce + Adam step per step (reported as training samples/s)")
     ap.add_argument("--precision", default="", choices=["", "fp32", "bf16x3", "bf16x6"],
                     help="forward arithmetic (default: the library default, bf16x3)")
     args = ap.parse_args()
@@ -110,9 +113,23 @@ def main():
     torch.manual_seed(1000 + rank)                      # every rank owns a different shard of the global batch
     x = torch.randn(cfg["rows"], cfg["d"], device=device)
 
-    def step():
-        with torch.no_grad():
-            return model.compute_ll(x)
+    if args.mode == "train":
+        model.train()
+        sharding.broadcast_parameters(model)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            ll, z = model.compute_ll(x)
+            (-ll.mean()).backward()
+            sharding.allreduce_gradients(model, world)          # one flattened all-reduce, before clipping
+            torch.nn.utils.clip_grad_value_(model.parameters(), 10.0)
+            opt.step()
+            return ll.detach(), z
+    else:
+        def step():
+            with torch.no_grad():
+                return model.compute_ll(x)
 
     for _ in range(args.warmup):
         step()
@@ -155,7 +172,8 @@ def main():
                  "bf16x6": "f32 via bf16x6-split MFMA (fp32 accumulate)"}[precision] if on_bf16 or precision == "fp32" \
             else "f32"
         out = {
-            "metric": "umnn_maf_log_density_evals_per_s", "value": value, "unit": "evals/s",
+            "metric": "umnn_maf_log_density_evals_per_s" if args.mode == "eval" else "umnn_maf_training_samples_per_s",
+            "value": value, "unit": "evals/s" if args.mode == "eval" else "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": cfg["desc"], "rows_per_gpu": cfg["rows"], "dim": cfg["d"], "n_steps": cfg["n"],
@@ -175,7 +193,10 @@ def main():
                          "peak_dtype": "bf16 dense MFMA" if on_bf16 else "fp32 MFMA",
                          "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.mode == "train":
+            out["config"]["mode"] = "train: fwd + HIP bwd + flattened gradient all-reduce (RCCL) + Adam"
+            out["roofline"] = None      # the per-launch timing above mixes forward and backward launches
+        if world == 1 and not args.no_cpu_baseline and args.mode == "eval":
             out["cpu_baseline"] = cpu_baseline(cfg, model)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)

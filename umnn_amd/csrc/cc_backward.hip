@@ -78,33 +78,35 @@ __device__ __forceinline__ void stage_rowmajor_images(const BwdArgs& a, float* l
 }
 
 // out[t] = sum_s W-fragment(t, s) * in[s]   (forward orientation; image row = output feature)
-template <int TMAX>
+// KSC > 0: exact shapes -- every hidden layer has KSC K-steps and fills all TMAX tiles, so the wave-uniform guards
+// (and the register copies they force at every basic-block boundary) vanish.  KSC = 0: per-layer runtime counts.
+template <int TMAX, int KSC>
 __device__ __forceinline__ void layer_fwd(const float* wf, int LD, int ks, int to, const f32x4 (&in)[TMAX],
                                           f32x4 (&out)[TMAX]) {
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) out[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4 * TMAX; ++s) {
-        if (s < ks) {
+        if (KSC ? (s < KSC) : (s < ks)) {
 #pragma unroll
             for (int t = 0; t < TMAX; ++t)
-                if (t < to) out[t] = mfma16(wf[16 * t * LD + 4 * s], in[s >> 2][s & 3], out[t]);
+                if (KSC || t < to) out[t] = mfma16(wf[16 * t * LD + 4 * s], in[s >> 2][s & 3], out[t]);
         }
     }
 }
 
 // out[t] = sum_s W^T-fragment(t, s) * in[s]   (backward orientation; image row = K index)
-template <int TMAX>
+template <int TMAX, int KSC>
 __device__ __forceinline__ void layer_bwd(const float* wt, int LD, int ks, int to, const f32x4 (&in)[TMAX],
                                           f32x4 (&out)[TMAX]) {
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) out[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4 * TMAX; ++s) {
-        if (s < ks) {
+        if (KSC ? (s < KSC) : (s < ks)) {
 #pragma unroll
             for (int t = 0; t < TMAX; ++t)
-                if (t < to) out[t] = mfma16(wt[4 * s * LD + 16 * t], in[s >> 2][s & 3], out[t]);
+                if (KSC || t < to) out[t] = mfma16(wt[4 * s * LD + 16 * t], in[s >> 2][s & 3], out[t]);
         }
     }
 }
@@ -119,7 +121,7 @@ __device__ __forceinline__ unsigned sign_bits(const f32x4 (&v)[TMAX]) {
     return bits;
 }
 
-template <int TMAX, int NACC, bool EDGE>
+template <int TMAX, int NACC, bool EDGE, int KSC>
 __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const MlpDev& m = a.m;
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
                 const float hv = e < E ? hb[(long long)e * d] : 0.f;
 #pragma unroll
                 for (int t = 0; t < TMAX; ++t) {
-                    if (t < m.t_out[1]) {
+                    if (KSC || t < m.t_out[1]) {
                         const int fo = fout_of(t, p);
                         const float A = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
                         c[t] = mfma16(A, hv, c[t]);
@@ -240,11 +242,12 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
                             for (int r = 0; r < 4; ++r) scratch[j * (TMAX * 256) + (16 * t + 4 * r) * 16 + wr_off] = act[t][r];
                     }
                 f32x4 acc[TMAX];
-                layer_fwd<TMAX>(lds + a.roff[l] + perm16(p) * a.ld[l] + g, a.ld[l], m.ks_in[l], m.t_out[l + 1], act, acc);
+                layer_fwd<TMAX, KSC>(lds + a.roff[l] + perm16(p) * a.ld[l] + g, a.ld[l], m.ks_in[l], m.t_out[l + 1], act, acc);
 #pragma unroll
                 for (int t = 0; t < TMAX; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) act[t][r] = t < m.t_out[l + 1] ? hidden_act_f(acc[t][r], slope) : 0.f;
+                    for (int r = 0; r < 4; ++r)
+                        act[t][r] = (KSC || t < m.t_out[l + 1]) ? hidden_act_f(acc[t][r], slope) : 0.f;
                 bits[l + 1] = sign_bits<TMAX>(act);
             }
             float sdot = 0.f;
@@ -268,12 +271,12 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
                         ta[t][r] = w1x[t][r] * ((bits[1] >> (4 * t + r)) & 1u ? 1.f : slope);
                 for (int l = 1; l < L; ++l) {
                     f32x4 tz[TMAX];
-                    layer_fwd<TMAX>(lds + a.roff[l] + perm16(p) * a.ld[l] + g, a.ld[l], m.ks_in[l], m.t_out[l + 1], ta, tz);
+                    layer_fwd<TMAX, KSC>(lds + a.roff[l] + perm16(p) * a.ld[l] + g, a.ld[l], m.ks_in[l], m.t_out[l + 1], ta, tz);
 #pragma unroll
                     for (int t = 0; t < TMAX; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            ta[t][r] = t < m.t_out[l + 1] ? tz[t][r] * ((bits[l + 1] >> (4 * t + r)) & 1u ? 1.f : slope) : 0.f;
+                            ta[t][r] = (KSC || t < m.t_out[l + 1]) ? tz[t][r] * ((bits[l + 1] >> (4 * t + r)) & 1u ? 1.f : slope) : 0.f;
                 }
                 float ds = 0.f;
 #pragma unroll
@@ -311,10 +314,10 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
                         }
 #pragma unroll
                         for (int to = 0; to < TMAX; ++to)
-                            if (to < m.t_out[l + 1]) {
+                            if (KSC || to < m.t_out[l + 1]) {
 #pragma unroll
                                 for (int ti = 0; ti < TMAX; ++ti)
-                                    if (ti < m.t_out[l]) {
+                                    if (KSC || ti < m.t_out[l]) {
 #pragma unroll
                                         for (int r = 0; r < 4; ++r)
                                             dW[j][to][ti] = mfma16(dT[to][r], aT[ti][r], dW[j][to][ti]);
@@ -323,12 +326,12 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
                     }
                 // delta_l = (W_l^T delta_{l+1}) * act'(z_l)
                 f32x4 nd[TMAX];
-                layer_bwd<TMAX>(lds + a.roff[l] + g * a.ld[l] + perm16(p), a.ld[l], m.ks_in[l + 1], m.t_out[l], delta, nd);
+                layer_bwd<TMAX, KSC>(lds + a.roff[l] + g * a.ld[l] + perm16(p), a.ld[l], m.ks_in[l + 1], m.t_out[l], delta, nd);
 #pragma unroll
                 for (int t = 0; t < TMAX; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        delta[t][r] = t < m.t_out[l] ? nd[t][r] * ((bits[l] >> (4 * t + r)) & 1u ? 1.f : slope) : 0.f;
+                        delta[t][r] = (KSC || t < m.t_out[l]) ? nd[t][r] * ((bits[l] >> (4 * t + r)) & 1u ? 1.f : slope) : 0.f;
             }
             if (EDGE) {
 #pragma unroll
@@ -469,13 +472,14 @@ __global__ __launch_bounds__(256) void cc_bwd_reduce_kernel(const float* __restr
 // host side
 // ------------------------------------------------------------------------------------------
 typedef void (*bwd_kernel_t)(const BwdArgs);
-struct BwdVariant { int tmax, nacc, edge; bwd_kernel_t fn; const char* name; };
-#define BWD_VARIANT(T, N, E) { T, N, E, cc_bwd_kernel<T, N, (E) != 0>, "cc_bwd<T=" #T ",NACC=" #N ",EDGE=" #E ">" }
+struct BwdVariant { int tmax, nacc, edge, ksc; bwd_kernel_t fn; const char* name; };
+#define BWD_VARIANT(T, N, E, K) { T, N, E, K, cc_bwd_kernel<T, N, (E) != 0, K>, "cc_bwd<T=" #T ",NACC=" #N ",EDGE=" #E ",KS=" #K ">" }
 static const BwdVariant kBwdVariants[] = {
-    BWD_VARIANT(2, 3, 1), BWD_VARIANT(2, 3, 0),
-    BWD_VARIANT(4, 3, 1), BWD_VARIANT(4, 3, 0),
-    BWD_VARIANT(7, 0, 1), BWD_VARIANT(7, 1, 0),
-    BWD_VARIANT(8, 0, 1), BWD_VARIANT(8, 1, 0),
+    BWD_VARIANT(4, 3, 1, 13), BWD_VARIANT(4, 3, 0, 13),     // exact: every hidden layer 48..51 wide (UCI / VAE nets)
+    BWD_VARIANT(2, 3, 1, 0), BWD_VARIANT(2, 3, 0, 0),
+    BWD_VARIANT(4, 3, 1, 0), BWD_VARIANT(4, 3, 0, 0),
+    BWD_VARIANT(7, 0, 1, 0), BWD_VARIANT(7, 1, 0, 0),
+    BWD_VARIANT(8, 0, 1, 0), BWD_VARIANT(8, 1, 0, 0),
 };
 
 static int pick_tmax_bwd(int tmax) { return tmax <= 2 ? 2 : tmax <= 4 ? 4 : tmax <= 7 ? 7 : 8; }
@@ -505,6 +509,7 @@ static int pick_ld(int cols) {
 struct BwdPlan {
     BwdArgs a;
     int tmax;          // template tile count
+    int ksu;           // common K-step count when every hidden layer fills exactly `tmax` tiles, else 0
     int nwaves, nblocks, wpb;
     size_t lds_bytes_for(int nacc, int waves) const { return (size_t)(a.scratch_off + waves * (nacc + 1) * tmax * 256) * sizeof(float); }
     long long ws_partials, ws_dc, ws_p0;   // byte offsets in the workspace
@@ -518,6 +523,7 @@ static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan
     BwdArgs& a = pl->a;
     const int L = a.m.n_linear - 1;
     pl->tmax = pick_tmax_bwd(tmax);
+    pl->ksu = (ksu && tmax == pl->tmax) ? ksu : 0;
     int off = 0;
     for (int l = 1; l < L; ++l) {
         a.ld[l] = pick_ld(4 * a.m.ks_in[l]);
@@ -564,9 +570,10 @@ extern "C" long long umnn_cc_backward_workspace_bytes(const umnn_mlp* net, long 
     return pl.ws_total;
 }
 
-static const BwdVariant* find_bwd(int tmax, int nacc, int edge) {
-    for (const BwdVariant& v : kBwdVariants)
-        if (v.tmax == tmax && v.nacc == nacc && v.edge == edge) return &v;
+static const BwdVariant* find_bwd(int tmax, int nacc, int edge, int ksu) {
+    for (int exact = 1; exact >= 0; --exact)
+        for (const BwdVariant& v : kBwdVariants)
+            if (v.tmax == tmax && v.nacc == nacc && v.edge == edge && (exact ? (v.ksc && v.ksc == ksu) : !v.ksc)) return &v;
     return nullptr;
 }
 
@@ -605,7 +612,7 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
     int l_next = 1;
     for (int pass = 0; pass == 0 || l_next < L; ++pass) {
         const int nacc = pass == 0 ? nacc_main : nacc_rest;
-        const BwdVariant* v = find_bwd(T, nacc, pass == 0 ? 1 : 0);
+        const BwdVariant* v = find_bwd(T, nacc, pass == 0 ? 1 : 0, pl.ksu);
         if (!v) return umnn_fail(UMNN_EUNSUPPORTED, "backward: no kernel variant for this width");
         a.l_lo = l_next;
         a.scratch_per_wave = (nacc + 1) * T * 256;
