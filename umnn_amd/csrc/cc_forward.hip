@@ -18,9 +18,10 @@
 #include "cc_fwd_shared.h"
 
 // TAIL = 1 (exact variants only): the last tile holds at most 4 features (<= 3 real ones + the constant), all
-// in component r = 0.  Giving that tile 13 or 26 MFMAs to produce 2-3 useful rows wastes a quarter of the
-// matrix pipe, so it is computed on the otherwise idle VALU instead: each lane dots its own K-slice of the
-// tail rows (weights broadcast from LDS as b128) and the four lane groups are summed with row/half swaps.
+// in component r = 0.  Giving that tile 13 MFMAs (416 cycles) to produce 2-3 useful rows costs more than computing
+// them on the VALU (~45 instructions, ~130 cycles; MFMA and VALU time add on this hardware): each
+// lane dots its own K-slice of the tail rows (weights broadcast from LDS as b128) and the four lane groups are
+// summed with row/half swaps.
 template <int TMAX, int KSC, int P, int TAIL, int NT>
 __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_kernel(const FwdArgs a) {
     constexpr int TT = TMAX - TAIL;            // tiles produced by MFMA; NT = real features of the VALU tail tile
