@@ -10,11 +10,14 @@
 // Layer 1 (one FMA per feature), the hoisted first-layer term, the output dot product, ELU and the quadrature sum
 // stay in fp32.  Same reference lines as cc_forward.hip.
 //
-// Layout: natural feature numbering, lane (g,p) / tile t / component r <-> feature 16t + 4g + r (the accumulator
-// row order of the 16x16 MFMAs).  One K-step of 16x16x32 consumes 32 features = two tiles (2s, 2s+1); lane group g
-// supplies k-slots 8g..8g+7 = its own 4 components of tile 2s followed by its 4 components of tile 2s+1 -- again
-// the accumulators of one layer ARE (after activation, splitting and packing) the B operands of the next, with no
-// cross-lane movement.  Weight fragments are pre-split and pre-permuted into LDS: fragment (tile t', K-step s, part)
+// Layout: the same feature numbering as the fp32 kernels, lane (g,p) / tile t / component r <-> feature 16t + 4r + g
+// (accumulator row rho = 4g + r of tile t is given output feature 16t + 4(rho&3) + (rho>>2) when the weight image
+// is staged).  Features are therefore dense in the register index 4t + r: a layer of width H has only
+// ceil((H+1)/4) live registers per lane (13 of 16 for H = 50) and the activation / split VALU work of the dead
+// ones is skipped (NRL template parameter).  One K-step of 16x16x32 consumes 32 features = two tiles (2s, 2s+1);
+// lane group g supplies k-slots 8g..8g+7 = its own 4 components of tile 2s followed by its 4 components of tile
+// 2s+1 -- again the accumulators of one layer ARE (after activation, splitting and packing) the B operands of the
+// next, with no cross-lane movement.  Weight fragments are pre-split and pre-permuted into LDS: fragment (tile t', K-step s, part)
 // is 64 lanes x 8 bf16 = 1 KiB, read with one ds_read_b128 per lane.
 #include "cc_fwd_shared.h"
 #include "cc_host.h"
@@ -64,8 +67,8 @@ __device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks
         for (int idx = tid; idx < total; idx += nthreads) {
             const int j = idx & 7, ln = (idx >> 3) & 63, ts = idx >> 9;
             const int s = ts % ks, t = ts / ks;
-            const int fo = 16 * t + (ln & 15);
-            const int fi = 16 * (2 * s + (j >> 2)) + 4 * (ln >> 4) + (j & 3);
+            const int fo = fout_of(t, ln & 15);
+            const int fi = feat_of(2 * s + (j >> 2), j & 3, ln >> 4);
             float v = 0.f;
             if (fo < Hout) {
                 if (fi < Hin) v = W[fo * Hin + fi];
@@ -96,9 +99,11 @@ struct FwdBf16Args {
 
 // EXACT: every hidden layer fills exactly TMAX tiles, so tile / K-step counts are compile-time constants and the
 // wave-uniform guards (and the accumulator copies they force at every basic-block boundary) disappear.
-template <int TMAX, int NPARTS, int P, bool EXACT>
+// NRL (EXACT only): live registers per lane = ceil((H+1)/4) for the common hidden width H; 0 = all 4*TMAX.
+template <int TMAX, int NPARTS, int P, bool EXACT, int NRL>
 __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Args args) {
     constexpr int KSM = TMAX / 2;
+    constexpr int NLIVE = NRL > 0 ? NRL : 4 * TMAX;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FwdArgs& a = args.f;
     const MlpDev& m = a.m;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 f32x4 init;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int f = 16 * t + 4 * g + r;
+                    const int f = feat_of(t, r, g);
                     w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
                     wout[t][r] = f < HL ? WL[f] : (f == HL ? bL : 0.f);
                     init[r] = f < H1 ? b0[f] : (f == H1 ? 1.f : 0.f);
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
 #pragma unroll
                 for (int t = 0; t < TMAX; ++t) {
                     if (EXACT || t < t1) {
-                        const int fo = 16 * t + p;
+                        const int fo = fout_of(t, p);
                         const float A = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
 #pragma unroll
                         for (int pt = 0; pt < P; ++pt) c[pt][t] = mfma16(A, hv[pt], c[pt][t]);
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 for (int t = 0; t < TMAX; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        act[pt][t][r] = hidden_act_f(fmaf(w1x[t][r], tk, c[pt][t][r]), slope);
+                        act[pt][t][r] = 4 * t + r < NLIVE ? hidden_act_f(fmaf(w1x[t][r], tk, c[pt][t][r]), slope) : 0.f;
             }
 
             for (int l = 1; l < L; ++l) {
@@ -206,10 +211,12 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
 #pragma unroll
                     for (int s = 0; s < KSM; ++s) {
                         unsigned q0[NPARTS], q1[NPARTS], q2[NPARTS], q3[NPARTS];
-                        split_pair<NPARTS>(act[pt][2 * s][0], act[pt][2 * s][1], q0);
-                        split_pair<NPARTS>(act[pt][2 * s][2], act[pt][2 * s][3], q1);
-                        split_pair<NPARTS>(act[pt][2 * s + 1][0], act[pt][2 * s + 1][1], q2);
-                        split_pair<NPARTS>(act[pt][2 * s + 1][2], act[pt][2 * s + 1][3], q3);
+#pragma unroll
+                        for (int k2 = 0; k2 < NPARTS; ++k2) q0[k2] = q1[k2] = q2[k2] = q3[k2] = 0u;
+                        if (8 * s + 0 < NLIVE) split_pair<NPARTS>(act[pt][2 * s][0], act[pt][2 * s][1], q0);
+                        if (8 * s + 2 < NLIVE) split_pair<NPARTS>(act[pt][2 * s][2], act[pt][2 * s][3], q1);
+                        if (8 * s + 4 < NLIVE) split_pair<NPARTS>(act[pt][2 * s + 1][0], act[pt][2 * s + 1][1], q2);
+                        if (8 * s + 6 < NLIVE) split_pair<NPARTS>(act[pt][2 * s + 1][2], act[pt][2 * s + 1][3], q3);
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) bf[pt][s][k2] = u32x4{q0[k2], q1[k2], q2[k2], q3[k2]};
                     }
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     for (int t = 0; t < TMAX; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            act[pt][t][r] = (EXACT || t < to) ? hidden_act_f(acc[pt][t][r], slope) : 0.f;
+                            act[pt][t][r] = ((EXACT || t < to) && 4 * t + r < NLIVE) ? hidden_act_f(acc[pt][t][r], slope) : 0.f;
             }
 
 #pragma unroll
@@ -260,7 +267,8 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
 #pragma unroll
                 for (int t = 0; t < TMAX; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s = fmaf(wout[t][r], act[pt][t][r], s);
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * t + r < NLIVE) s = fmaf(wout[t][r], act[pt][t][r], s);
                 s = group_allreduce(s);
                 const float f = out_act_f(s, m.out_act);
                 Facc[pt] = fmaf(wk, a.inv_f ? 1.f / f : f, Facc[pt]);
@@ -274,13 +282,14 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
 
 // ------------------------------------------------------------------------------------------
 typedef void (*fwd_bf16_kernel_t)(const FwdBf16Args);
-struct Bf16Variant { int tmax, nparts, p, exact; fwd_bf16_kernel_t fn; const char* name; };
-#define BF16_VARIANT(T, NP, PP, EX) { T, NP, PP, EX, cc_fwd_bf16_kernel<T, NP, PP, (EX) != 0>, "cc_fwd_bf16<T=" #T ",PARTS=" #NP ",P=" #PP ",EXACT=" #EX ">" }
+struct Bf16Variant { int tmax, nparts, p, exact, nrl; fwd_bf16_kernel_t fn; const char* name; };
+#define BF16_VARIANT(T, NP, PP, EX, NR) { T, NP, PP, EX, NR, cc_fwd_bf16_kernel<T, NP, PP, (EX) != 0, NR>, "cc_fwd_bf16<T=" #T ",PARTS=" #NP ",P=" #PP ",EXACT=" #EX ",LIVE=" #NR ">" }
 static const Bf16Variant kBf16Variants[] = {
-    BF16_VARIANT(4, 2, 1, 1), BF16_VARIANT(4, 2, 2, 1), BF16_VARIANT(4, 3, 1, 1), BF16_VARIANT(4, 3, 2, 1),   // widths 48..62
-    BF16_VARIANT(2, 2, 1, 0), BF16_VARIANT(2, 2, 2, 0), BF16_VARIANT(2, 3, 1, 0), BF16_VARIANT(2, 3, 2, 0),
-    BF16_VARIANT(4, 2, 1, 0), BF16_VARIANT(4, 2, 2, 0), BF16_VARIANT(4, 3, 1, 0), BF16_VARIANT(4, 3, 2, 0),
-    BF16_VARIANT(8, 2, 1, 0), BF16_VARIANT(8, 2, 2, 0),   // (8 tiles x 3 parts does not fit the register file: fp32 kernels instead)
+    BF16_VARIANT(4, 2, 1, 1, 13), BF16_VARIANT(4, 2, 2, 1, 13), BF16_VARIANT(4, 3, 1, 1, 13), BF16_VARIANT(4, 3, 2, 1, 13),   // widths 48..51
+    BF16_VARIANT(4, 2, 1, 1, 0), BF16_VARIANT(4, 2, 2, 1, 0), BF16_VARIANT(4, 3, 1, 1, 0), BF16_VARIANT(4, 3, 2, 1, 0),       // widths 52..62
+    BF16_VARIANT(2, 2, 1, 0, 0), BF16_VARIANT(2, 2, 2, 0, 0), BF16_VARIANT(2, 3, 1, 0, 0), BF16_VARIANT(2, 3, 2, 0, 0),
+    BF16_VARIANT(4, 2, 1, 0, 0), BF16_VARIANT(4, 2, 2, 0, 0), BF16_VARIANT(4, 3, 1, 0, 0), BF16_VARIANT(4, 3, 2, 0, 0),
+    BF16_VARIANT(8, 2, 1, 0, 0), BF16_VARIANT(8, 2, 2, 0, 0),   // (8 tiles x 3 parts does not fit the register file: fp32 kernels instead)
 };
 
 // Returns 0 and launches, UMNN_EUNSUPPORTED (without setting the error text's prefix) if the shape does not fit
@@ -303,12 +312,17 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
     args.f.m.lds_off[L] = (img_floats + 3) & ~3;          // NS-reduction scratch starts after the images
     const size_t lds_bytes = ((size_t)args.f.m.lds_off[L] + (ns > 1 ? UMNN_WAVES_PER_BLOCK * 3 * P * 16 : 0)) * sizeof(float);
     if (lds_bytes > 160 * 1024) return UMNN_EUNSUPPORTED;
-    int exact = 1;
-    for (int l = 1; l <= L; ++l) exact = exact && a.m.t_out[l] == T;
+    int exact = 1, nrl = a.m.ks_in[1];        // live registers per lane when every hidden layer has the same K-step count
+    for (int l = 1; l <= L; ++l) {
+        exact = exact && a.m.t_out[l] == T;
+        if (a.m.ks_in[l] != nrl) nrl = 0;
+    }
     const Bf16Variant* pick = nullptr;
     for (int ex = exact; ex >= 0 && !pick; --ex)
-        for (const Bf16Variant& v : kBf16Variants)
-            if (v.tmax == T && v.nparts == nparts && v.p == P && v.exact == ex) { pick = &v; break; }
+        for (int pass = 0; pass < 2 && !pick; ++pass)      // pass 0: a variant with exactly this live-register count
+            for (const Bf16Variant& v : kBf16Variants)
+                if (v.tmax == T && v.nparts == nparts && v.p == P && v.exact == ex &&
+                    (pass == 0 ? (ex && nrl && v.nrl == nrl) : v.nrl == 0)) { pick = &v; break; }
     if (!pick) return UMNN_EUNSUPPORTED;
     fwd_bf16_kernel_t kfn = pick->fn;
     const char* kname = pick->name;
