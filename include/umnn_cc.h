@@ -129,6 +129,11 @@ int umnn_cc_forward_timed(const umnn_mlp* net, const float* x0, const float* x, 
 #define UMNN_PRECISION_BF16X6 2
 int umnn_set_forward_precision(int mode);
 int umnn_get_forward_precision(void);
+/* Same for the backward kernels: UMNN_PRECISION_FP32 or UMNN_PRECISION_BF16X3 (default; env UMNN_BWD_PRECISION =
+ * fp32 | bf16x3).  The bf16 kernels cover nets whose hidden layers are all 48..62 wide with <= 3 hidden->hidden
+ * layers; other shapes always run the fp32 kernels. */
+int umnn_set_backward_precision(int mode);
+int umnn_get_backward_precision(void);
 
 /* Per-launch timing: while enabled, every forward/backward launch is bracketed by hipEvents recorded on its own
  * launch stream.  umnn_profile_read synchronises on them and returns the summed kernel milliseconds, the number of

@@ -21,8 +21,18 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True, params=["bf16x3", "fp32"])
+def bwd_precision(request):
+    """Every gradient-parity test runs with both arithmetic modes of the backward kernels (same tolerance)."""
+    import umnn_amd
+    old = umnn_amd.get_backward_precision()
+    umnn_amd.set_backward_precision(request.param)
+    yield request.param
+    umnn_amd.set_backward_precision(old)
+
+
 @pytest.mark.parametrize("name", U.g2_names())
-def test_backward_matches_golden(name, dev):
+def test_backward_matches_golden(name, dev, bwd_precision):
     from umnn_amd import integral as I, _lib
     from umnn_amd.nets import mlp_spec
     G = U.load(name)

@@ -51,6 +51,8 @@ SIGNATURES = {
                                              ctypes.POINTER(ctypes.c_float), _fp]),
     "umnn_set_forward_precision": (ctypes.c_int, [ctypes.c_int]),
     "umnn_get_forward_precision": (ctypes.c_int, []),
+    "umnn_set_backward_precision": (ctypes.c_int, [ctypes.c_int]),
+    "umnn_get_backward_precision": (ctypes.c_int, []),
     "umnn_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "umnn_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_ll),
                                          ctypes.POINTER(ctypes.c_double)]),
@@ -97,4 +99,14 @@ def set_forward_precision(name):
 
 def get_forward_precision():
     mode = lib().umnn_get_forward_precision()
+    return next(k for k, v in PRECISIONS.items() if v == mode)
+
+
+def set_backward_precision(name):
+    """'fp32' or 'bf16x3' (default) for the GEMMs of the backward kernels."""
+    check(lib().umnn_set_backward_precision(PRECISIONS[name]), "umnn_set_backward_precision")
+
+
+def get_backward_precision():
+    mode = lib().umnn_get_backward_precision()
     return next(k for k, v in PRECISIONS.items() if v == mode)

@@ -20,36 +20,9 @@
 //     finishing kernels turn it into d_h = W1h^T dc and dW1[:,1:], db1;
 //   * every wave writes its partial d_theta to its own slice of the workspace; a last kernel sums the slices
 //     (deterministic, no atomics).
-#include "cc_host.h"
+#include <cstring>
 
-struct BwdArgs {
-    MlpDev m;
-    int ld[UMNN_MAX_LINEAR];        // row stride (floats) of the row-major image of hidden layer l -> l+1
-    int roff[UMNN_MAX_LINEAR];      // float offset of that image in LDS
-    int poffW[UMNN_MAX_LINEAR];     // offset of W_l / b_l in the flat theta vector
-    int poffb[UMNN_MAX_LINEAR];
-    const float* x0;
-    const float* x;
-    const float* h;
-    const float* g;
-    const float* gfx;               // nullable
-    const float* ccw;
-    const float* ccs;
-    float* dx0;                     // nullable
-    float* dx;                      // nullable
-    float* dc;                      // [NI][H1] (EDGE pass)
-    float* partials;                // [nwaves][n_params]
-    long long NI;
-    int d, E, n;
-    unsigned ngroups;               // tiles of 16 integrals
-    int l_lo;                       // this pass accumulates dW for hidden layers l_lo .. l_lo+NACC-1
-    int n_params;
-    int scratch_off;                // float offset of the per-wave scratch region in LDS
-    int scratch_per_wave;           // floats
-};
-
-// permutation that turns an accumulator row (lane&15 in an A operand) into a feature offset inside a tile
-__device__ __forceinline__ int perm16(int rho) { return 4 * (rho & 3) + (rho >> 2); }
+#include "cc_bwd_shared.h"
 
 __device__ __forceinline__ void stage_rowmajor_images(const BwdArgs& a, float* lds, int tid, int nthreads) {
     const MlpDev& m = a.m;
@@ -577,6 +550,26 @@ static const BwdVariant* find_bwd(int tmax, int nacc, int edge, int ksu) {
     return nullptr;
 }
 
+int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblocks_max, int* nwaves_out, hipStream_t stream);
+
+// arithmetic of the backward GEMMs: UMNN_PRECISION_FP32 or UMNN_PRECISION_BF16X3 (default)
+static int g_bwd_precision = -1;
+static int bwd_precision() {
+    if (g_bwd_precision < 0) {
+        int mode = UMNN_PRECISION_BF16X3;
+        if (const char* ev = getenv("UMNN_BWD_PRECISION")) mode = !strcmp(ev, "fp32") ? UMNN_PRECISION_FP32 : UMNN_PRECISION_BF16X3;
+        g_bwd_precision = mode;
+    }
+    return g_bwd_precision;
+}
+extern "C" int umnn_set_backward_precision(int mode) {
+    if (mode != UMNN_PRECISION_FP32 && mode != UMNN_PRECISION_BF16X3)
+        return umnn_fail(UMNN_EINVAL, "backward precision must be UMNN_PRECISION_FP32 or UMNN_PRECISION_BF16X3");
+    g_bwd_precision = mode;
+    return 0;
+}
+extern "C" int umnn_get_backward_precision(void) { return bwd_precision(); }
+
 extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const float* x, const float* h,
                                 const float* g, const float* g_fx,
                                 const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
@@ -605,12 +598,20 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
     float* p0 = (float*)(ws + pl.ws_p0);
     if (int rc = umnn_check(hipMemsetAsync(a.partials, 0, (size_t)pl.nwaves * a.n_params * 4, stream), "memset partials")) return rc;
 
+    // ---- bf16-split kernels (default) where the shape allows; otherwise / on request the fp32-MFMA kernels below
+    bool done = false;
+    if (bwd_precision() == UMNN_PRECISION_BF16X3) {
+        int nw = 0;
+        const int rc = umnn_launch_backward_bf16(a, net, pl.nblocks, &nw, stream);
+        if (rc == 0) done = true;
+        else if (rc != UMNN_EUNSUPPORTED) return rc;
+    }
     // ---- passes: the EDGE pass (with as many dW layers as its variant holds), then the remaining layers
     const int T = pl.tmax;
     const int nacc_main = (T <= 4) ? 3 : 0;
     const int nacc_rest = (T <= 4) ? 3 : 1;
     int l_next = 1;
-    for (int pass = 0; pass == 0 || l_next < L; ++pass) {
+    for (int pass = 0; !done && (pass == 0 || l_next < L); ++pass) {
         const int nacc = pass == 0 ? nacc_main : nacc_rest;
         const BwdVariant* v = find_bwd(T, nacc, pass == 0 ? 1 : 0, pl.ksu);
         if (!v) return umnn_fail(UMNN_EUNSUPPORTED, "backward: no kernel variant for this width");

@@ -1,0 +1,33 @@
+// Shared by the backward kernels (fp32-MFMA and bf16-split): launch arguments.
+#pragma once
+#include "cc_host.h"
+
+struct BwdArgs {
+    MlpDev m;
+    int ld[UMNN_MAX_LINEAR];        // row stride (floats) of the row-major image of hidden layer l -> l+1
+    int roff[UMNN_MAX_LINEAR];      // float offset of that image in LDS
+    int poffW[UMNN_MAX_LINEAR];     // offset of W_l / b_l in the flat theta vector
+    int poffb[UMNN_MAX_LINEAR];
+    const float* x0;
+    const float* x;
+    const float* h;
+    const float* g;
+    const float* gfx;               // nullable
+    const float* ccw;
+    const float* ccs;
+    float* dx0;                     // nullable
+    float* dx;                      // nullable
+    float* dc;                      // [NI][H1] (EDGE pass)
+    float* partials;                // [nwaves][n_params]
+    long long NI;
+    int d, E, n;
+    unsigned ngroups;               // tiles of 16 integrals
+    int l_lo;                       // this pass accumulates dW for hidden layers l_lo .. l_lo+NACC-1
+    int n_params;
+    int scratch_off;                // float offset of the per-wave scratch region in LDS
+    int scratch_per_wave;           // floats
+};
+
+// permutation that turns an accumulator row (lane&15 in an A operand) into a feature offset inside a tile
+__device__ __forceinline__ int perm16(int rho) { return 4 * (rho & 3) + (rho >> 2); }
+
