@@ -277,3 +277,61 @@ def test_large_batch_65536_rows(dev):
     for rows in (slice(0, 64), slice(B - 64, B)):
         Fs, _, _ = I.hip_forward(spec, None, x[rows].contiguous(), h[rows].contiguous(), n)
         assert U.rel_err(Fs.cpu().numpy(), F[rows].cpu().numpy()) < 2e-5
+
+
+def _random_case(seed):
+    rng = np.random.RandomState(seed)
+    depth = int(rng.randint(1, 8))                          # 1..7 hidden layers
+    hid = [int(rng.choice([rng.randint(1, 128), 50, 16, 48, 63, 64, 100, 127])) for _ in range(depth)]
+    d = int(rng.choice([1, 2, 3, 6, 17, 63]))
+    E = int(rng.choice([1, 2, 10, 30, 37]))
+    n = int(rng.choice([1, 2, 7, 20, 51]))
+    B = int(rng.randint(1, 40))
+    relu = bool(rng.randint(0, 2))
+    sigmoid = bool(rng.randint(0, 4) == 0)
+    return depth, hid, d, E, n, B, relu, sigmoid
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_mlp_shapes_forward_and_backward(seed, dev):
+    """Random depth / widths / d / E / n / batch: whatever kernel family the launcher picks (exact, generic, bf16 or
+    the fp32 fallback when LDS does not fit) must agree with the oracle, forward and backward."""
+    from umnn_amd import integral as I, _lib
+    from umnn_amd.nets import MlpSpec
+    depth, hid, d, E, n, B, relu, sigmoid = _random_case(seed)
+    rng = np.random.RandomState(1000 + seed)
+    sizes = [1 + E] + hid + [1]
+    Ws = [(rng.randn(sizes[i + 1], sizes[i]) * (1.5 / np.sqrt(sizes[i]))).astype(np.float32) for i in range(len(sizes) - 1)]
+    bs = [(rng.randn(sizes[i + 1]) * 0.3).astype(np.float32) for i in range(len(sizes) - 1)]
+    lin = []
+    for W, b in zip(Ws, bs):
+        m = torch.nn.Linear(W.shape[1], W.shape[0])
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(W))
+            m.bias.copy_(torch.from_numpy(b))
+        lin.append(m.to(dev))
+    spec = MlpSpec(lin, _lib.ACT_RELU if relu else _lib.ACT_LEAKY_RELU,
+                   _lib.OUT_SIGMOID if sigmoid else _lib.OUT_ELU_PLUS_ONE)
+    onet = O.Net(Ws, bs, O.RELU if relu else O.LEAKY, O.SIGMOID if sigmoid else O.ELU1)
+    x = (rng.randn(B, d) * 2).astype(np.float32)
+    x0 = (rng.randn(B, d) * 0.5).astype(np.float32)
+    h = rng.randn(B, E * d).astype(np.float32)
+    g = rng.randn(B, d).astype(np.float32)
+    try:
+        F, fx, fx0 = I.hip_forward(spec, t(x0, dev), t(x, dev), t(h, dev), n)
+    except RuntimeError as e:                               # only "does not fit LDS" may refuse, and it must say so
+        assert "LDS" in str(e), str(e)
+        return
+    assert U.rel_err(F.cpu().numpy(), O.integrate_parallel(onet, x0, x, h, n)) < TOL
+    assert U.rel_err(fx.cpu().numpy(), O.integrand(onet, x, h)) < TOL
+    assert U.rel_err(fx0.cpu().numpy(), O.integrand(onet, x0, h)) < TOL
+    try:
+        dx0, dx, dh, dth = I.hip_backward(spec, t(x0, dev), t(x, dev), t(h, dev), t(g, dev), None, n)
+    except RuntimeError as e:
+        assert "LDS" in str(e), str(e)
+        return
+    rdx0, rdx, rdh, _, _, rflat = O.integrate_backward(onet, x0, x, h, n, g)
+    assert U.rel_err(dx0.cpu().numpy(), rdx0) < TOL and U.rel_err(dx.cpu().numpy(), rdx) < TOL
+    # ReLU nets at random init have kinks exactly where fp32 summation order decides the sign: allow a few 1e-4
+    assert U.scaled_err(dh.cpu().numpy(), rdh) < 5e-4
+    assert U.scaled_err(dth.cpu().numpy(), rflat) < 5e-4
