@@ -2,7 +2,8 @@
 // as cc_backward.hip, for the shapes the headline configurations use: every hidden layer 48..62 wide (4 tiles of 16)
 // and at most 3 hidden->hidden layers.  One pass, persistent waves (one per SIMD, the whole register file), one tile
 // of 16 integrals per wave.  Per quadrature node:
-//   forward recompute  W_l fragments x split(a_l), THREE bf16 pieces / 6 cross terms: fp32-level accuracy.  This one
+//   forward recompute  W_l fragments x split(a_l), THREE bf16 pieces / 6 cross terms: fp32-level accuracy (the sign of
+//                      each activation is later read off its leading bf16 piece, which is kept for dW anyway).  This one
 //                      must be that accurate: the backward needs the SIGN of every pre-activation (LeakyReLU/ReLU
 //                      kink), and a recompute that is only 1e-5 accurate flips enough signs to move small-batch
 //                      gradients by 5e-4 relative to the reference (measured with a 3-term recompute).
@@ -88,8 +89,7 @@ __device__ __forceinline__ void split_regs(const f32x4 (&act)[BT], BFrag<NP>& bf
 // acc[t] = sum over K-steps and the cross terms (wa + ba < NP) of frag(t, s, wa) * bf[s][ba]
 template <int NP>
 __device__ __forceinline__ void gemm_frags(const unsigned short* img, const BFrag<NP>& bf, f32x4 (&acc)[BT]) {
-#pragma unroll
-    for (int t = 0; t < BT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};        // the first MFMA of every accumulator takes the literal 0 as C
 #pragma unroll
     for (int s = 0; s < BKS; ++s) {
         u32x4 wf[BT][NP];
@@ -103,19 +103,21 @@ __device__ __forceinline__ void gemm_frags(const unsigned short* img, const BFra
 #pragma unroll
             for (int ba = 0; ba < NP; ++ba) {
                 if (wa + ba >= NP) continue;
+                const bool first = s == 0 && wa == 0 && ba == 0;
 #pragma unroll
-                for (int t = 0; t < BT; ++t) acc[t] = mfma_bf16(wf[t][wa], bf.v[s][ba], acc[t]);
+                for (int t = 0; t < BT; ++t) acc[t] = mfma_bf16(wf[t][wa], bf.v[s][ba], first ? zero : acc[t]);
             }
     }
 }
 
-__device__ __forceinline__ unsigned sign_bits4(const f32x4 (&v)[BT]) {
-    unsigned bits = 0;
-#pragma unroll
-    for (int t = 0; t < BT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bits |= (v[t][r] > 0.f ? 1u : 0u) << (4 * t + r);
-    return bits;
+// d act / d pre-activation of the feature held in register (t, r), read off the SIGN of its leading bf16 piece
+// (a_l > 0  <=>  its round-to-nearest bf16 is > 0): 1 for a positive activation, `slope` otherwise -- the same
+// convention as torch's LeakyReLU / ReLU backward (x > 0 ? 1 : slope).
+template <int NP>
+__device__ __forceinline__ float act_grad(const BFrag<NP>& a, int t, int r, float slope) {
+    const unsigned u = a.v[t >> 1][0][(t & 1) * 2 + (r >> 1)];
+    const int hi16 = (r & 1) ? (int)(u & 0xffff0000u) : (int)(u << 16);
+    return hi16 > 0 ? 1.f : slope;
 }
 
 // Transposition on the matrix core.  `x` holds, as packed bf16 k-slots, the features of two tiles (2s, 2s+1) for the
@@ -136,9 +138,12 @@ __device__ __forceinline__ void transpose_pieces(const BFrag<NPB>& x, const u32x
             }
 }
 
-template <int NACC, bool EDGE, int NRL>
+// LH = number of hidden layers (compile-time: the layer loops are unrolled so that every register array is
+// statically indexed); NACC = LH - 1 hidden->hidden layers, all accumulated in this one pass (l_lo = 1).
+template <int LH, bool EDGE, int NRL>
 __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf16Args args) {
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
+    constexpr int NACC = LH - 1;
     constexpr int NA = NACC > 0 ? NACC : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const BwdArgs& a = args.b;
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, p = lane & 15;
-    const int L = m.n_linear - 1;
+    constexpr int L = LH;
     const int H1 = m.width[1], HL = m.width[L];
     const int E = a.E, d = a.d, n = a.n;
     const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
@@ -244,7 +249,6 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
             const float u = a.ccs[k] + 1.f;
             const float wk = a.ccw[k];
             const float tk = k == 0 ? xv : __fadd_rn(x0v, __fmul_rn(dxv, u) * 0.5f);
-            unsigned bits[UMNN_MAX_LINEAR];
             f32x4 act[BT];
             BFrag<NPB> asave[NA];            // packed (hi, next) pieces of a_l for the layers whose dW this pass owns
             // ---------------- forward recompute (6 cross terms) ----------------
@@ -253,25 +257,20 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     act[t][r] = 4 * t + r < NLIVE ? hidden_act_f(fmaf(w1x[t][r], tk, c[t][r]), slope) : 0.f;
-            bits[1] = sign_bits4(act);
+#pragma unroll
             for (int l = 1; l < L; ++l) {
                 BFrag<NPF> bf;
                 split_regs<NRL, NPF>(act, bf);
 #pragma unroll
-                for (int j = 0; j < NACC; ++j)
-                    if (l == a.l_lo + j) {
+                for (int s = 0; s < BKS; ++s)
 #pragma unroll
-                        for (int s = 0; s < BKS; ++s)
-#pragma unroll
-                            for (int k2 = 0; k2 < NPB; ++k2) asave[j].v[s][k2] = bf.v[s][k2];
-                    }
+                    for (int k2 = 0; k2 < NPB; ++k2) asave[l - 1].v[s][k2] = bf.v[s][k2];
                 f32x4 acc[BT];
                 gemm_frags<NPF>(frag_base + args.off_fwd[l], bf, acc);
 #pragma unroll
                 for (int t = 0; t < BT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) act[t][r] = 4 * t + r < NLIVE ? hidden_act_f(acc[t][r], slope) : 0.f;
-                bits[l + 1] = sign_bits4(act);
             }
             float sdot = 0.f;
 #pragma unroll
@@ -291,7 +290,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
 #pragma unroll
                 for (int t = 0; t < BT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ta[t][r] = w1x[t][r] * ((bits[1] >> (4 * t + r)) & 1u ? 1.f : slope);
+                    for (int r = 0; r < 4; ++r) ta[t][r] = 4 * t + r < NLIVE ? w1x[t][r] * act_grad(asave[0], t, r, slope) : 0.f;
+#pragma unroll
                 for (int l = 1; l < L; ++l) {
                     BFrag<NPF> bf;
                     split_regs<NRL, NPF>(ta, bf);
@@ -300,8 +300,12 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
 #pragma unroll
                     for (int t = 0; t < BT; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            ta[t][r] = tz[t][r] * ((bits[l + 1] >> (4 * t + r)) & 1u ? 1.f : slope);
+                        for (int r = 0; r < 4; ++r) {
+                            // layer l+1: its activation is a saved fragment, except the last layer whose act is still live
+                            const float fac = l + 1 < L ? act_grad(asave[l + 1 < L ? l : 0], t, r, slope)
+                                                        : (act[t][r] > 0.f ? 1.f : slope);
+                            ta[t][r] = 4 * t + r < NLIVE ? tz[t][r] * fac : 0.f;
+                        }
                 }
                 float ds = 0.f;
 #pragma unroll
@@ -320,36 +324,35 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (EDGE) dwo[t][r] = fmaf(dout, act[t][r], dwo[t][r]);
-                    delta[t][r] = dout * wout[t][r] * ((bits[L] >> (4 * t + r)) & 1u ? 1.f : slope);
+                    delta[t][r] = dout * wout[t][r] * (act[t][r] > 0.f ? 1.f : slope);
                 }
+#pragma unroll
             for (int l = L - 1; l >= 1; --l) {
                 BFrag<NPB> bd;
                 split_regs<NRL, NPB>(delta, bd);
+                {
+                    u32x4 dT[BT][NPB], aT[BT][NPB];
+                    transpose_pieces(bd, sel, dT);
+                    transpose_pieces(asave[l - 1], sel, aT);
 #pragma unroll
-                for (int j = 0; j < NACC; ++j)
-                    if (l == a.l_lo + j) {
-                        u32x4 dT[BT][NPB], aT[BT][NPB];
-                        transpose_pieces(bd, sel, dT);
-                        transpose_pieces(asave[j], sel, aT);
+                    for (int wa = 0; wa < NPB; ++wa)
 #pragma unroll
-                        for (int wa = 0; wa < NPB; ++wa)
+                        for (int ba = 0; ba < NPB; ++ba) {
+                            if (wa + ba >= NPB) continue;
 #pragma unroll
-                            for (int ba = 0; ba < NPB; ++ba) {
-                                if (wa + ba >= NPB) continue;
+                            for (int to = 0; to < BT; ++to)
 #pragma unroll
-                                for (int to = 0; to < BT; ++to)
-#pragma unroll
-                                    for (int ti = 0; ti < BT; ++ti)
-                                        dW[j][to][ti] = mfma_bf16(dT[to][wa], aT[ti][ba], dW[j][to][ti]);
-                            }
-                    }
+                                for (int ti = 0; ti < BT; ++ti)
+                                    dW[l - 1][to][ti] = mfma_bf16(dT[to][wa], aT[ti][ba], dW[l - 1][to][ti]);
+                        }
+                }
                 f32x4 nd[BT];
                 gemm_frags<NPB>(frag_base + args.off_tr[l], bd, nd);
 #pragma unroll
                 for (int t = 0; t < BT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        delta[t][r] = nd[t][r] * ((bits[l] >> (4 * t + r)) & 1u ? 1.f : slope);
+                        delta[t][r] = 4 * t + r < NLIVE ? nd[t][r] * act_grad(asave[l - 1], t, r, slope) : 0.f;
             }
             if (EDGE) {
 #pragma unroll
@@ -383,8 +386,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
     float* part = a.partials + (size_t)wave_global * a.n_params;
 #pragma unroll
     for (int j = 0; j < NACC; ++j) {
-        const int l = a.l_lo + j;
-        if (l < L) {
+        const int l = 1 + j;
+        {
             const int Hin = m.width[l], Hout = m.width[l + 1];
 #pragma unroll
             for (int to = 0; to < BT; ++to)
@@ -420,10 +423,13 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
 
 // ------------------------------------------------------------------------------------------
 typedef void (*bwd_bf16_kernel_t)(const BwdBf16Args);
-struct BwdBf16Variant { int nacc, edge, nrl; bwd_bf16_kernel_t fn; const char* name; };
-#define BWD_BF16_VARIANT(N, E, NR) { N, E, NR, cc_bwd_bf16_kernel<N, (E) != 0, NR>, "cc_bwd_bf16<NACC=" #N ",EDGE=" #E ",LIVE=" #NR ">" }
+struct BwdBf16Variant { int lh, edge, nrl; bwd_bf16_kernel_t fn; const char* name; };
+#define BWD_BF16_VARIANT(LHH, E, NR) { LHH, E, NR, cc_bwd_bf16_kernel<LHH, (E) != 0, NR>, "cc_bwd_bf16<L=" #LHH ",EDGE=" #E ",LIVE=" #NR ">" }
+// Only the 13-live-register shape (hidden widths 48..51) is instantiated: the general 16-register variant needs
+// more than the 512-entry register file once MFMA results stay in VGPRs (and hipcc 7.2 crashes on it with
+// -amdgpu-mfma-vgpr-form); widths 52..62 use the fp32 kernels.
 static const BwdBf16Variant kBwdBf16Variants[] = {
-    BWD_BF16_VARIANT(3, 1, 13), BWD_BF16_VARIANT(3, 1, 0),
+    BWD_BF16_VARIANT(4, 1, 13), BWD_BF16_VARIANT(3, 1, 13), BWD_BF16_VARIANT(2, 1, 13),
 };
 
 // Plans and launches the main backward pass with the bf16 kernels.  Returns UMNN_EUNSUPPORTED when the shape is
@@ -440,7 +446,7 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
         if (a.m.t_out[l] != BT) return UMNN_EUNSUPPORTED;
         if (a.m.ks_in[l] != nrl) nrl = 0;
     }
-    if (nrl != 13) nrl = 0;
+    if (nrl != 13) return UMNN_EUNSUPPORTED;
     int off16 = 0;
     for (int l = 1; l < L; ++l) { args.off_fwd[l] = off16; off16 += BT * BKS * NPF * FRAG; }
     for (int l = 1; l < L; ++l) { args.off_tr[l] = off16; off16 += BT * BKS * NPB * FRAG; }
@@ -454,7 +460,7 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
     *nwaves_out = nblocks * UMNN_WAVES_PER_BLOCK;
     const BwdBf16Variant* v = nullptr;
     for (const BwdBf16Variant& c : kBwdBf16Variants)
-        if (c.nrl == nrl) { v = &c; break; }
+        if (c.nrl == nrl && c.lh == L) { v = &c; break; }
     if (!v) return UMNN_EUNSUPPORTED;
     a.l_lo = 1;
     if (int rc = umnn_allow_lds((const void*)v->fn, lds_bytes)) return rc;
