@@ -47,7 +47,7 @@ def test_reference_toy_experiment_runs_and_checkpoint_loads_into_the_reference(t
                CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
     try:
         subprocess.run([sys.executable, os.path.join(REF, "ToyExperiments.py"), "-dataset", "moons"], cwd=str(tmp_path),
-                       env=env, capture_output=True, text=True, timeout=25)
+                       env=env, capture_output=True, text=True, timeout=75)
     except subprocess.TimeoutExpired:
         pass
     out = tmp_path / "moons"
