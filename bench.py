@@ -148,6 +148,28 @@ def main():
     lib.umnn_profile_read(ctypes.byref(k_ms), ctypes.byref(k_n), ctypes.byref(k_fl))
     lib.umnn_profile_enable(0)
     assert torch.isfinite(ll).all()
+
+    # for the record: the same workload with the exact-fp32 MFMA kernels (N=1 eval only; a few untimed-by-the-driver steps)
+    exact = None
+    if world == 1 and args.mode == "eval" and precision != "fp32":
+        _lib.set_forward_precision("fp32")
+        for _ in range(2):
+            step()
+        lib.umnn_profile_enable(1)
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        te = time.perf_counter() - te
+        e_ms, e_n, e_fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+        lib.umnn_profile_read(ctypes.byref(e_ms), ctypes.byref(e_n), ctypes.byref(e_fl))
+        lib.umnn_profile_enable(0)
+        tf = e_fl.value / max(e_ms.value, 1e-9) / 1e9
+        exact = {"value": cfg["rows"] * 3 / te, "ms_per_step": 1e3 * te / 3, "kernel": lib.umnn_last_kernel_name().decode(),
+                 "avg_launch_ms": e_ms.value / max(1, e_n.value), "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
+                 "frac": tf / PEAK_FP32_MFMA_TFLOPS}
+        _lib.set_forward_precision(precision)
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -193,6 +215,8 @@ def main():
                          "peak_dtype": "bf16 dense MFMA" if on_bf16 else "fp32 MFMA",
                          "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS},
         }
+        if exact is not None:
+            out["exact_fp32"] = exact
         if args.mode == "train":
             out["config"]["mode"] = "train: fwd + HIP bwd + flattened gradient all-reduce (RCCL) + Adam"
             out["roofline"] = None      # the per-launch timing above mixes forward and backward launches

@@ -335,3 +335,28 @@ def test_random_mlp_shapes_forward_and_backward(seed, dev):
     # ReLU nets at random init have kinks exactly where fp32 summation order decides the sign: allow a few 1e-4
     assert U.scaled_err(dh.cpu().numpy(), rdh) < 5e-4
     assert U.scaled_err(dth.cpu().numpy(), rflat) < 5e-4
+
+
+def test_half_precision_callers(dev):
+    """bf16 / fp16 tensors (autocast, the bf16 VAE-prior configuration): converted at the boundary, fp32 inside, the
+    caller's dtype outside; gradients flow.  Tolerance = the I/O dtype's own resolution."""
+    import umnn_amd
+    from umnn_amd import integral as I
+    from umnn_amd.nets import mlp_spec
+    G = U.load("g2_vae_d64")
+    net = build_integrand(G, dev)
+    spec = mlp_spec(net)
+    n = int(G["n"])
+    for dt, tol in ((torch.bfloat16, 2e-2), (torch.float16, 3e-3)):
+        x = t(G["x"], dev).to(dt)
+        h = t(G["h"], dev).to(dt)
+        F, fx, fx0 = I.hip_forward(spec, None, x, h, n)
+        assert F.dtype == dt and umnn_amd.path_taken() == "hip"
+        ref = O.integrate_parallel(U.net_from_g2(G), np.zeros_like(G["x"]), x.float().cpu().numpy(), h.float().cpu().numpy(), n)
+        assert U.rel_err(F.float().cpu().numpy(), ref) < tol
+        xr = x.clone().requires_grad_()
+        hr = h.clone().requires_grad_()
+        flat = torch.cat([p.contiguous().view(-1) for p in net.parameters()])
+        out = umnn_amd.ParallelNeuralIntegral.apply(torch.zeros_like(xr), xr, net, flat, hr, n)
+        out.float().sum().backward()
+        assert xr.grad.dtype == dt and hr.grad.dtype == dt and bool(torch.isfinite(hr.grad.float()).all())

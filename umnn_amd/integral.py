@@ -93,7 +93,7 @@ def _use_hip(spec, x):
                           "(the HIP kernels need GPU tensors; move the model and data to 'cuda').")
             _warned_host = True
         return False
-    if x.dtype != torch.float32:
+    if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         return False
     if spec.linears[0].weight.device != x.device:
         raise RuntimeError("umnn_amd: integrand weights and inputs are on different devices")
@@ -119,6 +119,7 @@ def hip_forward(spec, x0, x, h, nb_steps, inv_f=False):
     """-> (F, f_x, f_x0), each [B,d].  x0 may be None (zeros)."""
     lib = _lib.lib()
     B, d, E = _shape(spec, x, h)
+    out_dtype = x.dtype
     x, h = _f32c(x), _f32c(h)
     x0 = _f32c(x0) if x0 is not None else None
     w, s = device_tables(nb_steps, x.device)
@@ -130,6 +131,8 @@ def hip_forward(spec, x0, x, h, nb_steps, inv_f=False):
                                  B, d, E, int(bool(inv_f)), _ptr(F), _ptr(fx), _ptr(fx0), stream)
     _lib.check(rc, "umnn_cc_forward")
     _state.path = "hip"
+    if out_dtype != torch.float32:        # half-precision callers (autocast / bf16 VAE prior): fp32 inside, their dtype outside
+        F, fx, fx0 = F.to(out_dtype), fx.to(out_dtype), fx0.to(out_dtype)
     return F, fx, fx0
 
 
@@ -137,6 +140,7 @@ def hip_flow_block(spec, x, h, scaling, nb_steps):
     """Fused block epilogue -> (z, log_jac, f_x, f_x0)."""
     lib = _lib.lib()
     B, d, E = _shape(spec, x, h)
+    out_dtype = x.dtype
     x, h, scaling = _f32c(x), _f32c(h), _f32c(scaling)
     w, s = device_tables(nb_steps, x.device)
     z, lj, fx, fx0 = (torch.empty_like(x) for _ in range(4))
@@ -147,6 +151,8 @@ def hip_flow_block(spec, x, h, scaling, nb_steps):
                                          int(nb_steps), B, d, E, _ptr(z), _ptr(lj), _ptr(fx), _ptr(fx0), stream)
     _lib.check(rc, "umnn_flow_block_forward")
     _state.path = "hip"
+    if out_dtype != torch.float32:
+        z, lj, fx, fx0 = z.to(out_dtype), lj.to(out_dtype), fx.to(out_dtype), fx0.to(out_dtype)
     return z, lj, fx, fx0
 
 
@@ -154,6 +160,7 @@ def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True
     """-> (dx0, dx, dh, dtheta_flat); entries are None where need[...] is False."""
     lib = _lib.lib()
     B, d, E = _shape(spec, x, h)
+    x_dtype, h_dtype = x.dtype, h.dtype
     x, h, g = _f32c(x), _f32c(h), _f32c(g)
     x0 = _f32c(x0) if x0 is not None else None
     g_fx = _f32c(g_fx) if g_fx is not None else None
@@ -173,6 +180,11 @@ def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True
                                   _ptr(dx0), _ptr(dx), _ptr(dh), _ptr(dtheta), _ptr(ws), int(nbytes), stream)
     _lib.check(rc, "umnn_cc_backward")
     _state.path = "hip"
+    if x_dtype != torch.float32:
+        dx0 = dx0.to(x_dtype) if dx0 is not None else None
+        dx = dx.to(x_dtype) if dx is not None else None
+    if h_dtype != torch.float32 and dh is not None:
+        dh = dh.to(h_dtype)
     return dx0, dx, dh, dtheta
 
 
