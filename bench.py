@@ -148,6 +148,7 @@ def main():
     lib.umnn_profile_read(ctypes.byref(k_ms), ctypes.byref(k_n), ctypes.byref(k_fl))
     lib.umnn_profile_enable(0)
     assert torch.isfinite(ll).all()
+    kernel_name = lib.umnn_last_kernel_name().decode()
 
     # for the record: the same workload with the exact-fp32 MFMA kernels (N=1 eval only; a few untimed-by-the-driver steps)
     exact = None
@@ -187,7 +188,6 @@ def main():
                 traffic = json.load(open(tf)).get(args.workload, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        kernel_name = lib.umnn_last_kernel_name().decode()
         on_bf16 = "bf16" in kernel_name
         peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
         dtype = {"fp32": "f32", "bf16x3": "f32 via bf16x3-split MFMA (fp32 accumulate)",
