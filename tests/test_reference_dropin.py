@@ -72,3 +72,61 @@ def test_reference_toy_experiment_runs_and_checkpoint_loads_into_the_reference(t
     r = subprocess.run([sys.executable, "-W", "ignore", "-c", check], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
     assert r.returncode == 0 and "checkpoint ok" in r.stdout, r.stderr[-2000:]
+
+
+_VAE_SNIPPET = r"""
+import sys, argparse, torch
+torch.manual_seed(0)
+from models.vae_lib.models import VAE
+import models
+args = argparse.Namespace(z_size=8, input_size=[1, 28, 28], input_type='binary', cuda=False, made_h_size=16, num_flows=2,
+                          gpu_num=0, steps=20, solver=%(solver)r, hidden_embedding=[32, 32],
+                          hidden_derivative=[50, 50, 50, 50], embedding_size=6)
+vae = VAE.MMAVAE(args)
+path = %(path)r
+if %(load)r:
+    vae.load_state_dict(torch.load(path + '/vae.pt'))
+else:
+    torch.save(vae.state_dict(), path + '/vae.pt')
+torch.manual_seed(1)
+x = torch.rand(5, 1, 28, 28).bernoulli()
+x_mean, z_mu, z_var, ldj, z0, zk = vae(x)
+loss = (x_mean - x).pow(2).sum() - ldj.sum() + zk.pow(2).sum()
+loss.backward()
+if %(load)r:
+    vae.flow.model.force_lipschitz(1.5)      # the reference never defined the name its VAE wrapper calls (flows.py:327)
+else:
+    vae.forceLipshitz(1.5)                   # the shim provides it
+out = dict(module=models.UMNNMAFFlow.__module__, x_mean=x_mean.detach(), ldj=ldj.detach(), zk=zk.detach(),
+           grads={n: p.grad.clone() for n, p in vae.named_parameters() if p.grad is not None},
+           after={n: p.detach().clone() for n, p in vae.flow.named_parameters()})
+torch.save(out, path + '/%(tag)s.pt')
+print('vae ok')
+"""
+
+
+@pytest.mark.parametrize("solver", ["CC", "CCParallel"])
+def test_reference_vae_flow_prior_uses_this_package_and_matches_the_reference(tmp_path, solver):
+    """BASELINE config C4's caller: the reference's MMAVAE (models/vae_lib, TrainVaeFlow.py) builds its conditional
+    UMNNMAFFlow through `from models import UMNNMAFFlow` (flows.py:16,309) and calls compute_log_jac_bis, forceLipshitz
+    (flows.py:318-330).  Through the shim it must construct, train one step and match the pure reference run on the
+    same weights and noise (outputs and every parameter gradient)."""
+    import torch
+    def run(tag, pythonpath, load):
+        code = _VAE_SNIPPET % dict(solver=solver, path=str(tmp_path), load=load, tag=tag)
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join(pythonpath), CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+        r = subprocess.run([sys.executable, "-W", "ignore", "-c", code], cwd=str(tmp_path), env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "vae ok" in r.stdout, r.stderr[-3000:]
+        return torch.load(str(tmp_path / (tag + ".pt")))
+    mine = run("mine", [os.path.join(ROOT, "compat"), ROOT, REF], False)
+    ref = run("ref", [REF], True)
+    assert mine["module"].startswith("umnn_amd") and not ref["module"].startswith("umnn_amd")
+    for k in ("x_mean", "ldj", "zk"):
+        assert torch.allclose(mine[k], ref[k], rtol=1e-4, atol=1e-5), (k, (mine[k] - ref[k]).abs().max())
+    assert set(mine["grads"]) == set(ref["grads"])
+    for n, g in ref["grads"].items():
+        scale = g.abs().max().clamp_min(1e-6)
+        assert (mine["grads"][n] - g).abs().max() <= 2e-4 * scale, n
+    for n, p in ref["after"].items():
+        assert torch.allclose(mine["after"][n], p, rtol=1e-5, atol=1e-6), n
