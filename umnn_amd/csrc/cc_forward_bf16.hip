@@ -19,6 +19,7 @@
 // 2s+1 -- again the accumulators of one layer ARE (after activation, splitting and packing) the B operands of the
 // next, with no cross-lane movement.  Weight fragments are pre-split and pre-permuted into LDS: fragment (tile t', K-step s, part)
 // is 64 lanes x 8 bf16 = 1 KiB, read with one ds_read_b128 per lane.
+#include <utility>
 #include "cc_bf16.h"
 #include "cc_fwd_shared.h"
 #include "cc_host.h"
@@ -68,10 +69,43 @@ struct FwdBf16Args {
     Bf16Plan pl;
 };
 
+// ---- software-pipelined node loop (PIPE variants: four tiles, two bf16 pieces, two point tiles per wave) -----------
+// tools/ubench/fill.hip: a wave may issue about two independent VALU instructions in the shadow of each
+// v_mfma_f32_16x16x32_bf16 for free, while VALU work issued between the matrix phases costs full price -- and the
+// activation / split work of a layer is ~130 VALU instructions against 48 MFMAs.  So the two point tiles of a wave run
+// half a layer out of phase: while the matrix pipe multiplies tile A by layer l, the VALU activates, splits and packs
+// tile B's layer l-1 output, and vice versa.  Every MFMA is followed by its slice of that work and a scheduling fence.
+// The weight fragments of a layer stay in registers for both tiles (LDS is read once per layer, during the second
+// tile's section, into registers whose last use has passed).
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// sub-step SUB (0: activation, 1: leading bf16 piece + remainder, 2: second piece) of register pair J of a point
+// tile: z0, z1 are the raw pre-activations of registers 2J, 2J+1 (HAS1: the second one is live); a0, a1 carry the
+// pair between sub-steps; the packed pieces land in dword J%4 of bf[J/4][piece].
+template <int J, int SUB, bool HAS1>
+__device__ __forceinline__ void pack_step(float z0, float z1, float slope, float& a0, float& a1, u32x4 (&bf)[2][2]) {
+    if constexpr (SUB == 0) {
+        a0 = hidden_act_f(z0, slope);
+        a1 = HAS1 ? hidden_act_f(z1, slope) : 0.f;
+    } else if constexpr (SUB == 1) {
+        const bf16x2 h = __builtin_convertvector(f32x2{a0, a1}, bf16x2);
+        const unsigned bits = __builtin_bit_cast(unsigned, h);
+        bf[J / 4][0][J % 4] = bits;
+        a0 -= __uint_as_float(bits << 16);
+        a1 -= __uint_as_float(bits & 0xffff0000u);
+    } else {
+        const bf16x2 h = __builtin_convertvector(f32x2{a0, a1}, bf16x2);
+        bf[J / 4][1][J % 4] = __builtin_bit_cast(unsigned, h);
+    }
+}
+
 // EXACT: every hidden layer fills exactly TMAX tiles, so tile / K-step counts are compile-time constants and the
 // wave-uniform guards (and the accumulator copies they force at every basic-block boundary) disappear.
 // NRL (EXACT only): live registers per lane = ceil((H+1)/4) for the common hidden width H; 0 = all 4*TMAX.
-template <int TMAX, int NPARTS, int P, bool EXACT, int NRL>
+// PIPE (EXACT, TMAX = 4, at least two hidden layers): the node loop is software-pipelined, see pipe_layer.
+template <int TMAX, int NPARTS, int P, bool EXACT, int NRL, bool PIPE = false>
 __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Args args) {
     constexpr int KSM = TMAX / 2;
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * TMAX;
@@ -158,6 +192,119 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
             }
         }
 
+        if constexpr (PIPE) {
+            static_assert(TMAX == 4 && EXACT && NPARTS == 2 && P == 2, "pipelined loop: 4 tiles, 2 pieces, 2 point tiles");
+            constexpr int NPAIR = (NLIVE + 1) / 2;
+            constexpr int NSLOT = 24;                               // MFMAs of one point tile in one layer
+            static_assert(3 * NPAIR <= NSLOT, "one sub-step per MFMA slot");
+            using Slots = std::make_integer_sequence<int, NSLOT>;
+            float pa0[NPAIR], pa1[NPAIR];                           // a register pair between its packing sub-steps
+            u32x4 wf[4][2][2];                                      // [tile][K-step][piece] of the layer in flight
+            u32x4 bf[2][2][2];                                      // [point tile][K-step][piece]
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) bf[pt][ks][k2] = u32x4{0u, 0u, 0u, 0u};
+            auto frag = [&](int l, int t, int ks, int k2) {
+                return *reinterpret_cast<const u32x4*>(lds16 + args.pl.off16[l] + lane * 8 + ((t * 2 + ks) * 2 + k2) * 512);
+            };
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) wf[t][ks][k2] = frag(1, t, ks, k2);
+            // slot i of a section: K-step i/12, cross term (i/4)%3 = (W piece, activation piece) (0,0),(0,1),(1,0), tile i%4
+            auto mfma_slot = [&](auto ic, const u32x4 (&bfin)[2][2], f32x4 (&acc)[4]) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / 12, term = (i / 4) % 3, t = i % 4;
+                constexpr int wa = term == 2 ? 1 : 0, ba = term == 1 ? 1 : 0;
+                if constexpr (i < 4) acc[t] = mfma_bf16(wf[t][ks][wa], bfin[ks][ba], f32x4{0.f, 0.f, 0.f, 0.f});
+                else acc[t] = mfma_bf16(wf[t][ks][wa], bfin[ks][ba], acc[t]);
+            };
+            // in the second tile's section: once a fragment has been used for the last time, fetch the same
+            // fragment of the layer that runs next into its registers
+            auto reload_slot = [&](auto ic, int lnext) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / 12, term = (i / 4) % 3, t = i % 4;
+                if constexpr (term == 1) wf[t][ks][0] = frag(lnext, t, ks, 0);
+                if constexpr (term == 2) wf[t][ks][1] = frag(lnext, t, ks, 1);
+            };
+            auto pack_slot = [&](auto ic, const f32x4 (&z)[4], u32x4 (&bfout)[2][2]) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < 3 * NPAIR) {
+                    constexpr int j = i / 3, sub = i % 3;
+                    pack_step<j, sub, (2 * j + 1 < NLIVE)>(z[j / 2][2 * (j % 2)], z[j / 2][2 * (j % 2) + 1], slope, pa0[j], pa1[j], bfout);
+                }
+            };
+
+            for (int k = k_lo; k < k_hi; ++k) {
+                const float u = a.ccs[k] + 1.f;
+                const float wk = a.ccw[k];
+                float tk[2];
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) tk[pt] = k == 0 ? xv[pt] : __fadd_rn(x0v[pt], __fmul_rn(dxv[pt], u) * 0.5f);
+                f32x4 acc0[4], acc1[4];
+                // first tile: layer 1 on the VALU, nothing to hide behind yet
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc0[t][r] = 4 * t + r < NLIVE ? fmaf(w1x[t][r], tk[0], c[0][t][r]) : 0.f;
+                static_for(Slots{}, [&](auto ic) { pack_slot(ic, acc0, bf[0]); });
+                __builtin_amdgcn_sched_barrier(0);
+                // section A of layer 1: first tile on the matrix pipe, second tile's layer 1 + packing on the VALU
+                static_for(Slots{}, [&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    mfma_slot(ic, bf[0], acc0);
+                    if constexpr (i < 3 * NPAIR && i % 3 == 0) {
+                        constexpr int j = i / 3, t = j / 2, r = 2 * (j % 2);
+                        acc1[t][r] = fmaf(w1x[t][r], tk[1], c[1][t][r]);
+                        acc1[t][r + 1] = 4 * t + r + 1 < NLIVE ? fmaf(w1x[t][r + 1], tk[1], c[1][t][r + 1]) : 0.f;
+                    }
+                    pack_slot(ic, acc1, bf[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                for (int l = 1; l + 1 < L; ++l) {
+                    // section B of layer l: second tile on the matrix pipe, first tile's output packed for layer l+1
+                    static_for(Slots{}, [&](auto ic) {
+                        mfma_slot(ic, bf[1], acc1);
+                        pack_slot(ic, acc0, bf[0]);
+                        reload_slot(ic, l + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    // section A of layer l+1
+                    static_for(Slots{}, [&](auto ic) {
+                        mfma_slot(ic, bf[0], acc0);
+                        pack_slot(ic, acc1, bf[1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                }
+                // section B of the last hidden layer: the first tile's output goes into the output dot product
+                float sd0 = 0.f, sd1 = 0.f;
+                static_for(Slots{}, [&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    mfma_slot(ic, bf[1], acc1);
+                    if constexpr (i < NLIVE) sd0 = fmaf(wout[i / 4][i % 4], hidden_act_f(acc0[i / 4][i % 4], slope), sd0);
+                    reload_slot(ic, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * t + r < NLIVE) sd1 = fmaf(wout[t][r], hidden_act_f(acc1[t][r], slope), sd1);
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const float sr = group_allreduce(pt == 0 ? sd0 : sd1);
+                    const float f = out_act_f(sr, m.out_act);
+                    Facc[pt] = fmaf(wk, a.inv_f ? 1.f / f : f, Facc[pt]);
+                    if (k == 0) fxv[pt] = f;
+                    if (k == n) fx0v[pt] = f;
+                }
+            }
+        } else
         for (int k = k_lo; k < k_hi; ++k) {
             const float u = a.ccs[k] + 1.f;
             const float wk = a.ccw[k];
@@ -253,9 +400,11 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
 
 // ------------------------------------------------------------------------------------------
 typedef void (*fwd_bf16_kernel_t)(const FwdBf16Args);
-struct Bf16Variant { int tmax, nparts, p, exact, nrl; fwd_bf16_kernel_t fn; const char* name; };
-#define BF16_VARIANT(T, NP, PP, EX, NR) { T, NP, PP, EX, NR, cc_fwd_bf16_kernel<T, NP, PP, (EX) != 0, NR>, "cc_fwd_bf16<T=" #T ",PARTS=" #NP ",P=" #PP ",EXACT=" #EX ",LIVE=" #NR ">" }
+struct Bf16Variant { int tmax, nparts, p, exact, nrl, pipe; fwd_bf16_kernel_t fn; const char* name; };
+#define BF16_VARIANT(T, NP, PP, EX, NR) { T, NP, PP, EX, NR, 0, cc_fwd_bf16_kernel<T, NP, PP, (EX) != 0, NR>, "cc_fwd_bf16<T=" #T ",PARTS=" #NP ",P=" #PP ",EXACT=" #EX ",LIVE=" #NR ">" }
+#define BF16_PIPE_VARIANT(NP, PP, NR) { 4, NP, PP, 1, NR, 1, cc_fwd_bf16_kernel<4, NP, PP, true, NR, true>, "cc_fwd_bf16<T=4,PARTS=" #NP ",P=" #PP ",EXACT=1,LIVE=" #NR ",PIPE>" }
 static const Bf16Variant kBf16Variants[] = {
+    BF16_PIPE_VARIANT(2, 2, 13), BF16_PIPE_VARIANT(2, 2, 0),   // software-pipelined node loop (>= 2 hidden layers, bf16x3)
     BF16_VARIANT(4, 2, 1, 1, 13), BF16_VARIANT(4, 2, 2, 1, 13), BF16_VARIANT(4, 3, 1, 1, 13), BF16_VARIANT(4, 3, 2, 1, 13),   // widths 48..51
     BF16_VARIANT(4, 2, 1, 1, 0), BF16_VARIANT(4, 2, 2, 1, 0), BF16_VARIANT(4, 3, 1, 1, 0), BF16_VARIANT(4, 3, 2, 1, 0),       // widths 52..62
     BF16_VARIANT(2, 2, 1, 0, 0), BF16_VARIANT(2, 2, 2, 0, 0), BF16_VARIANT(2, 3, 1, 0, 0), BF16_VARIANT(2, 3, 2, 0, 0),
@@ -288,11 +437,13 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
         exact = exact && a.m.t_out[l] == T;
         if (a.m.ks_in[l] != nrl) nrl = 0;
     }
+    static const int pipe_env = [] { const char* e = getenv("UMNN_FWD_PIPE"); return e ? atoi(e) : 1; }();
+    const bool want_pipe = pipe_env != 0 && L >= 2;
     const Bf16Variant* pick = nullptr;
     for (int ex = exact; ex >= 0 && !pick; --ex)
         for (int pass = 0; pass < 2 && !pick; ++pass)      // pass 0: a variant with exactly this live-register count
             for (const Bf16Variant& v : kBf16Variants)
-                if (v.tmax == T && v.nparts == nparts && v.p == P && v.exact == ex &&
+                if (v.tmax == T && v.nparts == nparts && v.p == P && v.exact == ex && (!v.pipe || want_pipe) &&
                     (pass == 0 ? (ex && nrl && v.nrl == nrl) : v.nrl == 0)) { pick = &v; break; }
     if (!pick) return UMNN_EUNSUPPORTED;
     fwd_bf16_kernel_t kfn = pick->fn;
