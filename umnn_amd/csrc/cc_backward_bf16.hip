@@ -13,7 +13,7 @@
 //                      B operands) are reused as A operands against a 0/1 selection fragment, which returns
 //                      "feature on lane&15, points on (lane>>4, r)" -- exact, since it multiplies by one.  No LDS round
 //                      trip (the fp32 kernel's transposes cost ~770 LDS cycles per layer and tile, CU-wide).
-//                      The product then runs as 16 output tiles x 3 terms with half of K = 32 zero-padded.
+//                      The product then runs as 16 output tiles x 3 terms on the K = 16 instruction (16x16x16).
 // What depends on an integral only once leaves as dc = sum_k delta_1 (finishing kernels of cc_backward.hip);
 // every wave writes its partial d_theta slice (deterministic reduction, no atomics).
 #include "cc_bf16.h"
@@ -123,8 +123,8 @@ __device__ __forceinline__ float act_grad(const BFrag<NP>& a, int t, int r, floa
 // Transposition on the matrix core.  `x` holds, as packed bf16 k-slots, the features of two tiles (2s, 2s+1) for the
 // point lane&15 -- i.e. it is a valid A operand with rows = points.  Multiplying by the 0/1 fragment sel[h] (k-slot of
 // feature 16(2s+h)+n  ->  column n) returns D[point][n]: lane (g, n) gets feature 16(2s+h)+n at points 4g..4g+3.
-// Both pieces are transposed and re-packed into the k-slots 0..3 of an operand whose k-slots 4..7 stay zero.
-__device__ __forceinline__ void transpose_pieces(const BFrag<NPB>& x, const u32x4 (&sel)[2], u32x4 (&out)[BT][NPB]) {
+// Both pieces are transposed and re-packed as the 4 k-slots of a 16x16x16 operand (K = the 16 points of the tile).
+__device__ __forceinline__ void transpose_pieces(const BFrag<NPB>& x, const u32x4 (&sel)[2], u32x2 (&out)[BT][NPB]) {
 #pragma unroll
     for (int s = 0; s < BKS; ++s)
 #pragma unroll
@@ -134,7 +134,7 @@ __device__ __forceinline__ void transpose_pieces(const BFrag<NPB>& x, const u32x
                 const f32x4 tr = mfma_bf16(x.v[s][part], sel[h], f32x4{0.f, 0.f, 0.f, 0.f});
                 const bf16x2 lo = __builtin_convertvector(f32x2{tr[0], tr[1]}, bf16x2);     // exact: values are bf16 already
                 const bf16x2 hi = __builtin_convertvector(f32x2{tr[2], tr[3]}, bf16x2);
-                out[2 * s + h][part] = u32x4{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi), 0u, 0u};
+                out[2 * s + h][part] = u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
             }
 }
 
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
                 BFrag<NPB> bd;
                 split_regs<NRL, NPB>(delta, bd);
                 {
-                    u32x4 dT[BT][NPB], aT[BT][NPB];
+                    u32x2 dT[BT][NPB], aT[BT][NPB];
                     transpose_pieces(bd, sel, dT);
                     transpose_pieces(asave[l - 1], sel, aT);
 #pragma unroll
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
                             for (int to = 0; to < BT; ++to)
 #pragma unroll
                                 for (int ti = 0; ti < BT; ++ti)
-                                    dW[l - 1][to][ti] = mfma_bf16(dT[to][wa], aT[ti][ba], dW[l - 1][to][ti]);
+                                    dW[l - 1][to][ti] = mfma_bf16_k16(dT[to][wa], aT[ti][ba], dW[l - 1][to][ti]);
                         }
                 }
                 f32x4 nd[BT];

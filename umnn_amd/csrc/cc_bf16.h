@@ -7,6 +7,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned short bf16_rn_bits(float x) {
     const unsigned u = __float_as_uint(x);
@@ -16,6 +18,12 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __u
 
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// K = 16 variant (4 bf16 per lane): same 16 cycles as the K = 32 instruction, for products whose contraction is only
+// 16 long (the backward's dW = delta x a over the 16 points of a tile) -- no zero-padded operand halves to build.
+__device__ __forceinline__ f32x4 mfma_bf16_k16(u32x2 a, u32x2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
 }
 
 // (x0,x1) -> packed bf16 pairs of the NPARTS pieces (piece k of x0 in the low half of out[k], of x1 in the high half)
