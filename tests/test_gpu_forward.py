@@ -360,3 +360,37 @@ def test_half_precision_callers(dev):
         out = umnn_amd.ParallelNeuralIntegral.apply(torch.zeros_like(xr), xr, net, flat, hr, n)
         out.float().sum().backward()
         assert xr.grad.dtype == dt and hr.grad.dtype == dt and bool(torch.isfinite(hr.grad.float()).all())
+
+
+def test_pipelined_and_plain_bf16x3_kernels_agree_bit_for_bit(dev):
+    """The software-pipelined node loop (default for bf16x3, two point tiles per wave) issues the same MFMAs per
+    accumulator in the same order as the plain loop it replaces (still reachable with UMNN_FWD_PIPE=0, read once per
+    process): the two must return identical bits, and the plain one must still pass the oracle tolerance."""
+    import subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import umnn_amd\n"
+        "from umnn_amd import integral as I, _lib, IntegrandNetwork\n"
+        "from umnn_amd.nets import mlp_spec\n"
+        "umnn_amd.set_forward_precision('bf16x3')\n"
+        "torch.manual_seed(5); dev = torch.device('cuda:0')\n"
+        "net = IntegrandNetwork(7, 31, [50, 50, 50, 50], 1).to(dev)\n"
+        "x = torch.randn(300, 7, device=dev) * 2; h = torch.randn(300, 30 * 7, device=dev)\n"
+        "F, fx, fx0 = I.hip_forward(mlp_spec(net), None, x, h, 100)\n"
+        "torch.cuda.synchronize()\n"
+        "np.savez(sys.argv[1], F=F.cpu().numpy(), fx=fx.cpu().numpy(), fx0=fx0.cpu().numpy(),\n"
+        "         kernel=_lib.lib().umnn_last_kernel_name().decode())\n") % root
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for pipe in ("1", "0"):
+            path = os.path.join(tmp, f"pipe{pipe}.npz")
+            env = dict(os.environ, UMNN_FWD_PIPE=pipe, UMNN_FWD_P="2")
+            r = subprocess.run([sys.executable, "-W", "ignore", "-c", code, path], env=env, capture_output=True,
+                               text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            out[pipe] = dict(np.load(path))
+    assert "PIPE" in str(out["1"]["kernel"]) and "PIPE" not in str(out["0"]["kernel"]), (out["1"]["kernel"], out["0"]["kernel"])
+    for k in ("F", "fx", "fx0"):
+        assert np.array_equal(out["1"][k], out["0"][k]), k

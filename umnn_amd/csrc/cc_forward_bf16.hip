@@ -430,8 +430,6 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
     }
     const int img_floats = (off16 + 1) / 2;
     args.f.m.lds_off[L] = (img_floats + 3) & ~3;          // NS-reduction scratch starts after the images
-    const size_t lds_bytes = ((size_t)args.f.m.lds_off[L] + (ns > 1 ? UMNN_WAVES_PER_BLOCK * 3 * P * 16 : 0)) * sizeof(float);
-    if (lds_bytes > 160 * 1024) return UMNN_EUNSUPPORTED;
     int exact = 1, nrl = a.m.ks_in[1];        // live registers per lane when every hidden layer has the same K-step count
     for (int l = 1; l <= L; ++l) {
         exact = exact && a.m.t_out[l] == T;
@@ -439,6 +437,12 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
     }
     static const int pipe_env = [] { const char* e = getenv("UMNN_FWD_PIPE"); return e ? atoi(e) : 1; }();
     const bool want_pipe = pipe_env != 0 && L >= 2;
+    // the pipelined loop needs two point tiles per wave and pays off as soon as that still leaves a wave per SIMD
+    // (measured at the POWER and VAE shapes: P=2, NS=1 beats every P=1 split by 6-7 %)
+    if (want_pipe && exact && T == 4 && nparts == 2 && !getenv("UMNN_FWD_P") && !getenv("UMNN_FWD_NS") &&
+        (a.NI + 15) / 16 >= 2LL * umnn_num_cus() * 4) { P = 2; ns = 1; }
+    const size_t lds_bytes = ((size_t)args.f.m.lds_off[L] + (ns > 1 ? UMNN_WAVES_PER_BLOCK * 3 * P * 16 : 0)) * sizeof(float);
+    if (lds_bytes > 160 * 1024) return UMNN_EUNSUPPORTED;
     const Bf16Variant* pick = nullptr;
     for (int ex = exact; ex >= 0 && !pick; --ex)
         for (int pass = 0; pass < 2 && !pick; ++pass)      // pass 0: a variant with exactly this live-register count
