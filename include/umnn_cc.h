@@ -141,6 +141,13 @@ int umnn_get_backward_precision(void);
 int umnn_profile_enable(int on);
 int umnn_profile_read(double* total_ms, long long* launches, double* total_flops);
 
+/* MADE conditioner operand builder (reference models/UMNN/made.py:16-27: MaskedLinear chains around ReLU).  Reads the
+ * previous layer's raw fp32 output x [rows, cols] and writes, per row, the bf16 operand
+ *   [ hi(a) | lo(a) | hi(a) | 1 | 1 | 0 ... ]  (ld_out >= 3*cols+2 bf16 per row),  a = relu ? max(x,0) : x,
+ * hi/lo = round-to-nearest bf16 pieces of a.  Multiplied (one bf16 GEMM, fp32 accumulate) by the host-packed weights
+ * [Wh | Wh | Wl | bh | bl | 0...] it gives W a + b to ~3e-6 of the output range. */
+int umnn_made_split3(const float* x, long long rows, int cols, int relu, void* out_bf16, int ld_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,7 @@ SIGNATURES = {
     "umnn_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "umnn_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_ll),
                                          ctypes.POINTER(ctypes.c_double)]),
+    "umnn_made_split3": (ctypes.c_int, [_fp, _ll, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]),
 }
 
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}
