@@ -394,3 +394,44 @@ def test_pipelined_and_plain_bf16x3_kernels_agree_bit_for_bit(dev):
     assert "PIPE" in str(out["1"]["kernel"]) and "PIPE" not in str(out["0"]["kernel"]), (out["1"]["kernel"], out["0"]["kernel"])
     for k in ("F", "fx", "fx0"):
         assert np.array_equal(out["1"][k], out["0"][k]), k
+
+
+@pytest.mark.parametrize("hid,relu,sigmoid,inv_f,n,NS", [
+    ([50, 50], False, False, False, 100, 1),       # one hidden->hidden layer: first section + last section only
+    ([50, 50, 50], True, False, False, 51, 2),     # ReLU, odd node count, node range split over two waves
+    ([56, 56, 56, 56], False, True, False, 40, 1),  # widths 52..62: all 16 registers live; Sigmoid output
+    ([63, 63, 63], False, False, True, 30, 4),     # full tiles (63 + the constant feature), 1/f integrand
+    ([48, 49, 50, 51, 50], False, False, False, 20, 1),   # mixed widths inside the 4-tile family, 5 hidden layers
+])
+def test_pipelined_kernel_shapes_against_oracle(hid, relu, sigmoid, inv_f, n, NS, dev, monkeypatch):
+    """The software-pipelined bf16x3 loop (two point tiles per wave) over its whole shape family, against the oracle."""
+    import umnn_amd
+    from umnn_amd import integral as I, _lib
+    from umnn_amd.nets import MlpSpec
+    if umnn_amd.get_forward_precision() != "bf16x3":
+        pytest.skip("the pipelined loop exists for bf16x3 only")
+    monkeypatch.setenv("UMNN_FWD_P", "2")
+    monkeypatch.setenv("UMNN_FWD_NS", str(NS))
+    B, d, E = 23, 5, 7
+    rng = np.random.RandomState(len(hid) * 17 + n)
+    sizes = [1 + E] + hid + [1]
+    Ws = [(rng.randn(sizes[i + 1], sizes[i]) * (1.6 / np.sqrt(sizes[i]))).astype(np.float32) for i in range(len(sizes) - 1)]
+    bs = [(rng.randn(sizes[i + 1]) * 0.3).astype(np.float32) for i in range(len(sizes) - 1)]
+    lin = []
+    for W, b in zip(Ws, bs):
+        m = torch.nn.Linear(W.shape[1], W.shape[0])
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(W))
+            m.bias.copy_(torch.from_numpy(b))
+        lin.append(m.to(dev))
+    spec = MlpSpec(lin, _lib.ACT_RELU if relu else _lib.ACT_LEAKY_RELU, _lib.OUT_SIGMOID if sigmoid else _lib.OUT_ELU_PLUS_ONE)
+    net = O.Net(Ws, bs, O.RELU if relu else O.LEAKY, O.SIGMOID if sigmoid else O.ELU1)
+    x = (rng.randn(B, d) * 2).astype(np.float32)
+    x0 = (rng.randn(B, d) * 0.5).astype(np.float32)
+    h = rng.randn(B, E * d).astype(np.float32)
+    F, fx, fx0 = I.hip_forward(spec, t(x0, dev), t(x, dev), t(h, dev), n, inv_f=inv_f)
+    kname = _lib.lib().umnn_last_kernel_name().decode()
+    assert "PIPE" in kname, kname
+    assert U.rel_err(F.cpu().numpy(), O.integrate_parallel(net, x0, x, h, n, inv_f=inv_f)) < TOL
+    assert U.rel_err(fx.cpu().numpy(), O.integrand(net, x, h)) < TOL
+    assert U.rel_err(fx0.cpu().numpy(), O.integrand(net, x0, h)) < TOL
