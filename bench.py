@@ -190,6 +190,15 @@ def main():
                 traffic = None
         on_bf16 = "bf16" in kernel_name
         peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
+        # FLOPs the matrix pipe actually executes per launch in the bf16-split kernels: per hidden->hidden layer
+        # ceil((H_out+1)/16) output tiles x ceil(ceil((H_in+1)/16)/2) K-steps x 3|6 cross terms of 16x16x32 MFMAs
+        # (2*16*16*32 FLOPs each) per 16 integrals and node
+        executed = None
+        if on_bf16:
+            hd, terms = cfg["hd"], (3 if "PARTS=2" in kernel_name else 6)
+            per_tile_node = sum(-(-(hd[i + 1] + 1) // 16) * -(-(-(-(hd[i] + 1) // 16)) // 2) * terms for i in range(len(hd) - 1))
+            tiles = -(-cfg["rows"] * cfg["d"] // 16)
+            executed = per_tile_node * 16384.0 * tiles * (cfg["n"] + 1) / max(avg_kernel_ms, 1e-9) / 1e9
         dtype = {"fp32": "f32", "bf16x3": "f32 via bf16x3-split MFMA (fp32 accumulate)",
                  "bf16x6": "f32 via bf16x6-split MFMA (fp32 accumulate)"}[precision] if on_bf16 or precision == "fp32" \
             else "f32"
@@ -213,7 +222,9 @@ def main():
                          "flops_per_launch": k_fl.value / max(1, k_n.value),
                          "kernel_share_of_step": k_ms.value / (1e3 * elapsed),
                          "peak_dtype": "bf16 dense MFMA" if on_bf16 else "fp32 MFMA",
-                         "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS},
+                         "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "executed_mfma_tflops": executed,
+                         "executed_frac_of_peak": executed / peak if executed else None},
         }
         if exact is not None:
             out["exact_fp32"] = exact
