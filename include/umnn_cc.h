@@ -81,6 +81,16 @@ int umnn_flow_block_forward(const umnn_mlp* net, const float* x, const float* h,
                             long long B, int d, int E,
                             float* z, float* log_jac, float* f_x, float* f_x0, void* stream);
 
+/* The same block as one link of a UMNNMAFFlow stack (UMNNMAFFlow.py:109-123: `for net: z, lj = ...; log_jac += lj;
+ * x = z[:, inv_idx]`), with the glue between blocks folded into the kernel's stores:
+ *   reverse_z != 0   z is written with its dimensions reversed, z[b, d-1-i] -- the input of the next block;
+ *   log_jac_in       nullable [B,d]: running sum over the previous blocks; log_jac = log_jac_in + this block's
+ *                    (same index order as the reference's elementwise `+=`; may alias log_jac). */
+int umnn_flow_stack_block_forward(const umnn_mlp* net, const float* x, const float* h, const float* scaling,
+                                  const float* cc_w, const float* cc_s, int nb_steps,
+                                  long long B, int d, int E, int reverse_z, const float* log_jac_in,
+                                  float* z, float* log_jac, float* f_x, float* f_x0, void* stream);
+
 /* Replaces integrate(..., compute_grad=True) + the Leibniz terms -- ParallelNeuralIntegral.py:66-94,
  * 110-123 (NeuralIntegral.py:47-58,69-75,90-99).  g is grad_output [B,d] (cotangent of F).
  *   g_fx    nullable [B,d]: cotangent of the f_x output of umnn_cc_forward.  The reference gets this

@@ -435,3 +435,21 @@ def test_pipelined_kernel_shapes_against_oracle(hid, relu, sigmoid, inv_f, n, NS
     assert U.rel_err(F.cpu().numpy(), O.integrate_parallel(net, x0, x, h, n, inv_f=inv_f)) < TOL
     assert U.rel_err(fx.cpu().numpy(), O.integrand(net, x, h)) < TOL
     assert U.rel_err(fx0.cpu().numpy(), O.integrand(net, x0, h)) < TOL
+
+
+def test_stack_block_entry_reverses_z_and_accumulates_log_jac(dev):
+    """umnn_flow_stack_block_forward = umnn_flow_block_forward + the glue between the blocks of a flow
+    (UMNNMAFFlow.py:109-123): same bits, z stored reversed, log_jac added to the running sum."""
+    from umnn_amd import integral as I, IntegrandNetwork
+    from umnn_amd.nets import mlp_spec
+    torch.manual_seed(11)
+    B, d, E = 70, 9, 5
+    net = IntegrandNetwork(d, 1 + E, [50, 50, 50], 1).to(dev)
+    spec = mlp_spec(net)
+    x, h = torch.randn(B, d, device=dev), torch.randn(B, E * d, device=dev)
+    scaling = torch.randn(d, device=dev) * 0.1
+    run = torch.randn(B, d, device=dev)
+    z, lj, fx, fx0 = I.hip_flow_block(spec, x, h, scaling, 30)
+    z2, lj2, fx2, fx02 = I.hip_flow_block(spec, x, h, scaling, 30, reverse_z=True, log_jac_in=run)
+    assert torch.equal(z2, torch.flip(z, [1])) and torch.equal(lj2, run + lj)
+    assert torch.equal(fx, fx2) and torch.equal(fx0, fx02)

@@ -36,6 +36,9 @@ SIGNATURES = {
                                        _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]),
     "umnn_flow_block_forward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                                _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp]),
+    "umnn_flow_stack_block_forward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                                     _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
+                                                     _fp, _fp, _fp, _fp, _fp]),
     "umnn_cc_backward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                         _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _ll, _fp]),
     "umnn_cc_backward_workspace_bytes": (_ll, [ctypes.POINTER(MlpDesc), _ll, ctypes.c_int, ctypes.c_int]),

@@ -260,7 +260,8 @@ extern "C" int umnn_get_forward_precision(void) { return fwd_precision(); }
 static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, const float* h,
                           const float* scaling, const float* cc_w, const float* cc_s, int nb_steps,
                           long long B, int d, int E, int inv_f,
-                          float* F, float* f_x, float* f_x0, float* z, float* log_jac, hipStream_t stream) {
+                          float* F, float* f_x, float* f_x0, float* z, float* log_jac, hipStream_t stream,
+                          int reverse_z = 0, const float* log_jac_in = nullptr) {
     FwdArgs a;
     int tmax = 0, ksu = 0;
     if (int rc = umnn_prepare_mlp(net, E, &a.m, &tmax, &ksu)) return rc;
@@ -273,6 +274,7 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
 
     a.x0 = x0; a.x = x; a.h = h; a.ccw = cc_w; a.ccs = cc_s;
     a.F = F; a.fx = f_x; a.fx0 = f_x0; a.scaling = scaling; a.z = z; a.logjac = log_jac;
+    a.logjac_in = log_jac_in; a.reverse_z = reverse_z;
     a.NI = B * (long long)d; a.d = d; a.E = E; a.n = nb_steps; a.inv_f = inv_f;
 
     // ---- choose the variant: exact (compile-time K-steps) when all hidden layers share a width we
@@ -351,6 +353,16 @@ extern "C" int umnn_flow_block_forward(const umnn_mlp* net, const float* x, cons
     if (!scaling) return umnn_fail(UMNN_EINVAL, "flow forward: scaling must be non-null");
     return launch_forward(net, nullptr, x, h, scaling, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr, f_x, f_x0,
                           z, log_jac, (hipStream_t)stream);
+}
+
+extern "C" int umnn_flow_stack_block_forward(const umnn_mlp* net, const float* x, const float* h, const float* scaling,
+                                             const float* cc_w, const float* cc_s, int nb_steps,
+                                             long long B, int d, int E, int reverse_z, const float* log_jac_in,
+                                             float* z, float* log_jac, float* f_x, float* f_x0, void* stream) {
+    if (!scaling) return umnn_fail(UMNN_EINVAL, "flow forward: scaling must be non-null");
+    if (z == x && reverse_z) return umnn_fail(UMNN_EINVAL, "flow forward: z must not alias x when reverse_z is set");
+    return launch_forward(net, nullptr, x, h, scaling, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr, f_x, f_x0,
+                          z, log_jac, (hipStream_t)stream, reverse_z != 0, log_jac_in);
 }
 
 extern "C" int umnn_cc_forward_timed(const umnn_mlp* net, const float* x0, const float* x, const float* h,

@@ -15,6 +15,8 @@ struct FwdArgs {
     const float* scaling;  // flow epilogue (nullable => plain integral)
     float* z;
     float* logjac;
+    const float* logjac_in;   // nullable: running sum of the previous blocks' log_jac (may alias logjac)
+    int reverse_z;            // write z with the dimensions reversed (the flip between the blocks of a flow)
     long long NI;      // B*d integrals
     int d, E, n, ns, inv_f;
     unsigned ngroups;  // tile groups (of 16*P integrals)
@@ -64,8 +66,9 @@ __device__ __forceinline__ void fwd_epilogue(const FwdArgs& a, float* lds, float
                 const int i = (int)(q - bi * d);
                 const float sc = a.scaling[i];
                 const float z0 = a.h[bi * ((long long)E * d) + i];
-                a.z[q] = __expf(sc) * (Fv + z0);
-                a.logjac[q] = __logf(fxv[pt] + 1e-10f) + sc;
+                a.z[a.reverse_z ? bi * d + (d - 1 - i) : q] = __expf(sc) * (Fv + z0);
+                const float lj = __logf(fxv[pt] + 1e-10f) + sc;
+                a.logjac[q] = a.logjac_in ? a.logjac_in[q] + lj : lj;
             }
         }
     }

@@ -84,8 +84,10 @@ class UMNNMAF(nn.Module):
         return self
 
     # ------------------------------------------------------------------ core: one pass, both outputs
-    def _transform(self, x, context=None, x0=None, want_jac=True):
-        """-> (z, log_jac or None).  One conditioner pass, one quadrature launch."""
+    def _transform(self, x, context=None, x0=None, want_jac=True, reverse_z=False, log_jac_in=None):
+        """-> (z, log_jac or None).  One conditioner pass, one quadrature launch.  ``reverse_z`` / ``log_jac_in`` are
+        the glue of a UMNNMAFFlow stack (UMNNMAFFlow.py:109-123): z with its dimensions reversed for the next block,
+        log_jac added to the running sum -- inside the kernel on the HIP inference path, with ATen ops otherwise."""
         if self.solver not in _SOLVERS:
             return None, None
         integrand = self.net.parallel_nets
@@ -96,7 +98,7 @@ class UMNNMAF(nn.Module):
         no_graph = (not torch.is_grad_enabled()) or ((not self.training) and (not x.requires_grad))
         if _I._use_hip(spec, x):
             if no_graph and x0 is None:
-                z, log_jac, _, _ = _I.hip_flow_block(spec, x, h, self.scaling, self.nb_steps)
+                z, log_jac, _, _ = _I.hip_flow_block(spec, x, h, self.scaling, self.nb_steps, reverse_z, log_jac_in)
                 return z, log_jac
             x0 = x0.to(x.device) if x0 is not None else torch.zeros_like(x)
             if no_graph:
@@ -114,6 +116,10 @@ class UMNNMAF(nn.Module):
             fx = integrand(x, h) if want_jac else None
         z = torch.exp(self.scaling).unsqueeze(0) * (F + z0)
         log_jac = torch.log(fx + 1e-10) + self.scaling.unsqueeze(0) if want_jac else None
+        if reverse_z:
+            z = torch.flip(z, [1])
+        if log_jac_in is not None and log_jac is not None:
+            log_jac = log_jac_in + log_jac
         return z, log_jac
 
     # ------------------------------------------------------------------ reference API
@@ -257,13 +263,15 @@ class UMNNMAFFlow(nn.Module):
 
     def _stack(self, x, context, want_jac):
         """Run the blocks with the dimension reversal between them -> (z in original order, summed log_jac)."""
-        log_jac = 0.
-        for net in self.nets:
-            z, lj = net._transform(x, context, want_jac=want_jac)
+        log_jac = None
+        nb = len(self.nets)
+        for i, net in enumerate(self.nets):
+            # every block but the last hands its z over reversed (the reference flips after every block and once more
+            # at the end: the last two flips cancel); log_jac accumulates elementwise in each block's own input order
+            x, lj = net._transform(x, context, want_jac=want_jac, reverse_z=i + 1 < nb, log_jac_in=log_jac)
             if want_jac:
-                log_jac = log_jac + lj
-            x = torch.flip(z, [1])
-        return torch.flip(x, [1]), log_jac
+                log_jac = lj
+        return x, (log_jac if want_jac else 0.)
 
     def forward(self, x, context=None):
         return self._stack(x, context, False)[0]

@@ -136,8 +136,9 @@ def hip_forward(spec, x0, x, h, nb_steps, inv_f=False):
     return F, fx, fx0
 
 
-def hip_flow_block(spec, x, h, scaling, nb_steps):
-    """Fused block epilogue -> (z, log_jac, f_x, f_x0)."""
+def hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z=False, log_jac_in=None):
+    """Fused block epilogue -> (z, log_jac, f_x, f_x0).  ``reverse_z``: z comes back with its dimensions reversed (the
+    flip between the blocks of a flow); ``log_jac_in``: running log_jac of the previous blocks, added in the kernel."""
     lib = _lib.lib()
     B, d, E = _shape(spec, x, h)
     out_dtype = x.dtype
@@ -147,9 +148,11 @@ def hip_flow_block(spec, x, h, scaling, nb_steps):
     desc, keep = _desc(spec)
     with torch.cuda.device(x.device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        rc = lib.umnn_flow_block_forward(ctypes.byref(desc), _ptr(x), _ptr(h), _ptr(scaling), _ptr(w), _ptr(s),
-                                         int(nb_steps), B, d, E, _ptr(z), _ptr(lj), _ptr(fx), _ptr(fx0), stream)
-    _lib.check(rc, "umnn_flow_block_forward")
+        lj_in = _f32c(log_jac_in) if log_jac_in is not None else None
+        rc = lib.umnn_flow_stack_block_forward(ctypes.byref(desc), _ptr(x), _ptr(h), _ptr(scaling), _ptr(w), _ptr(s),
+                                               int(nb_steps), B, d, E, 1 if reverse_z else 0, _ptr(lj_in),
+                                               _ptr(z), _ptr(lj), _ptr(fx), _ptr(fx0), stream)
+    _lib.check(rc, "umnn_flow_stack_block_forward")
     _state.path = "hip"
     if out_dtype != torch.float32:
         z, lj, fx, fx0 = z.to(out_dtype), lj.to(out_dtype), fx.to(out_dtype), fx0.to(out_dtype)
