@@ -24,9 +24,12 @@
 #include "cc_fwd_shared.h"
 #include "cc_host.h"
 
-// Stage the pre-split, pre-permuted weight fragments.  img16 index: ((t'*ks + s)*NPARTS + part)*512 + lane*8 + j
+// Stage the pre-split, pre-permuted weight fragments.  img16 index: ((t'*ks + s)*NPARTS + part)*512 + lane*8 + j.
+// half_in[l] != 0: the input layer has an odd tile count; ks counts its FULL K-steps (tile pairs) only and the last
+// tile follows as half fragments (64 lanes x 4 bf16, for the K = 16 MFMA) at ((t'*NPARTS + part)*256 + lane*4 + j)
+// behind the full ones -- the padding tile of a full K-step would cost 7 KB of LDS per layer and part at width 100.
 template <int NPARTS>
-__device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks32, const int* off16,
+__device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks32, const int* off16, const int* half_in,
                                                   unsigned short* lds16, int tid, int nthreads) {
     const int L = m.n_linear - 1;
     for (int l = 1; l < L; ++l) {
@@ -55,12 +58,34 @@ __device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks
                 v -= bf16_bits_to_f32(hb);
             }
         }
+        if (half_in[l]) {
+            unsigned short* himg = img + to * ks * NPARTS * 512;
+            for (int idx = tid; idx < to * 256; idx += nthreads) {
+                const int j = idx & 3, ln = (idx >> 2) & 63, t = idx >> 8;
+                const int fo = fout_of(t, ln & 15);
+                const int fi = feat_of(2 * ks, j, ln >> 4);
+                float v = 0.f;
+                if (fo < Hout) {
+                    if (fi < Hin) v = W[fo * Hin + fi];
+                    else if (fi == Hin) v = b[fo];
+                } else if (fo == Hout && fi == Hin) {
+                    v = 1.f;
+                }
+#pragma unroll
+                for (int part = 0; part < NPARTS; ++part) {
+                    const unsigned short hb = bf16_rn_bits(v);
+                    himg[(t * NPARTS + part) * 256 + ln * 4 + j] = hb;
+                    v -= bf16_bits_to_f32(hb);
+                }
+            }
+        }
     }
 }
 
 struct Bf16Plan {
     int ks32[UMNN_MAX_LINEAR];     // K-steps of 32 features when hidden layer l is the input
     int off16[UMNN_MAX_LINEAR];    // ushort offset of image l
+    int half_in[UMNN_MAX_LINEAR];  // layer l has an odd tile count and its image ends in half fragments (see staging)
     int scratch_off_floats;        // float offset of the NS-reduction scratch (after the images)
 };
 
@@ -121,7 +146,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
     const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
     unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
 
-    stage_bf16_images<NPARTS>(m, args.pl.ks32, args.pl.off16, lds16, tid, UMNN_BLOCK);
+    stage_bf16_images<NPARTS>(m, args.pl.ks32, args.pl.off16, args.pl.half_in, lds16, tid, UMNN_BLOCK);
     __syncthreads();
 
     const int ns = a.ns;
@@ -338,6 +363,20 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) bf[pt][s][k2] = u32x4{q0[k2], q1[k2], q2[k2], q3[k2]};
                     }
+                // odd tile count (EXACT only): the last tile is a K = 16 step of its own
+                u32x2 hb[P][NPARTS];
+                if constexpr (EXACT && (TMAX & 1)) {
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt) {
+                        unsigned q0[NPARTS], q1[NPARTS];
+#pragma unroll
+                        for (int k2 = 0; k2 < NPARTS; ++k2) q0[k2] = q1[k2] = 0u;
+                        if (4 * (TMAX - 1) + 0 < NLIVE) split_pair<NPARTS>(act[pt][TMAX - 1][0], act[pt][TMAX - 1][1], q0);
+                        if (4 * (TMAX - 1) + 2 < NLIVE) split_pair<NPARTS>(act[pt][TMAX - 1][2], act[pt][TMAX - 1][3], q1);
+#pragma unroll
+                        for (int k2 = 0; k2 < NPARTS; ++k2) hb[pt][k2] = u32x2{q0[k2], q1[k2]};
+                    }
+                }
                 f32x4 acc[P][TMAX];
 #pragma unroll
                 for (int pt = 0; pt < P; ++pt)
@@ -369,6 +408,26 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                                     }
                             }
                     }
+                }
+                if constexpr (EXACT && (TMAX & 1)) {
+                    const unsigned short* himg = lds16 + args.pl.off16[l] + TMAX * KSM * NPARTS * 512 + lane * 4;
+                    u32x2 wh[TMAX][NPARTS];
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                        for (int k2 = 0; k2 < NPARTS; ++k2)
+                            wh[t][k2] = *reinterpret_cast<const u32x2*>(himg + (t * NPARTS + k2) * 256);
+#pragma unroll
+                    for (int wa = 0; wa < NPARTS; ++wa)
+#pragma unroll
+                        for (int ba = 0; ba < NPARTS; ++ba) {
+                            if (wa + ba >= NPARTS) continue;
+#pragma unroll
+                            for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                                for (int pt = 0; pt < P; ++pt)
+                                    acc[pt][t] = mfma_bf16_k16(wh[t][wa], hb[pt][ba], acc[pt][t]);
+                        }
                 }
 #pragma unroll
                 for (int pt = 0; pt < P; ++pt)
@@ -409,6 +468,7 @@ static const Bf16Variant kBf16Variants[] = {
     BF16_VARIANT(4, 2, 1, 1, 0), BF16_VARIANT(4, 2, 2, 1, 0), BF16_VARIANT(4, 3, 1, 1, 0), BF16_VARIANT(4, 3, 2, 1, 0),       // widths 52..62
     BF16_VARIANT(2, 2, 1, 0, 0), BF16_VARIANT(2, 2, 2, 0, 0), BF16_VARIANT(2, 3, 1, 0, 0), BF16_VARIANT(2, 3, 2, 0, 0),
     BF16_VARIANT(4, 2, 1, 0, 0), BF16_VARIANT(4, 2, 2, 0, 0), BF16_VARIANT(4, 3, 1, 0, 0), BF16_VARIANT(4, 3, 2, 0, 0),
+    BF16_VARIANT(7, 2, 1, 1, 26), BF16_VARIANT(7, 2, 1, 1, 0),   // widths 96..111 (100-wide toy / MonotonicNN nets): 3 K-steps + a half one
     BF16_VARIANT(8, 2, 1, 0, 0), BF16_VARIANT(8, 2, 2, 0, 0),   // (8 tiles x 3 parts does not fit the register file: fp32 kernels instead)
 };
 
@@ -419,14 +479,26 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
     const int L = a.m.n_linear - 1;
     int tmax = 0;
     for (int l = 1; l <= L; ++l) tmax = a.m.t_out[l] > tmax ? a.m.t_out[l] : tmax;
-    const int T = tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8;
+    int T = tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8;
+    bool seven = nparts == 2;              // every hidden layer 7 tiles wide: the exact variant with a half K-step
+    for (int l = 1; l <= L; ++l) seven = seven && a.m.t_out[l] == 7;
+    if (seven && (P == 1 || !getenv("UMNN_FWD_P"))) { T = 7; P = 1; } else seven = false;   // (no two-tile variant at this width)
+    if (seven && !getenv("UMNN_FWD_NS")) {
+        // 147 KB of images = one workgroup per CU = one wave per SIMD: split the node range only as far as that fills
+        const long long tiles16 = (a.NI + 15) / 16, slots = (long long)umnn_num_cus() * 4;
+        ns = tiles16 * 4 <= slots ? 4 : tiles16 * 2 <= slots ? 2 : 1;
+        if (ns > nb_steps + 1) ns = 1;
+    }
     FwdBf16Args args;
     args.f = a;
     int off16 = 0;
-    for (int l = 1; l <= L; ++l) args.pl.ks32[l] = (a.m.t_out[l] + 1) / 2;
+    for (int l = 1; l <= L; ++l) {
+        args.pl.half_in[l] = seven ? 1 : 0;
+        args.pl.ks32[l] = seven ? 3 : (a.m.t_out[l] + 1) / 2;
+    }
     for (int l = 1; l < L; ++l) {
         args.pl.off16[l] = off16;
-        off16 += a.m.t_out[l + 1] * args.pl.ks32[l] * nparts * 512;
+        off16 += a.m.t_out[l + 1] * (args.pl.ks32[l] * nparts * 512 + args.pl.half_in[l] * nparts * 256);
     }
     const int img_floats = (off16 + 1) / 2;
     args.f.m.lds_off[L] = (img_floats + 3) & ~3;          // NS-reduction scratch starts after the images
