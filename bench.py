@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--mode", default="eval", choices=["eval", "train"],
                     help="eval: compute_ll forward (the headline metric). train: forward + backward + one flattened "
                          "RCCL gradient all-reduce + Adam step per step (reported as training samples/s)")
+    ap.add_argument("--graph", action="store_true",
+                    help="eval only: replay the step as one captured hipGraph (umnn_amd.GraphedLL) -- for the launch-bound "
+                         "small workloads; the roofline record then comes from an eager pass after the timed region")
     ap.add_argument("--precision", default="", choices=["", "fp32", "bf16x3", "bf16x6"],
                     help="forward arithmetic (default: the library default, bf16x3)")
     args = ap.parse_args()
@@ -127,9 +130,14 @@ def main():
             opt.step()
             return ll.detach(), z
     else:
-        def step():
+        def eager_step():
             with torch.no_grad():
                 return model.compute_ll(x)
+        step = eager_step
+        if args.graph:
+            import umnn_amd
+            graphed = umnn_amd.GraphedLL(model, x)
+            step = lambda: graphed()        # noqa: E731  (x is already in the captured buffer)
 
     for _ in range(args.warmup):
         step()
@@ -147,6 +155,13 @@ def main():
     k_ms, k_n, k_fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
     lib.umnn_profile_read(ctypes.byref(k_ms), ctypes.byref(k_n), ctypes.byref(k_fl))
     lib.umnn_profile_enable(0)
+    if args.graph and args.mode == "eval":      # launches inside a replayed graph carry no events: time them eagerly
+        lib.umnn_profile_enable(1)
+        for _ in range(max(3, args.steps // 4)):
+            eager_step()
+        torch.cuda.synchronize()
+        lib.umnn_profile_read(ctypes.byref(k_ms), ctypes.byref(k_n), ctypes.byref(k_fl))
+        lib.umnn_profile_enable(0)
     assert torch.isfinite(ll).all()
     kernel_name = lib.umnn_last_kernel_name().decode()
 
@@ -220,12 +235,15 @@ def main():
                          "kernel": kernel_name, "avg_launch_ms": avg_kernel_ms,
                          "launches": k_n.value,
                          "flops_per_launch": k_fl.value / max(1, k_n.value),
-                         "kernel_share_of_step": k_ms.value / (1e3 * elapsed),
+                         "kernel_share_of_step": (avg_kernel_ms * cfg["nb_flow"] / ms_step) if args.graph
+                         else k_ms.value / (1e3 * elapsed),
                          "peak_dtype": "bf16 dense MFMA" if on_bf16 else "fp32 MFMA",
                          "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "executed_mfma_tflops": executed,
                          "executed_frac_of_peak": executed / peak if executed else None},
         }
+        if args.graph:
+            out["config"]["graph"] = "step replayed as one hipGraph; roofline timings from an eager pass after the timed region"
         if exact is not None:
             out["exact_fp32"] = exact
         if args.mode == "train":

@@ -453,3 +453,22 @@ def test_stack_block_entry_reverses_z_and_accumulates_log_jac(dev):
     z2, lj2, fx2, fx02 = I.hip_flow_block(spec, x, h, scaling, 30, reverse_z=True, log_jac_in=run)
     assert torch.equal(z2, torch.flip(z, [1])) and torch.equal(lj2, run + lj)
     assert torch.equal(fx, fx2) and torch.equal(fx0, fx02)
+
+
+def test_graphed_compute_ll_replays_the_same_numbers(dev):
+    """hipGraph capture of a whole compute_ll (conditioner GEMMs + quadrature launches through the C ABI): replays
+    must reproduce the eager result bit for bit, also on new data copied into the captured buffers."""
+    import umnn_amd
+    torch.manual_seed(4)
+    model = umnn_amd.UMNNMAFFlow(nb_flow=2, nb_in=2, hidden_derivative=[100] * 4, hidden_embedding=[100] * 4, embedding_s=10,
+                                 nb_steps=50, device=dev).to(dev)
+    model.eval()
+    x1, x2 = torch.randn(512, 2, device=dev), torch.randn(512, 2, device=dev)
+    with torch.no_grad():
+        ref1 = [t.clone() for t in model.compute_ll(x1)]
+        ref2 = [t.clone() for t in model.compute_ll(x2)]
+    g = umnn_amd.GraphedLL(model, x1)
+    out = g()
+    assert torch.equal(out[0], ref1[0]) and torch.equal(out[1], ref1[1])
+    out = g(x2)
+    assert torch.equal(out[0], ref2[0]) and torch.equal(out[1], ref2[1])

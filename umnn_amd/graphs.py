@@ -1,0 +1,36 @@
+"""hipGraph capture of a launch-bound inference step (small flows: the 2-D toy configuration is ~17 short launches).
+
+``GraphedLL(model, x_example)`` records ``model.compute_ll`` once on static buffers (``torch.cuda.CUDAGraph``; the
+quadrature launches of libumnn_cc go to torch's current stream, so they are captured like any ATen kernel) and replays
+it per call.  Inference only (autograd off); shapes are fixed at capture.  For the large configurations the step is one
+long kernel per block and a graph buys nothing."""
+import torch
+
+
+class GraphedLL:
+    def __init__(self, model, x_example, context=None, warmup=3):
+        assert x_example.is_cuda, "hipGraph capture needs device tensors"
+        self.model = model
+        self.x = x_example.clone()
+        self.context = context.clone() if context is not None else None
+        with torch.no_grad():
+            side = torch.cuda.Stream(device=x_example.device)
+            side.wait_stream(torch.cuda.current_stream(x_example.device))
+            with torch.cuda.stream(side):               # warm every cache (LDS caps, tables, packed weights) first
+                for _ in range(warmup):
+                    model.compute_ll(self.x, self.context) if self.context is not None else model.compute_ll(self.x)
+            torch.cuda.current_stream(x_example.device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = model.compute_ll(self.x, self.context) if self.context is not None \
+                    else model.compute_ll(self.x)
+
+    def __call__(self, x=None, context=None):
+        """Replay on new data (copied into the captured buffers); returns the captured output tensors (overwritten by
+        the next call)."""
+        if x is not None:
+            self.x.copy_(x)
+        if context is not None:
+            self.context.copy_(context)
+        self.graph.replay()
+        return self.out
