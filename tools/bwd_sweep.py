@@ -13,8 +13,8 @@ from umnn_amd.nets import mlp_spec  # noqa: E402
 from tools.fwd_sweep import SHAPES  # noqa: E402
 
 
-def run(shape, reps, gfx):
-    B, d, E, hid, n = SHAPES[shape]
+def run(shape, reps, gfx, override=None):
+    B, d, E, hid, n = override or SHAPES[shape]
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     net = IntegrandNetwork(d, 1 + E, hid, 1).to(dev)
@@ -40,7 +40,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="bsds300")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--custom", default="", help="B,d,E,H,L,n  e.g. 100,2,10,100,4,20")
     a = ap.parse_args()
-    for sh in a.shape.split(","):
-        run(sh, a.reps, False)
-        run(sh, a.reps, True)
+    if a.custom:
+        B, d, E, H, L, n = (int(v) for v in a.custom.split(","))
+        run(f"B{B}d{d}", a.reps, True, (B, d, E, [H] * L, n))
+    else:
+        for sh in a.shape.split(","):
+            run(sh, a.reps, False)
+            run(sh, a.reps, True)

@@ -451,6 +451,7 @@ static const BwdVariant kBwdVariants[] = {
     BWD_VARIANT(4, 3, 1, 13), BWD_VARIANT(4, 3, 0, 13),     // exact: every hidden layer 48..51 wide (UCI / VAE nets)
     BWD_VARIANT(2, 3, 1, 0), BWD_VARIANT(2, 3, 0, 0),
     BWD_VARIANT(4, 3, 1, 0), BWD_VARIANT(4, 3, 0, 0),
+    BWD_VARIANT(7, 0, 1, 26), BWD_VARIANT(7, 1, 0, 26),   // exact: every hidden layer 100 wide (toy flows, MonotonicNN): no spills
     BWD_VARIANT(7, 0, 1, 0), BWD_VARIANT(7, 1, 0, 0),
     BWD_VARIANT(8, 0, 1, 0), BWD_VARIANT(8, 1, 0, 0),
 };
