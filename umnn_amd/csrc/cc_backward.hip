@@ -148,7 +148,10 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
     const unsigned wave_global = blockIdx.x * nwb + wid;
     const unsigned nwaves = gridDim.x * nwb;
 
-    for (unsigned grp = wave_global; grp < a.ngroups; grp += nwaves) {
+    const unsigned nsp = a.ns > 1 ? (unsigned)a.ns : 1u;
+    for (unsigned item = wave_global; item < a.ngroups * nsp; item += nwaves) {
+        const unsigned grp = item / nsp, part = item - grp * nsp;
+        const int k_lo = (int)(((long long)part * (n + 1)) / nsp), k_hi = (int)(((long long)(part + 1) * (n + 1)) / nsp);
         const long long q = (long long)grp * 16 + p;
         const bool ok = q < a.NI;
         const long long qq = ok ? q : a.NI - 1;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
         for (int t = 0; t < TMAX; ++t) dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         float fxv = 0.f, fx0v = 0.f, dfdt = 0.f;
 
-        for (int k = 0; k <= n; ++k) {
+        for (int k = k_lo; k < k_hi; ++k) {
             const float u = a.ccs[k] + 1.f;
             const float wk = a.ccw[k];
             const float tk = k == 0 ? xv : __fadd_rn(x0v, __fmul_rn(dxv, u) * 0.5f);
@@ -323,11 +326,11 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int f = feat_of(t, r, g);
-                    if (f < H1) a.dc[q * H1 + f] = dcs[t][r];
+                    if (f < H1) a.dc[(size_t)part * a.NI * H1 + q * H1 + f] = dcs[t][r];
                 }
-            if (g == 0) {
-                if (a.dx) a.dx[q] = fmaf(gfxv, dfdt, fxv * gv);
-                if (a.dx0) a.dx0[q] = -fx0v * gv;
+            if (g == 0) {       // Leibniz terms: from the work items that own node 0 / node n
+                if (a.dx && k_lo == 0) a.dx[q] = fmaf(gfxv, dfdt, fxv * gv);
+                if (a.dx0 && k_hi == n + 1) a.dx0[q] = -fx0v * gv;
             }
         }
     }
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
 
 // d_h[b, e*d+i] = sum_f W1[f][1+e] dc[q][f]
 __global__ __launch_bounds__(256) void cc_bwd_dh_kernel(const float* __restrict__ dc, const float* __restrict__ W0,
-                                                        float* __restrict__ dh, long long NI, int d, int E, int H1) {
+                                                        float* __restrict__ dh, long long NI, int d, int E, int H1, int ns) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sW = sm;                       // [H1][E]
     float* sdc = sm + H1 * E;             // [64][H1+1]
@@ -381,7 +384,12 @@ __global__ __launch_bounds__(256) void cc_bwd_dh_kernel(const float* __restrict_
     for (int i = tid; i < H1 * E; i += 256) { const int f = i / E, e = i - f * E; sW[i] = W0[f * (1 + E) + 1 + e]; }
     const long long q0 = (long long)blockIdx.x * 64;
     const int nq = (int)min((long long)64, NI - q0);
-    for (int i = tid; i < nq * H1; i += 256) { const int ql = i / H1, f = i - ql * H1; sdc[ql * (H1 + 1) + f] = dc[q0 * H1 + i]; }
+    for (int i = tid; i < nq * H1; i += 256) {
+        const int ql = i / H1, f = i - ql * H1;
+        float v = dc[q0 * H1 + i];
+        for (int j = 1; j < ns; ++j) v += dc[(size_t)j * NI * H1 + q0 * H1 + i];      // node-split partials, fixed order
+        sdc[ql * (H1 + 1) + f] = v;
+    }
     __syncthreads();
     for (int o = tid; o < nq * E; o += 256) {
         const int e = o / nq, ql = o - e * nq;      // ql fastest: consecutive threads -> consecutive i
@@ -395,14 +403,18 @@ __global__ __launch_bounds__(256) void cc_bwd_dh_kernel(const float* __restrict_
 // partial[blk][f][e] = sum_{q in chunk} dc[q][f] * hext[q][e],  hext[q][E] = 1  (-> dW1[:,1:], db1)
 __global__ __launch_bounds__(256) void cc_bwd_dw0_kernel(const float* __restrict__ dc, const float* __restrict__ h,
                                                          float* __restrict__ partial, long long NI, int d, int E,
-                                                         int H1, int chunk) {
+                                                         int H1, int chunk, int ns) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sdc = sm;                          // [chunk][H1]
     float* sh = sm + chunk * H1;              // [chunk][E+1]
     const int tid = threadIdx.x;
     const long long q0 = (long long)blockIdx.x * chunk;
     const int nq = (int)min((long long)chunk, NI - q0);
-    for (int i = tid; i < nq * H1; i += 256) sdc[i] = dc[q0 * H1 + i];
+    for (int i = tid; i < nq * H1; i += 256) {
+        float v = dc[q0 * H1 + i];
+        for (int j = 1; j < ns; ++j) v += dc[(size_t)j * NI * H1 + q0 * H1 + i];
+        sdc[i] = v;
+    }
     for (int i = tid; i < nq * (E + 1); i += 256) {
         const int e = i / nq, ql = i - e * nq;
         const long long q = q0 + ql, bi = q / d;
@@ -485,6 +497,7 @@ struct BwdPlan {
     int tmax;          // template tile count
     int ksu;           // common K-step count when every hidden layer fills exactly `tmax` tiles, else 0
     int nwaves, nblocks, wpb;
+    int ns;            // node-range split of the fp32 kernels (small batches: fewer tiles than waves)
     size_t lds_bytes_for(int nacc, int waves) const { return (size_t)(a.scratch_off + waves * (nacc + 1) * tmax * 256) * sizeof(float); }
     long long ws_partials, ws_dc, ws_p0;   // byte offsets in the workspace
     long long ws_total;
@@ -520,18 +533,27 @@ static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan
     while (pl->wpb > 1 && pl->lds_bytes_for(nacc_max, pl->wpb) > 160 * 1024) pl->wpb >>= 1;
     if (pl->lds_bytes_for(nacc_max, pl->wpb) > 160 * 1024)
         return umnn_fail(UMNN_EUNSUPPORTED, "backward: weight images exceed 160 KiB of LDS");
+    // fewer tiles than waves (the reference's own training batches are 100 samples): share a tile's nodes among
+    // up to 32 waves; every work item keeps its own d_theta / dc partial, summed in a fixed order afterwards
+    pl->ns = 1;
+    {
+        const long long waves = (long long)umnn_num_cus() * pl->wpb;
+        if ((long long)a.ngroups * 2 <= waves) pl->ns = (int)(waves / a.ngroups > 32 ? 32 : waves / a.ngroups);
+        if (const char* ev = getenv("UMNN_BWD_NS")) { const int v = atoi(ev); if (v >= 1 && v <= 32) pl->ns = v; }
+    }
+    const long long items = (long long)a.ngroups * pl->ns;
     pl->nblocks = umnn_num_cus();
-    if ((long long)pl->nblocks * pl->wpb > (long long)a.ngroups)
-        pl->nblocks = (int)((a.ngroups + pl->wpb - 1) / pl->wpb);
+    if ((long long)pl->nblocks * pl->wpb > items) pl->nblocks = (int)((items + pl->wpb - 1) / pl->wpb);
     if (pl->nblocks < 1) pl->nblocks = 1;
     pl->nwaves = pl->nblocks * pl->wpb;
+    a.ns = 1;
     const int H1 = net->widths[1];
     pl->chunk0 = 256;
     while (pl->chunk0 > 16 && (size_t)pl->chunk0 * (H1 + E + 1) * sizeof(float) > 96 * 1024) pl->chunk0 /= 2;
     pl->nparts0 = (int)((a.NI + pl->chunk0 - 1) / pl->chunk0);
     long long o = 0;
     pl->ws_partials = o; o += (long long)pl->nwaves * a.n_params * 4; o = (o + 255) & ~255LL;
-    pl->ws_dc = o; o += a.NI * H1 * 4; o = (o + 255) & ~255LL;
+    pl->ws_dc = o; o += a.NI * H1 * 4 * pl->ns; o = (o + 255) & ~255LL;
     pl->ws_p0 = o; o += (long long)pl->nparts0 * H1 * (E + 1) * 4; o = (o + 255) & ~255LL;
     pl->ws_total = o;
     return 0;
@@ -608,6 +630,8 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
         else if (rc != UMNN_EUNSUPPORTED) return rc;
     }
     // ---- passes: the EDGE pass (with as many dW layers as its variant holds), then the remaining layers
+    const int ns_used = done ? 1 : (pl.ns > nb_steps + 1 ? nb_steps + 1 : pl.ns);
+    a.ns = ns_used;
     const int T = pl.tmax;
     const int nacc_main = (T <= 4) ? 3 : 0;
     const int nacc_rest = (T <= 4) ? 3 : 1;
@@ -634,13 +658,13 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
         const size_t sm = ((size_t)H1 * E + 64 * (H1 + 1)) * sizeof(float);
         const unsigned nb = (unsigned)((a.NI + 63) / 64);
         if (int rc = umnn_allow_lds((const void*)cc_bwd_dh_kernel, sm)) return rc;
-        hipLaunchKernelGGL(cc_bwd_dh_kernel, dim3(nb), dim3(256), sm, stream, a.dc, net->W[0], dh, a.NI, d, E, H1);
+        hipLaunchKernelGGL(cc_bwd_dh_kernel, dim3(nb), dim3(256), sm, stream, a.dc, net->W[0], dh, a.NI, d, E, H1, ns_used);
         umnn_note_launch("cc_bwd_dh");
     }
     if (dtheta) {
         const size_t sm = (size_t)pl.chunk0 * (H1 + E + 1) * sizeof(float);
         if (int rc = umnn_allow_lds((const void*)cc_bwd_dw0_kernel, sm)) return rc;
-        hipLaunchKernelGGL(cc_bwd_dw0_kernel, dim3(pl.nparts0), dim3(256), sm, stream, a.dc, h, p0, a.NI, d, E, H1, pl.chunk0);
+        hipLaunchKernelGGL(cc_bwd_dw0_kernel, dim3(pl.nparts0), dim3(256), sm, stream, a.dc, h, p0, a.NI, d, E, H1, pl.chunk0, ns_used);
         hipLaunchKernelGGL(cc_bwd_reduce_kernel, dim3((a.n_params + 255) / 256), dim3(256), 0, stream,
                            a.partials, pl.nwaves, a.n_params, p0, pl.nparts0, E, H1, a.poffW[0], a.poffb[0], dtheta);
         umnn_note_launch("cc_bwd_reduce");

@@ -22,6 +22,8 @@ struct BwdArgs {
     long long NI;
     int d, E, n;
     unsigned ngroups;               // tiles of 16 integrals
+    int ns;                         // node-range split: a tile's nodes are shared by ns work items (small batches);
+                                    // part j writes its dc partial at dc + j*NI*H1 (summed by the finishing kernels)
     int l_lo;                       // this pass accumulates dW for hidden layers l_lo .. l_lo+NACC-1
     int n_params;
     int scratch_off;                // float offset of the per-wave scratch region in LDS
