@@ -376,19 +376,17 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
 
 // d_h[b, e*d+i] = sum_f W1[f][1+e] dc[q][f]
 __global__ __launch_bounds__(256) void cc_bwd_dh_kernel(const float* __restrict__ dc, const float* __restrict__ W0,
-                                                        float* __restrict__ dh, long long NI, int d, int E, int H1, int ns) {
+                                                        float* __restrict__ dh, long long NI, int d, int E, int H1, int qpb) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sW = sm;                       // [H1][E]
-    float* sdc = sm + H1 * E;             // [64][H1+1]
+    float* sdc = sm + H1 * E;             // [qpb][H1+1], qpb = integrals per block (64, or 16 for small batches)
     const int tid = threadIdx.x;
     for (int i = tid; i < H1 * E; i += 256) { const int f = i / E, e = i - f * E; sW[i] = W0[f * (1 + E) + 1 + e]; }
-    const long long q0 = (long long)blockIdx.x * 64;
-    const int nq = (int)min((long long)64, NI - q0);
+    const long long q0 = (long long)blockIdx.x * qpb;
+    const int nq = (int)min((long long)qpb, NI - q0);
     for (int i = tid; i < nq * H1; i += 256) {
         const int ql = i / H1, f = i - ql * H1;
-        float v = dc[q0 * H1 + i];
-        for (int j = 1; j < ns; ++j) v += dc[(size_t)j * NI * H1 + q0 * H1 + i];      // node-split partials, fixed order
-        sdc[ql * (H1 + 1) + f] = v;
+        sdc[ql * (H1 + 1) + f] = dc[q0 * H1 + i];
     }
     __syncthreads();
     for (int o = tid; o < nq * E; o += 256) {
@@ -400,10 +398,19 @@ __global__ __launch_bounds__(256) void cc_bwd_dh_kernel(const float* __restrict_
     }
 }
 
+// node-split runs: dc[0][i] += dc[1][i] + ... + dc[ns-1][i], in that order (deterministic)
+__global__ __launch_bounds__(256) void cc_bwd_dcsum_kernel(float* __restrict__ dc, long long count, int ns) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    float v = dc[i];
+    for (int j = 1; j < ns; ++j) v += dc[(size_t)j * count + i];
+    dc[i] = v;
+}
+
 // partial[blk][f][e] = sum_{q in chunk} dc[q][f] * hext[q][e],  hext[q][E] = 1  (-> dW1[:,1:], db1)
 __global__ __launch_bounds__(256) void cc_bwd_dw0_kernel(const float* __restrict__ dc, const float* __restrict__ h,
                                                          float* __restrict__ partial, long long NI, int d, int E,
-                                                         int H1, int chunk, int ns) {
+                                                         int H1, int chunk) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sdc = sm;                          // [chunk][H1]
     float* sh = sm + chunk * H1;              // [chunk][E+1]
@@ -411,9 +418,7 @@ __global__ __launch_bounds__(256) void cc_bwd_dw0_kernel(const float* __restrict
     const long long q0 = (long long)blockIdx.x * chunk;
     const int nq = (int)min((long long)chunk, NI - q0);
     for (int i = tid; i < nq * H1; i += 256) {
-        float v = dc[q0 * H1 + i];
-        for (int j = 1; j < ns; ++j) v += dc[(size_t)j * NI * H1 + q0 * H1 + i];
-        sdc[i] = v;
+        sdc[i] = dc[q0 * H1 + i];
     }
     for (int i = tid; i < nq * (E + 1); i += 256) {
         const int e = i / nq, ql = i - e * nq;
@@ -430,27 +435,34 @@ __global__ __launch_bounds__(256) void cc_bwd_dw0_kernel(const float* __restrict
     }
 }
 
-// dtheta[i] = sum_w partials[w][i]  (+ first-layer slices from the dw0 partials)
+// dtheta[i] = sum_w partials[w][i]  (+ first-layer slices from the dw0 partials).  16 lanes per parameter: lane j sums
+// the slices j, j+16, ... , then the 16 partial sums are combined in a fixed butterfly order -- deterministic, and
+// enough threads in flight to hide the latency of a thousand-slice sum (small batches run many node-split waves).
 __global__ __launch_bounds__(256) void cc_bwd_reduce_kernel(const float* __restrict__ partials, int nparts, int n_params,
                                                             const float* __restrict__ p0, int nparts0, int E, int H1,
                                                             int poffW0, int poffb0, float* __restrict__ dtheta) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_params) return;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int j = threadIdx.x & 15;
+    const bool ok = i < n_params;
     float s = 0.f;
-    for (int w = 0; w < nparts; ++w) s += partials[(size_t)w * n_params + i];
-    // is i an entry of W0[:,1:] or b0 ?  those come from the dw0 partials
-    int o = -1;
-    if (i >= poffW0 && i < poffW0 + H1 * (1 + E)) {
-        const int f = (i - poffW0) / (1 + E), col = (i - poffW0) - f * (1 + E);
-        if (col >= 1) o = f * (E + 1) + (col - 1);
-    } else if (i >= poffb0 && i < poffb0 + H1) {
-        o = (i - poffb0) * (E + 1) + E;
+    if (ok) {
+        for (int w = j; w < nparts; w += 16) s += partials[(size_t)w * n_params + i];
+        // is i an entry of W0[:,1:] or b0 ?  those come from the dw0 partials
+        int o = -1;
+        if (i >= poffW0 && i < poffW0 + H1 * (1 + E)) {
+            const int f = (i - poffW0) / (1 + E), col = (i - poffW0) - f * (1 + E);
+            if (col >= 1) o = f * (E + 1) + (col - 1);
+        } else if (i >= poffb0 && i < poffb0 + H1) {
+            o = (i - poffb0) * (E + 1) + E;
+        }
+        if (o >= 0) {
+            const int nout = H1 * (E + 1);
+            for (int w = j; w < nparts0; w += 16) s += p0[(size_t)w * nout + o];
+        }
     }
-    if (o >= 0) {
-        const int nout = H1 * (E + 1);
-        for (int w = 0; w < nparts0; ++w) s += p0[(size_t)w * nout + o];
-    }
-    dtheta[i] = s;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+    if (ok && j == 0) dtheta[i] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -550,6 +562,7 @@ static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan
     const int H1 = net->widths[1];
     pl->chunk0 = 256;
     while (pl->chunk0 > 16 && (size_t)pl->chunk0 * (H1 + E + 1) * sizeof(float) > 96 * 1024) pl->chunk0 /= 2;
+    while (pl->chunk0 > 16 && a.NI / pl->chunk0 < 2LL * umnn_num_cus()) pl->chunk0 /= 2;     // small batches: more, smaller chunks
     pl->nparts0 = (int)((a.NI + pl->chunk0 - 1) / pl->chunk0);
     long long o = 0;
     pl->ws_partials = o; o += (long long)pl->nwaves * a.n_params * 4; o = (o + 255) & ~255LL;
@@ -623,6 +636,8 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
 
     // ---- bf16-split kernels (default) where the shape allows; otherwise / on request the fp32-MFMA kernels below
     bool done = false;
+    const int ns_used = pl.ns > nb_steps + 1 ? nb_steps + 1 : pl.ns;
+    a.ns = ns_used;
     if (bwd_precision() == UMNN_PRECISION_BF16X3) {
         int nw = 0;
         const int rc = umnn_launch_backward_bf16(a, net, pl.nblocks, &nw, stream);
@@ -630,8 +645,6 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
         else if (rc != UMNN_EUNSUPPORTED) return rc;
     }
     // ---- passes: the EDGE pass (with as many dW layers as its variant holds), then the remaining layers
-    const int ns_used = done ? 1 : (pl.ns > nb_steps + 1 ? nb_steps + 1 : pl.ns);
-    a.ns = ns_used;
     const int T = pl.tmax;
     const int nacc_main = (T <= 4) ? 3 : 0;
     const int nacc_rest = (T <= 4) ? 3 : 1;
@@ -654,18 +667,23 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
     }
 
     // ---- finishing kernels
+    if (ns_used > 1) {      // node-split partials of dc -> one sum, before anything reads dc
+        const long long count = a.NI * H1;
+        hipLaunchKernelGGL(cc_bwd_dcsum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, a.dc, count, ns_used);
+    }
     if (dh) {
-        const size_t sm = ((size_t)H1 * E + 64 * (H1 + 1)) * sizeof(float);
-        const unsigned nb = (unsigned)((a.NI + 63) / 64);
+        const int qpb = a.NI / 64 < 2LL * umnn_num_cus() ? 16 : 64;      // integrals per workgroup
+        const size_t sm = ((size_t)H1 * E + qpb * (H1 + 1)) * sizeof(float);
+        const unsigned nb = (unsigned)((a.NI + qpb - 1) / qpb);
         if (int rc = umnn_allow_lds((const void*)cc_bwd_dh_kernel, sm)) return rc;
-        hipLaunchKernelGGL(cc_bwd_dh_kernel, dim3(nb), dim3(256), sm, stream, a.dc, net->W[0], dh, a.NI, d, E, H1, ns_used);
+        hipLaunchKernelGGL(cc_bwd_dh_kernel, dim3(nb), dim3(256), sm, stream, a.dc, net->W[0], dh, a.NI, d, E, H1, qpb);
         umnn_note_launch("cc_bwd_dh");
     }
     if (dtheta) {
         const size_t sm = (size_t)pl.chunk0 * (H1 + E + 1) * sizeof(float);
         if (int rc = umnn_allow_lds((const void*)cc_bwd_dw0_kernel, sm)) return rc;
-        hipLaunchKernelGGL(cc_bwd_dw0_kernel, dim3(pl.nparts0), dim3(256), sm, stream, a.dc, h, p0, a.NI, d, E, H1, pl.chunk0, ns_used);
-        hipLaunchKernelGGL(cc_bwd_reduce_kernel, dim3((a.n_params + 255) / 256), dim3(256), 0, stream,
+        hipLaunchKernelGGL(cc_bwd_dw0_kernel, dim3(pl.nparts0), dim3(256), sm, stream, a.dc, h, p0, a.NI, d, E, H1, pl.chunk0);
+        hipLaunchKernelGGL(cc_bwd_reduce_kernel, dim3((a.n_params + 15) / 16), dim3(256), 0, stream,
                            a.partials, pl.nwaves, a.n_params, p0, pl.nparts0, E, H1, a.poffW[0], a.poffb[0], dtheta);
         umnn_note_launch("cc_bwd_reduce");
     }

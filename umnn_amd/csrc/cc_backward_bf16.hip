@@ -204,7 +204,10 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
     const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + wid;
     const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
 
-    for (unsigned grp = wave_global; grp < a.ngroups; grp += nwaves) {
+    const unsigned nsp = a.ns > 1 ? (unsigned)a.ns : 1u;       // node-range split (small batches), see BwdArgs::ns
+    for (unsigned item = wave_global; item < a.ngroups * nsp; item += nwaves) {
+        const unsigned grp = item / nsp, part = item - grp * nsp;
+        const int k_lo = (int)(((long long)part * (n + 1)) / nsp), k_hi = (int)(((long long)(part + 1) * (n + 1)) / nsp);
         const long long q = (long long)grp * 16 + p;
         const bool ok = q < a.NI;
         const long long qq = ok ? q : a.NI - 1;
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
         for (int t = 0; t < BT; ++t) dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         float fxv = 0.f, fx0v = 0.f, dfdt = 0.f;
 
-        for (int k = 0; k <= n; ++k) {
+        for (int k = k_lo; k < k_hi; ++k) {
             const float u = a.ccs[k] + 1.f;
             const float wk = a.ccw[k];
             const float tk = k == 0 ? xv : __fadd_rn(x0v, __fmul_rn(dxv, u) * 0.5f);
@@ -371,11 +374,11 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int f = feat_of(t, r, g);
-                    if (f < H1) a.dc[q * H1 + f] = dcs[t][r];
+                    if (f < H1) a.dc[(size_t)part * a.NI * H1 + q * H1 + f] = dcs[t][r];
                 }
             if (g == 0) {
-                if (a.dx) a.dx[q] = fmaf(gfxv, dfdt, fxv * gv);
-                if (a.dx0) a.dx0[q] = -fx0v * gv;
+                if (a.dx && k_lo == 0) a.dx[q] = fmaf(gfxv, dfdt, fxv * gv);
+                if (a.dx0 && k_hi == n + 1) a.dx0[q] = -fx0v * gv;
             }
         }
     }
@@ -453,9 +456,10 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
     const size_t lds_bytes = (size_t)off16 * sizeof(unsigned short);
     if (lds_bytes > 160 * 1024) return UMNN_EUNSUPPORTED;
     a.ngroups = (unsigned)((a.NI + 15) / 16);
+    const long long items = (long long)a.ngroups * (a.ns > 1 ? a.ns : 1);
     int nblocks = nblocks_max;
-    if ((long long)nblocks * UMNN_WAVES_PER_BLOCK > (long long)a.ngroups)
-        nblocks = (int)((a.ngroups + UMNN_WAVES_PER_BLOCK - 1) / UMNN_WAVES_PER_BLOCK);
+    if ((long long)nblocks * UMNN_WAVES_PER_BLOCK > items)
+        nblocks = (int)((items + UMNN_WAVES_PER_BLOCK - 1) / UMNN_WAVES_PER_BLOCK);
     if (nblocks < 1) nblocks = 1;
     *nwaves_out = nblocks * UMNN_WAVES_PER_BLOCK;
     const BwdBf16Variant* v = nullptr;
