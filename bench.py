@@ -93,8 +93,9 @@ def main():
                     help="eval: compute_ll forward (the headline metric). train: forward + backward + one flattened "
                          "RCCL gradient all-reduce + Adam step per step (reported as training samples/s)")
     ap.add_argument("--graph", action="store_true",
-                    help="eval only: replay the step as one captured hipGraph (umnn_amd.GraphedLL) -- for the launch-bound "
-                         "small workloads; the roofline record then comes from an eager pass after the timed region")
+                    help="replay the step as one captured hipGraph (umnn_amd.GraphedLL / GraphedTrainStep) -- for the "
+                         "launch-bound small workloads; the eval roofline record then comes from an eager pass after the "
+                         "timed region")
     ap.add_argument("--precision", default="", choices=["", "fp32", "bf16x3", "bf16x6"],
                     help="forward arithmetic (default: the library default, bf16x3)")
     args = ap.parse_args()
@@ -119,7 +120,7 @@ def main():
     if args.mode == "train":
         model.train()
         sharding.broadcast_parameters(model)
-        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, capturable=bool(args.graph))
 
         def step():
             opt.zero_grad(set_to_none=True)
@@ -129,6 +130,13 @@ def main():
             torch.nn.utils.clip_grad_value_(model.parameters(), 10.0)
             opt.step()
             return ll.detach(), z
+        if args.graph:      # the whole step (fwd, HIP bwd, all-reduce hook, clipping, Adam) as one replayed hipGraph
+            import umnn_amd
+            gstep = umnn_amd.GraphedTrainStep(model, opt, x, clip_value=10.0,
+                                              grad_hook=lambda mdl: sharding.allreduce_gradients(mdl, world))
+
+            def step():         # noqa: F811
+                return gstep().reshape(1), None
     else:
         def eager_step():
             with torch.no_grad():

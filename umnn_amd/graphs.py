@@ -34,3 +34,51 @@ class GraphedLL:
             self.context.copy_(context)
         self.graph.replay()
         return self.out
+
+
+class GraphedTrainStep:
+    """One optimisation step (``-compute_ll(x).mean()`` -> backward -> optional gradient hook / value clipping ->
+    ``optimizer.step()``) recorded as a single hipGraph and replayed per call.  For the launch-bound regime the
+    reference's own scripts train in (100 samples per step: ~280 short launches, the CPU cannot issue them as fast as
+    the GPU finishes them).  The optimizer must be capturable (e.g. ``torch.optim.Adam(..., capturable=True)``);
+    shapes are fixed at capture; as usual for whole-step capture, the warm-up iterations already update the model.
+
+        step = umnn_amd.GraphedTrainStep(model, opt, x_example)
+        for x in loader: loss = step(x)          # loss: 0-dim device tensor, overwritten by the next call
+    """
+
+    def __init__(self, model, optimizer, x_example, context=None, warmup=3, clip_value=None, grad_hook=None):
+        assert x_example.is_cuda, "hipGraph capture needs device tensors"
+        self.x = x_example.clone()
+        self.context = context.clone() if context is not None else None
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+
+        def one_step():
+            optimizer.zero_grad(set_to_none=True)
+            ll, _ = model.compute_ll(self.x, self.context) if self.context is not None else model.compute_ll(self.x)
+            loss = -ll.mean()
+            loss.backward()
+            if grad_hook is not None:
+                grad_hook(model)
+            if clip_value is not None:
+                torch.nn.utils.clip_grad_value_(params, clip_value)
+            optimizer.step()
+            return loss.detach()
+
+        side = torch.cuda.Stream(device=x_example.device)
+        side.wait_stream(torch.cuda.current_stream(x_example.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                one_step()
+        torch.cuda.current_stream(x_example.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = one_step()
+
+    def __call__(self, x=None, context=None):
+        if x is not None:
+            self.x.copy_(x)
+        if context is not None:
+            self.context.copy_(context)
+        self.graph.replay()
+        return self.loss
