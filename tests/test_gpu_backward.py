@@ -203,3 +203,51 @@ def test_graphed_train_step_matches_eager_training(dev):
     assert max(abs(a - b) for a, b in zip(losses_a[warm:], losses_b)) < 1e-5, (losses_a, losses_b)
     for (n, pa), (_, pb) in zip(model_a.named_parameters(), model_b.named_parameters()):
         assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6), n
+
+
+@pytest.mark.parametrize("hid", [[100, 50, 50], [72, 72], [120, 40, 40, 40]])
+def test_mixed_wide_nets_take_the_aten_backward_and_match_the_oracle(hid, dev, monkeypatch):
+    """Nets whose HIP backward only has the generic more-than-four-tile variants (they spill) are differentiated with
+    the materialised ATen chain on the GPU by default; UMNN_BWD_WIDE=hip still reaches the HIP kernels.  Both must match
+    the oracle's restatement of the reference backward."""
+    from umnn_amd import integral as I, IntegrandNetwork, _lib
+    from umnn_amd.nets import mlp_spec
+    torch.manual_seed(len(hid))
+    B, d, E, n = 9, 3, 4, 12
+    net = IntegrandNetwork(d, 1 + E, hid, 1).to(dev)
+    spec = mlp_spec(net)
+    lin = spec.linears
+    onet = O.Net([m.weight.detach().cpu().numpy() for m in lin], [m.bias.detach().cpu().numpy() for m in lin], O.LEAKY, O.ELU1)
+    x0 = torch.randn(B, d, device=dev) * 0.3
+    x = torch.randn(B, d, device=dev) * 2
+    h = torch.randn(B, E * d, device=dev)
+    g = torch.randn(B, d, device=dev)
+    ref = O.integrate_backward(onet, x0.cpu().numpy(), x.cpu().numpy(), h.cpu().numpy(), n, g.cpu().numpy())
+    ref_dh, ref_dtheta = ref[2], ref[5]
+    for mode in ("", "hip"):
+        monkeypatch.setenv("UMNN_BWD_WIDE", mode)
+        xr, hr = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
+        for p in net.parameters():
+            p.grad = None
+        F = I.ParallelNeuralIntegral.apply(x0, xr, net, I._flatten(net.parameters()), hr, n)
+        launches = _lib.lib().umnn_launch_count()
+        F.backward(g)
+        torch.cuda.synchronize()
+        # (autograd runs backward on its own thread: count library launches instead of asking path_taken())
+        assert (_lib.lib().umnn_launch_count() > launches) == (mode == "hip")
+        dtheta = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
+        assert np.abs(dtheta - ref_dtheta).max() <= 1e-4 * np.abs(ref_dtheta).max()
+        assert np.abs(hr.grad.cpu().numpy() - ref_dh).max() <= 1e-4 * np.abs(ref_dh).max()
+        assert U.rel_err(xr.grad.cpu().numpy(), O.integrand(onet, x.cpu().numpy(), h.cpu().numpy()) * g.cpu().numpy()) < 1e-4
+    # the (F, f_x) operator of the flow blocks: both routes agree with each other
+    outs = []
+    for mode in ("", "hip"):
+        monkeypatch.setenv("UMNN_BWD_WIDE", mode)
+        xr, hr = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
+        for p in net.parameters():
+            p.grad = None
+        F, fx = I.IntegralWithJacobian.apply(x0, xr, net, I._flatten(net.parameters()), hr, n)
+        (F * g).sum().add((torch.log(fx) * g.flip(0)).sum()).backward()
+        outs.append((xr.grad.clone(), hr.grad.clone(), torch.cat([p.grad.reshape(-1) for p in net.parameters()])))
+    for a, b in zip(*outs):
+        assert (a - b).abs().max() <= 2e-4 * b.abs().max()

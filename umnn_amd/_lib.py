@@ -54,6 +54,7 @@ SIGNATURES = {
                                              ctypes.POINTER(ctypes.c_float), _fp]),
     "umnn_set_forward_precision": (ctypes.c_int, [ctypes.c_int]),
     "umnn_get_forward_precision": (ctypes.c_int, []),
+    "umnn_cc_backward_kind": (ctypes.c_int, [ctypes.POINTER(MlpDesc), ctypes.c_int]),
     "umnn_set_backward_precision": (ctypes.c_int, [ctypes.c_int]),
     "umnn_get_backward_precision": (ctypes.c_int, []),
     "umnn_profile_enable": (ctypes.c_int, [ctypes.c_int]),

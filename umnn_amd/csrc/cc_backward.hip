@@ -588,6 +588,20 @@ static const BwdVariant* find_bwd(int tmax, int nacc, int edge, int ksu) {
 
 int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblocks_max, int* nwaves_out, hipStream_t stream);
 
+// Which kernel family umnn_cc_backward would use for this net: 1 = shape-exact kernels (compile-time tile counts),
+// 0 = generic kernels with at most four tiles per layer (runtime guards, ~2.5x slower), -1 = generic kernels with more
+// than four tiles -- those spill hundreds of registers per lane and are kept for completeness only: the Python host
+// routes such nets (mixed widths above 63) to the materialised ATen chain on the GPU instead.  < -1: error code.
+extern "C" int umnn_cc_backward_kind(const umnn_mlp* net, int E) {
+    MlpDev m;
+    int tmax = 0, ksu = 0;
+    if (int rc = umnn_prepare_mlp(net, E, &m, &tmax, &ksu)) return rc < -1 ? rc : -2;
+    const int T = pick_tmax_bwd(tmax);
+    const int ks = (ksu && tmax == T) ? ksu : 0;
+    if (ks && find_bwd(T, T <= 4 ? 3 : 0, 1, ks) && find_bwd(T, T <= 4 ? 3 : 0, 1, ks)->ksc) return 1;
+    return T <= 4 ? 0 : -1;
+}
+
 // arithmetic of the backward GEMMs: UMNN_PRECISION_FP32 or UMNN_PRECISION_BF16X3 (default)
 static int g_bwd_precision = -1;
 static int bwd_precision() {

@@ -21,6 +21,7 @@ Two execution paths, chosen per call, never silently:
     need device memory); ``path_taken()`` reports which path the last call used so tests can assert on it.
 """
 import ctypes
+import os
 import threading
 import warnings
 
@@ -98,6 +99,44 @@ def _use_hip(spec, x):
     if spec.linears[0].weight.device != x.device:
         raise RuntimeError("umnn_amd: integrand weights and inputs are on different devices")
     return True
+
+
+_bwd_kind = {}
+
+
+def _hip_backward_ok(spec, x, h):
+    """False for nets the HIP backward only covers with its register-spilling generic wide variants (mixed hidden
+    widths above 63, e.g. MNISTExperiment's 100-50-50-50-50: 687 ms per call at 256x784 against ~40 ms for the
+    materialised ATen chain on the same GPU).  ``UMNN_BWD_WIDE=hip`` forces the HIP kernels anyway."""
+    if os.environ.get("UMNN_BWD_WIDE", "") == "hip":
+        return True
+    E = h.shape[1] // x.shape[1]
+    key = (tuple((m.in_features, m.out_features) for m in spec.linears), E)
+    kind = _bwd_kind.get(key)
+    if kind is None:
+        desc, keep = _desc(spec)
+        kind = _bwd_kind[key] = _lib.lib().umnn_cc_backward_kind(ctypes.byref(desc), E)
+    return kind >= 0
+
+
+def aten_backward_jac(integrand, x0, x, h, gF, gfx, nb_steps):
+    """ATen counterpart of hip_backward for IntegralWithJacobian: the reference's quadrature VJP for the cotangent of F
+    plus ordinary autograd through f(x;h) for the cotangent of f_x -> (dx0, dx, dh, dtheta_flat)."""
+    dtheta, dh = aten_backward(integrand, x0, x, h, gF, nb_steps)
+    dh = dh.view(h.shape)
+    params = list(integrand.parameters())
+    xr, hr = x.detach().requires_grad_(True), h.detach().requires_grad_(True)
+    with torch.enable_grad():
+        fx = integrand(xr, hr)
+    dx = fx.detach() * gF
+    if gfx is not None:
+        grads = torch.autograd.grad(fx, [xr, hr] + params, gfx, allow_unused=True)
+        dx = dx + grads[0]
+        dh = dh + grads[1]
+        dtheta = dtheta + _flatten([g if g is not None else torch.zeros_like(p) for g, p in zip(grads[2:], params)])
+    with torch.no_grad():
+        dx0 = -integrand(x0, h) * gF
+    return dx0, dx, dh, dtheta
 
 
 def _shape(spec, x, h):
@@ -271,7 +310,7 @@ def integrate(x0, nb_steps, step_sizes, integrand, h, compute_grad=False, x_tot=
             return hip_forward(spec, x0, x, h, nb_steps, inv_f)[0]
         with torch.no_grad():
             return aten_forward(integrand, x0, x, h, nb_steps, inv_f)
-    if _use_hip(spec, x) and not inv_f:
+    if _use_hip(spec, x) and not inv_f and _hip_backward_ok(spec, x, h):
         _, _, dh, dtheta = hip_backward(spec, x0, x, h, x_tot, None, nb_steps, need=(False, False, True, True))
         return dtheta, dh
     return aten_backward(integrand, x0, x, h, x_tot, nb_steps, inv_f)
@@ -291,7 +330,7 @@ def _op_forward(ctx, x0, x, integrand, h, nb_steps, inv_f):
 def _op_backward(ctx, grad_output):
     x0, x, h = ctx.saved_tensors
     integrand, nb_steps, inv_f, spec = ctx.integrand, ctx.nb_steps, ctx.inv_f, ctx.spec
-    if _use_hip(spec, x) and not inv_f:
+    if _use_hip(spec, x) and not inv_f and _hip_backward_ok(spec, x, h):
         need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[4], ctx.needs_input_grad[3])
         dx0, dx, dh, dtheta = hip_backward(spec, x0, x, h, grad_output, None, nb_steps, need)
         return dx0, dx, dtheta, dh
@@ -335,7 +374,7 @@ class IntegralWithJacobian(torch.autograd.Function):
         spec = mlp_spec(integrand)
         if not _use_hip(spec, x):
             raise RuntimeError("IntegralWithJacobian needs an MLP integrand on a GPU")
-        ctx.spec, ctx.nb_steps = spec, nb_steps
+        ctx.spec, ctx.nb_steps, ctx.integrand = spec, nb_steps, integrand
         ctx.save_for_backward(x0.clone(), x.clone(), h)
         F, fx, _ = hip_forward(spec, x0, x, h, nb_steps, False)
         return F, fx
@@ -343,6 +382,9 @@ class IntegralWithJacobian(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gF, gfx):
         x0, x, h = ctx.saved_tensors
+        if not _hip_backward_ok(ctx.spec, x, h):
+            dx0, dx, dh, dtheta = aten_backward_jac(ctx.integrand, x0, x, h, gF, gfx, ctx.nb_steps)
+            return dx0, dx, None, dtheta, dh, None
         need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[4], ctx.needs_input_grad[3])
         dx0, dx, dh, dtheta = hip_backward(ctx.spec, x0, x, h, gF, gfx, ctx.nb_steps, need)
         return dx0, dx, None, dtheta, dh, None
