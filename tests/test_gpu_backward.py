@@ -251,3 +251,38 @@ def test_mixed_wide_nets_take_the_aten_backward_and_match_the_oracle(hid, dev, m
         outs.append((xr.grad.clone(), hr.grad.clone(), torch.cat([p.grad.reshape(-1) for p in net.parameters()])))
     for a, b in zip(*outs):
         assert (a - b).abs().max() <= 2e-4 * b.abs().max()
+
+
+def test_full_size_backward_properties_bsds300_shard(dev):
+    """BASELINE config C3 at one GPU's share (8192 x 63, n=100, 31-50^4-1), backward: (a) dh and dx of a random sample
+    of rows against the oracle (they depend on their own row only), (b) shard consistency: dh/dx of two half batches
+    concatenate bit-for-bit into the full batch's (the halves fall on tile boundaries) and their d_theta add up to the
+    full one, (c) linearity in the cotangent, (d) determinism."""
+    from umnn_amd import integral as I, IntegrandNetwork
+    from umnn_amd.nets import mlp_spec
+    torch.manual_seed(0)
+    B, d, E, n = 8192, 63, 30, 100
+    net = IntegrandNetwork(d, 1 + E, [50] * 4, 1)
+    lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    onet = O.Net([m.weight.detach().numpy() for m in lin], [m.bias.detach().numpy() for m in lin], O.LEAKY, O.ELU1)
+    net.to(dev)
+    spec = mlp_spec(net)
+    x, h, g = torch.randn(B, d), torch.randn(B, E * d), torch.randn(B, d)
+    xg, hg, gg = x.to(dev), h.to(dev), g.to(dev)
+    dx0, dx, dh, dth = I.hip_backward(spec, None, xg, hg, gg, None, n)
+    rows = np.random.RandomState(2).choice(B, 24, replace=False)
+    ref = O.integrate_backward(onet, np.zeros((24, d), np.float32), x.numpy()[rows], h.numpy()[rows], n, g.numpy()[rows])
+    assert U.rel_err(dx.cpu().numpy()[rows], ref[1]) < TOL
+    assert U.scaled_err(dh.cpu().numpy()[rows], ref[2]) < TOL
+    half = B // 2
+    a = I.hip_backward(spec, None, xg[:half].contiguous(), hg[:half].contiguous(), gg[:half].contiguous(), None, n)
+    b = I.hip_backward(spec, None, xg[half:].contiguous(), hg[half:].contiguous(), gg[half:].contiguous(), None, n)
+    assert torch.equal(torch.cat([a[1], b[1]]), dx) and torch.equal(torch.cat([a[2], b[2]]), dh)
+    assert float((a[3] + b[3] - dth).abs().max()) <= 2e-5 * float(dth.abs().max())
+    g2 = torch.randn(B, d, device=dev)
+    s1 = I.hip_backward(spec, None, xg, hg, g2, None, n)
+    s12 = I.hip_backward(spec, None, xg, hg, gg + g2, None, n)
+    assert float((s12[3] - dth - s1[3]).abs().max()) <= 2e-5 * float(s12[3].abs().max())
+    assert float((s12[2] - dh - s1[2]).abs().max()) <= 2e-5 * float(s12[2].abs().max())
+    again = I.hip_backward(spec, None, xg, hg, gg, None, n)
+    assert all(torch.equal(p, q) for p, q in zip(again[1:], (dx, dh, dth)))
