@@ -472,3 +472,37 @@ def test_graphed_compute_ll_replays_the_same_numbers(dev):
     assert torch.equal(out[0], ref1[0]) and torch.equal(out[1], ref1[1])
     out = g(x2)
     assert torch.equal(out[0], ref2[0]) and torch.equal(out[1], ref2[1])
+
+
+@pytest.mark.parametrize("hid,T", [([64, 64, 64], 5), ([70, 79, 64, 66], 5), ([90, 88, 95], 6), ([120, 112, 127], 8), ([100] * 4, 7)])
+def test_exact_wide_variants_against_oracle(hid, T, dev):
+    """Uniform tile counts above four (widths 64-127) run shape-exact bf16x3 variants (odd counts end in a half K-step
+    on the K=16 MFMA); checked against the oracle, on a ragged batch."""
+    import umnn_amd
+    from umnn_amd import integral as I, _lib
+    from umnn_amd.nets import MlpSpec
+    if umnn_amd.get_forward_precision() != "bf16x3":
+        pytest.skip("exact wide variants exist for bf16x3")
+    B, d, E, n = 21, 3, 6, 25
+    rng = np.random.RandomState(T * 7 + len(hid))
+    sizes = [1 + E] + hid + [1]
+    Ws = [(rng.randn(sizes[i + 1], sizes[i]) * (1.6 / np.sqrt(sizes[i]))).astype(np.float32) for i in range(len(sizes) - 1)]
+    bs = [(rng.randn(sizes[i + 1]) * 0.3).astype(np.float32) for i in range(len(sizes) - 1)]
+    lin = []
+    for W, b in zip(Ws, bs):
+        m = torch.nn.Linear(W.shape[1], W.shape[0])
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(W))
+            m.bias.copy_(torch.from_numpy(b))
+        lin.append(m.to(dev))
+    spec = MlpSpec(lin, _lib.ACT_LEAKY_RELU, _lib.OUT_ELU_PLUS_ONE)
+    net = O.Net(Ws, bs, O.LEAKY, O.ELU1)
+    x = (rng.randn(B, d) * 2).astype(np.float32)
+    x0 = (rng.randn(B, d) * 0.5).astype(np.float32)
+    h = rng.randn(B, E * d).astype(np.float32)
+    F, fx, fx0 = I.hip_forward(spec, t(x0, dev), t(x, dev), t(h, dev), n)
+    kname = _lib.lib().umnn_last_kernel_name().decode()
+    assert f"T={T}," in kname and "EXACT=1" in kname, kname
+    assert U.rel_err(F.cpu().numpy(), O.integrate_parallel(net, x0, x, h, n)) < TOL
+    assert U.rel_err(fx.cpu().numpy(), O.integrand(net, x, h)) < TOL
+    assert U.rel_err(fx0.cpu().numpy(), O.integrand(net, x0, h)) < TOL

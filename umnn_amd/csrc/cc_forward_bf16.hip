@@ -469,6 +469,7 @@ static const Bf16Variant kBf16Variants[] = {
     BF16_VARIANT(2, 2, 1, 0, 0), BF16_VARIANT(2, 2, 2, 0, 0), BF16_VARIANT(2, 3, 1, 0, 0), BF16_VARIANT(2, 3, 2, 0, 0),
     BF16_VARIANT(4, 2, 1, 0, 0), BF16_VARIANT(4, 2, 2, 0, 0), BF16_VARIANT(4, 3, 1, 0, 0), BF16_VARIANT(4, 3, 2, 0, 0),
     BF16_VARIANT(7, 2, 1, 1, 26), BF16_VARIANT(7, 2, 1, 1, 0),   // widths 96..111 (100-wide toy / MonotonicNN nets): 3 K-steps + a half one
+    BF16_VARIANT(5, 2, 1, 1, 0), BF16_VARIANT(6, 2, 1, 1, 0), BF16_VARIANT(8, 2, 1, 1, 0),   // widths 64..79, 80..95, 112..127
     BF16_VARIANT(8, 2, 1, 0, 0), BF16_VARIANT(8, 2, 2, 0, 0),   // (8 tiles x 3 parts does not fit the register file: fp32 kernels instead)
 };
 
@@ -480,12 +481,13 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
     int tmax = 0;
     for (int l = 1; l <= L; ++l) tmax = a.m.t_out[l] > tmax ? a.m.t_out[l] : tmax;
     int T = tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8;
-    bool seven = nparts == 2;              // every hidden layer 7 tiles wide: the exact variant with a half K-step
-    for (int l = 1; l <= L; ++l) seven = seven && a.m.t_out[l] == 7;
-    if (seven && (P == 1 || !getenv("UMNN_FWD_P"))) { T = 7; P = 1; } else seven = false;   // (no two-tile variant at this width)
-    if (seven && !getenv("UMNN_FWD_NS")) {
-        // 147 KB of images = one workgroup per CU = one wave per SIMD: split the node range only as far as that fills
-        const long long tiles16 = (a.NI + 15) / 16, slots = (long long)umnn_num_cus() * 4;
+    // every hidden layer the same tile count above four: exact single-tile variants, odd counts with a half K-step
+    int wide = (nparts == 2 && tmax >= 5) ? tmax : 0;
+    for (int l = 1; l <= L && wide; ++l) if (a.m.t_out[l] != wide) wide = 0;
+    if (wide && (P == 1 || !getenv("UMNN_FWD_P"))) { T = wide; P = 1; } else wide = 0;    // (no two-tile variant at these widths)
+    if (wide && !getenv("UMNN_FWD_NS")) {
+        // images this large leave one or two workgroups per CU: split the node range only as far as that fills the SIMDs
+        const long long tiles16 = (a.NI + 15) / 16, slots = (long long)umnn_num_cus() * 4 * (wide >= 7 ? 1 : 2);
         ns = tiles16 * 4 <= slots ? 4 : tiles16 * 2 <= slots ? 2 : 1;
         if (ns > nb_steps + 1) ns = 1;
     }
@@ -493,8 +495,8 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
     args.f = a;
     int off16 = 0;
     for (int l = 1; l <= L; ++l) {
-        args.pl.half_in[l] = seven ? 1 : 0;
-        args.pl.ks32[l] = seven ? 3 : (a.m.t_out[l] + 1) / 2;
+        args.pl.half_in[l] = wide ? (wide & 1) : 0;
+        args.pl.ks32[l] = wide ? wide / 2 : (a.m.t_out[l] + 1) / 2;
     }
     for (int l = 1; l < L; ++l) {
         args.pl.off16[l] = off16;
