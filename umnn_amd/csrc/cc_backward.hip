@@ -475,12 +475,33 @@ static const BwdVariant kBwdVariants[] = {
     BWD_VARIANT(4, 3, 1, 13), BWD_VARIANT(4, 3, 0, 13),     // exact: every hidden layer 48..51 wide (UCI / VAE nets)
     BWD_VARIANT(2, 3, 1, 0), BWD_VARIANT(2, 3, 0, 0),
     BWD_VARIANT(4, 3, 1, 0), BWD_VARIANT(4, 3, 0, 0),
+    BWD_VARIANT(5, 2, 1, 17), BWD_VARIANT(5, 3, 0, 17),     // exact: every hidden layer 64 wide
     BWD_VARIANT(7, 0, 1, 26), BWD_VARIANT(7, 1, 0, 26),   // exact: every hidden layer 100 wide (toy flows, MonotonicNN): no spills
     BWD_VARIANT(7, 0, 1, 0), BWD_VARIANT(7, 1, 0, 0),
     BWD_VARIANT(8, 0, 1, 0), BWD_VARIANT(8, 1, 0, 0),
 };
 
-static int pick_tmax_bwd(int tmax) { return tmax <= 2 ? 2 : tmax <= 4 ? 4 : tmax <= 7 ? 7 : 8; }
+static const BwdVariant* find_bwd(int tmax, int nacc, int edge, int ksu) {
+    for (int exact = 1; exact >= 0; --exact)
+        for (const BwdVariant& v : kBwdVariants)
+            if (v.tmax == tmax && v.nacc == nacc && v.edge == edge && (exact ? (v.ksc && v.ksc == ksu) : !v.ksc)) return &v;
+    return nullptr;
+}
+// template tile count: the net's own when a shape-exact family exists for it, else the next generic bucket
+static int pick_tmax_bwd(int tmax, int ksu) {
+    if (ksu)
+        for (const BwdVariant& v : kBwdVariants)
+            if (v.ksc == ksu && v.tmax == tmax) return tmax;
+    return tmax <= 2 ? 2 : tmax <= 4 ? 4 : tmax <= 7 ? 7 : 8;
+}
+// dW layers a pass can hold: the largest NACC instantiated for (T, edge), preferring the shape-exact family
+static int best_nacc(int T, int edge, int ksu) {
+    for (int exact = 1; exact >= 0; --exact)
+        for (int n = 3; n >= 0; --n)
+            for (const BwdVariant& v : kBwdVariants)
+                if (v.tmax == T && v.nacc == n && v.edge == edge && (exact ? (v.ksc && v.ksc == ksu) : !v.ksc)) return n;
+    return -1;
+}
 
 // row stride for the row-major image: >= cols, minimising bank conflicts of both fragment shapes
 // (forward: 16 rows x 2 adjacent cols per half-wave; backward: 2 adjacent rows x 16 cols)
@@ -521,7 +542,7 @@ static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan
     if (int rc = umnn_prepare_mlp(net, E, &pl->a.m, &tmax, &ksu)) return rc;
     BwdArgs& a = pl->a;
     const int L = a.m.n_linear - 1;
-    pl->tmax = pick_tmax_bwd(tmax);
+    pl->tmax = pick_tmax_bwd(tmax, ksu);
     pl->ksu = (ksu && tmax == pl->tmax) ? ksu : 0;
     int off = 0;
     for (int l = 1; l < L; ++l) {
@@ -540,7 +561,8 @@ static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan
     a.NI = B * (long long)d; a.d = d; a.E = E;
     a.ngroups = (unsigned)((a.NI + 15) / 16);
     // waves per workgroup: as many (4, 2, 1) as leave room for the wave-private transpose tiles
-    const int nacc_max = pl->tmax <= 4 ? 3 : 1;
+    const int nm = best_nacc(pl->tmax, 1, pl->ksu), nr = best_nacc(pl->tmax, 0, pl->ksu);
+    const int nacc_max = nm > nr ? nm : nr;
     pl->wpb = 4;
     while (pl->wpb > 1 && pl->lds_bytes_for(nacc_max, pl->wpb) > 160 * 1024) pl->wpb >>= 1;
     if (pl->lds_bytes_for(nacc_max, pl->wpb) > 160 * 1024)
@@ -579,12 +601,6 @@ extern "C" long long umnn_cc_backward_workspace_bytes(const umnn_mlp* net, long 
     return pl.ws_total;
 }
 
-static const BwdVariant* find_bwd(int tmax, int nacc, int edge, int ksu) {
-    for (int exact = 1; exact >= 0; --exact)
-        for (const BwdVariant& v : kBwdVariants)
-            if (v.tmax == tmax && v.nacc == nacc && v.edge == edge && (exact ? (v.ksc && v.ksc == ksu) : !v.ksc)) return &v;
-    return nullptr;
-}
 
 int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblocks_max, int* nwaves_out, hipStream_t stream);
 
@@ -596,9 +612,10 @@ extern "C" int umnn_cc_backward_kind(const umnn_mlp* net, int E) {
     MlpDev m;
     int tmax = 0, ksu = 0;
     if (int rc = umnn_prepare_mlp(net, E, &m, &tmax, &ksu)) return rc < -1 ? rc : -2;
-    const int T = pick_tmax_bwd(tmax);
+    const int T = pick_tmax_bwd(tmax, ksu);
     const int ks = (ksu && tmax == T) ? ksu : 0;
-    if (ks && find_bwd(T, T <= 4 ? 3 : 0, 1, ks) && find_bwd(T, T <= 4 ? 3 : 0, 1, ks)->ksc) return 1;
+    const int nm = best_nacc(T, 1, ks);
+    if (ks && nm >= 0 && find_bwd(T, nm, 1, ks)->ksc) return 1;
     return T <= 4 ? 0 : -1;
 }
 
@@ -660,8 +677,8 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
     }
     // ---- passes: the EDGE pass (with as many dW layers as its variant holds), then the remaining layers
     const int T = pl.tmax;
-    const int nacc_main = (T <= 4) ? 3 : 0;
-    const int nacc_rest = (T <= 4) ? 3 : 1;
+    const int nacc_main = best_nacc(T, 1, pl.ksu), nacc_rest = best_nacc(T, 0, pl.ksu);
+    if (nacc_main < 0 || nacc_rest < 1) return umnn_fail(UMNN_EUNSUPPORTED, "backward: no kernel variant for this width");
     int l_next = 1;
     for (int pass = 0; !done && (pass == 0 || l_next < L); ++pass) {
         const int nacc = pass == 0 ? nacc_main : nacc_rest;
