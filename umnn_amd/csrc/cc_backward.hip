@@ -476,7 +476,7 @@ static const BwdVariant kBwdVariants[] = {
     BWD_VARIANT(2, 3, 1, 0), BWD_VARIANT(2, 3, 0, 0),
     BWD_VARIANT(4, 3, 1, 0), BWD_VARIANT(4, 3, 0, 0),
     BWD_VARIANT(5, 2, 1, 17), BWD_VARIANT(5, 3, 0, 17),     // exact: every hidden layer 64 wide
-    BWD_VARIANT(7, 0, 1, 26), BWD_VARIANT(7, 1, 0, 26),   // exact: every hidden layer 100 wide (toy flows, MonotonicNN): no spills
+    BWD_VARIANT(7, 1, 1, 26), BWD_VARIANT(7, 0, 1, 26), BWD_VARIANT(7, 1, 0, 26),   // exact: every hidden layer 100 wide (toy flows, MonotonicNN): no spills
     BWD_VARIANT(7, 0, 1, 0), BWD_VARIANT(7, 1, 0, 0),
     BWD_VARIANT(8, 0, 1, 0), BWD_VARIANT(8, 1, 0, 0),
 };
