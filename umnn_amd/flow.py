@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import integral as _I
-from .integral import NeuralIntegral, ParallelNeuralIntegral, IntegralWithJacobian, _flatten
+from .integral import NeuralIntegral, ParallelNeuralIntegral, IntegralWithJacobian, IntegralWithJacobianParams, _flatten  # noqa: F401
 from .made import MADE, ConditionnalMADE
 from .nets import ELUPlus, IntegrandNetwork, compute_lipschitz_linear, mlp_spec  # noqa: F401  (re-exported)
 from .quadrature import compute_cc_weights
@@ -100,12 +100,11 @@ class UMNNMAF(nn.Module):
             if no_graph and x0 is None:
                 z, log_jac, _, _ = _I.hip_flow_block(spec, x, h, self.scaling, self.nb_steps, reverse_z, log_jac_in)
                 return z, log_jac
-            x0 = x0.to(x.device) if x0 is not None else torch.zeros_like(x)
+            x0 = x0.to(x.device) if x0 is not None else None      # None = lower limit 0 inside the kernels
             if no_graph:
                 F, fx, _ = _I.hip_forward(spec, x0, x, h, self.nb_steps)
             else:
-                F, fx = IntegralWithJacobian.apply(x0, x, integrand, _flatten(integrand.parameters()), h,
-                                                   self.nb_steps)
+                F, fx = IntegralWithJacobianParams.apply(x0, x, integrand, h, self.nb_steps, *integrand.parameters())
         else:
             x0 = x0.to(x.device) if x0 is not None else torch.zeros_like(x)
             if no_graph:

@@ -293,6 +293,48 @@ def aten_backward(integrand, x0, x, h, g, nb_steps, inv_f=False):
     return (_flatten(g_params) if params else None), g_h
 
 
+class IntegralWithJacobianParams(torch.autograd.Function):
+    """IntegralWithJacobian with the integrand's parameters passed one by one instead of as one flat tensor: no
+    ``torch.cat`` in the forward and no cat-backward (a narrow + copy per parameter) in the backward -- the gradients are
+    views into the kernel's flat d_theta.  Internal to the flow blocks; the public operators keep the reference's
+    ``flat_params`` signature."""
+
+    @staticmethod
+    def forward(ctx, x0, x, integrand, h, nb_steps, *params):
+        spec = mlp_spec(integrand)
+        if not _use_hip(spec, x):
+            raise RuntimeError("IntegralWithJacobianParams needs an MLP integrand on a GPU")
+        ctx.spec, ctx.nb_steps, ctx.integrand = spec, nb_steps, integrand
+        ctx.shapes = [p.shape for p in params]
+        ctx.x0_none = x0 is None                    # lower limit 0: no tensor to save, clone or differentiate
+        if ctx.x0_none:
+            ctx.save_for_backward(x.clone(), h)
+        else:
+            ctx.save_for_backward(x0.clone(), x.clone(), h)
+        F, fx, _ = hip_forward(spec, x0, x, h, nb_steps, False)
+        return F, fx
+
+    @staticmethod
+    def backward(ctx, gF, gfx):
+        if ctx.x0_none:
+            (x, h), x0 = ctx.saved_tensors, None
+        else:
+            x0, x, h = ctx.saved_tensors
+        if not _hip_backward_ok(ctx.spec, x, h):
+            dx0, dx, dh, dtheta = aten_backward_jac(ctx.integrand, torch.zeros_like(x) if x0 is None else x0, x, h, gF, gfx,
+                                                    ctx.nb_steps)
+        else:
+            need = (ctx.needs_input_grad[0] and x0 is not None, ctx.needs_input_grad[1], ctx.needs_input_grad[3],
+                    any(ctx.needs_input_grad[5:]))
+            dx0, dx, dh, dtheta = hip_backward(ctx.spec, x0, x, h, gF, gfx, ctx.nb_steps, need)
+        grads, o = [], 0
+        for shp, needed in zip(ctx.shapes, ctx.needs_input_grad[5:]):
+            n = int(torch.Size(shp).numel())
+            grads.append(dtheta[o:o + n].view(shp) if (needed and dtheta is not None) else None)
+            o += n
+        return (None if ctx.x0_none else dx0, dx, None, dh, None, *grads)
+
+
 # ----------------------------------------------------------------------------------------------
 # reference-shaped public API
 # ----------------------------------------------------------------------------------------------
