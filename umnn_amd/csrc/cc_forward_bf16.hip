@@ -473,6 +473,8 @@ static const Bf16Variant kBf16Variants[] = {
     BF16_VARIANT(8, 2, 1, 0, 0), BF16_VARIANT(8, 2, 2, 0, 0),   // (8 tiles x 3 parts does not fit the register file: fp32 kernels instead)
 };
 
+static int pad_env_min_tiles() { static const int v = [] { const char* e = getenv("UMNN_FWD_PAD_MIN"); return e ? atoi(e) : 1; }(); return v; }
+
 // Returns 0 and launches, UMNN_EUNSUPPORTED (without setting the error text's prefix) if the shape does not fit
 // this kernel family (caller then uses the fp32-MFMA kernels), or another error code.
 int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps,
@@ -508,6 +510,17 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
     for (int l = 1; l <= L; ++l) {
         exact = exact && a.m.t_out[l] == T;
         if (a.m.ks_in[l] != nrl) nrl = 0;
+    }
+    // Mixed or narrow widths up to 63: zero-pad every layer to four tiles (the staged images carry the zeros) and run
+    // the shape-exact kernels -- the padded MFMAs cost less than the runtime guards of the generic variants
+    // (UMNN_FWD_PAD=0 keeps the generic ones).
+    static const int pad_env = [] { const char* e = getenv("UMNN_FWD_PAD"); return e ? atoi(e) : 1; }();
+    if (!exact && !wide && nparts == 2 && tmax <= 4 && tmax >= pad_env_min_tiles() && pad_env) {
+        T = 4; exact = 1; nrl = 0;
+        for (int l = 1; l <= L; ++l) { args.f.m.t_out[l] = 4; args.pl.ks32[l] = 2; }
+        off16 = 0;
+        for (int l = 1; l < L; ++l) { args.pl.off16[l] = off16; off16 += 4 * 2 * nparts * 512; }
+        args.f.m.lds_off[L] = (((off16 + 1) / 2) + 3) & ~3;
     }
     static const int pipe_env = [] { const char* e = getenv("UMNN_FWD_PIPE"); return e ? atoi(e) : 1; }();
     const bool want_pipe = pipe_env != 0 && L >= 2;
