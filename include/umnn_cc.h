@@ -140,8 +140,8 @@ int umnn_cc_forward_timed(const umnn_mlp* net, const float* x0, const float* x, 
 int umnn_set_forward_precision(int mode);
 int umnn_get_forward_precision(void);
 /* Same for the backward kernels: UMNN_PRECISION_FP32 or UMNN_PRECISION_BF16X3 (default; env UMNN_BWD_PRECISION =
- * fp32 | bf16x3).  The bf16 kernels cover nets whose hidden layers are all 48..62 wide with <= 3 hidden->hidden
- * layers; other shapes always run the fp32 kernels. */
+ * fp32 | bf16x3).  The bf16 kernels cover nets with 2..4 hidden layers, each 32..63 wide (narrower layers of
+ * such a net are zero-padded to four 16-feature tiles); other shapes always run the fp32 kernels. */
 /* Which kernel family umnn_cc_backward would run for this net: 1 shape-exact kernels, 0 generic kernels with at most four
  * 16-feature tiles per layer, -1 generic kernels with more tiles (mixed widths above 63: they spill registers and are
  * ~100x slower -- the shipped host code sends such nets to the materialised ATen chain on the GPU), < -1 error. */

@@ -428,11 +428,12 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
 typedef void (*bwd_bf16_kernel_t)(const BwdBf16Args);
 struct BwdBf16Variant { int lh, edge, nrl; bwd_bf16_kernel_t fn; const char* name; };
 #define BWD_BF16_VARIANT(LHH, E, NR) { LHH, E, NR, cc_bwd_bf16_kernel<LHH, (E) != 0, NR>, "cc_bwd_bf16<L=" #LHH ",EDGE=" #E ",LIVE=" #NR ">" }
-// Only the 13-live-register shape (hidden widths 48..51) is instantiated: the general 16-register variant needs
-// more than the 512-entry register file once MFMA results stay in VGPRs (and hipcc 7.2 crashes on it with
-// -amdgpu-mfma-vgpr-form); widths 52..62 use the fp32 kernels.
+// LIVE=13: every hidden layer 48..51 wide (dead registers cost no VALU).  LIVE=0 (all 16 registers): every other net of
+// three or four tiles per layer, i.e. hidden widths 32..63 in any combination -- narrower layers are zero-padded to four
+// tiles by the staged images (fits the register file since the dW operands became K=16 fragments; 4 spills at L=4).
 static const BwdBf16Variant kBwdBf16Variants[] = {
     BWD_BF16_VARIANT(4, 1, 13), BWD_BF16_VARIANT(3, 1, 13), BWD_BF16_VARIANT(2, 1, 13),
+    BWD_BF16_VARIANT(4, 1, 0), BWD_BF16_VARIANT(3, 1, 0), BWD_BF16_VARIANT(2, 1, 0),
 };
 
 // Plans and launches the main backward pass with the bf16 kernels.  Returns UMNN_EUNSUPPORTED when the shape is
@@ -444,12 +445,14 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
     BwdArgs& a = args.b;
     const int L = a.m.n_linear - 1;
     if (L < 2 || L - 1 > 3) return UMNN_EUNSUPPORTED;
-    int nrl = a.m.ks_in[1];
+    int nrl = a.m.ks_in[1], tmax = 0;
     for (int l = 1; l <= L; ++l) {
-        if (a.m.t_out[l] != BT) return UMNN_EUNSUPPORTED;
+        if (a.m.t_out[l] > BT) return UMNN_EUNSUPPORTED;
+        tmax = a.m.t_out[l] > tmax ? a.m.t_out[l] : tmax;
         if (a.m.ks_in[l] != nrl) nrl = 0;
     }
-    if (nrl != 13) return UMNN_EUNSUPPORTED;
+    if (tmax < 3) return UMNN_EUNSUPPORTED;        // one or two tiles per layer: the fp32 kernels waste less
+    if (nrl != 13) nrl = 0;
     int off16 = 0;
     for (int l = 1; l < L; ++l) { args.off_fwd[l] = off16; off16 += BT * BKS * NPF * FRAG; }
     for (int l = 1; l < L; ++l) { args.off_tr[l] = off16; off16 += BT * BKS * NPB * FRAG; }
