@@ -39,7 +39,8 @@ __device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks
         const float* __restrict__ b = m.b[l];
         unsigned short* img = lds16 + off16[l];
         const int total = to * ks * 512;
-        for (int idx = tid; idx < total; idx += nthreads) {
+#pragma unroll 8
+        for (int idx = tid; idx < total; idx += nthreads) {      // (unrolled: the weight loads of 8 iterations in flight)
             const int j = idx & 7, ln = (idx >> 3) & 63, ts = idx >> 9;
             const int s = ts % ks, t = ts / ks;
             const int fo = fout_of(t, ln & 15);
@@ -200,18 +201,32 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 for (int pt = 0; pt < P; ++pt) c[pt][t] = init;
             }
             const int t1 = EXACT ? TMAX : m.t_out[1];
-            for (int se = 0; se < (E + 3) / 4; ++se) {
-                const int e = 4 * se + g;
-                float hv[P];
+            // eight K-steps (32 embedding entries) at a time: all their h and W1 loads are issued before the first
+            // MFMA needs one -- one memory round trip per chunk instead of one per step (h comes from HBM)
+            const int nse = (E + 3) / 4;
+            for (int se0 = 0; se0 < nse; se0 += 8) {
+                float hv[P][8], Av[TMAX][8];
 #pragma unroll
-                for (int pt = 0; pt < P; ++pt) hv[pt] = e < E ? hb[pt][(long long)e * d] : 0.f;
+                for (int j = 0; j < 8; ++j) {
+                    const int e = 4 * (se0 + j) + g;
+                    const bool in = se0 + j < nse && e < E;
 #pragma unroll
-                for (int t = 0; t < TMAX; ++t) {
-                    if (EXACT || t < t1) {
+                    for (int pt = 0; pt < P; ++pt) hv[pt][j] = in ? hb[pt][(long long)e * d] : 0.f;
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) {
                         const int fo = fout_of(t, p);
-                        const float A = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
+                        Av[t][j] = (in && (EXACT || t < t1) && fo < H1) ? W0[fo * (1 + E) + 1 + e] : 0.f;
+                    }
+                }
 #pragma unroll
-                        for (int pt = 0; pt < P; ++pt) c[pt][t] = mfma16(A, hv[pt], c[pt][t]);
+                for (int j = 0; j < 8; ++j) {
+                    if (se0 + j < nse) {
+#pragma unroll
+                        for (int t = 0; t < TMAX; ++t)
+                            if (EXACT || t < t1) {
+#pragma unroll
+                                for (int pt = 0; pt < P; ++pt) c[pt][t] = mfma16(Av[t][j], hv[pt][j], c[pt][t]);
+                            }
                     }
                 }
             }
