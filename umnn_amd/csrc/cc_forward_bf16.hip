@@ -19,6 +19,7 @@
 // 2s+1 -- again the accumulators of one layer ARE (after activation, splitting and packing) the B operands of the
 // next, with no cross-lane movement.  Weight fragments are pre-split and pre-permuted into LDS: fragment (tile t', K-step s, part)
 // is 64 lanes x 8 bf16 = 1 KiB, read with one ds_read_b128 per lane.
+#include <type_traits>
 #include <utility>
 #include "cc_bf16.h"
 #include "cc_fwd_shared.h"
@@ -103,30 +104,14 @@ struct FwdBf16Args {
 // tile B's layer l-1 output, and vice versa.  Every MFMA is followed by its slice of that work and a scheduling fence.
 // The weight fragments of a layer stay in registers for both tiles (LDS is read once per layer, during the second
 // tile's section, into registers whose last use has passed).
+// The VALU is the scarce unit here (3.9 vector instructions per MFMA, the matrix pipe 56 % busy), so the remainder
+// a - bf16(a) of the split is taken on the matrix pipe as well: one extra MFMA per tile with C = a, B = the freshly packed
+// leading pieces and A = a 0/-1 selection fragment returns the exact fp32 remainders of 16 features x 16 points, which
+// replaces shift / and / subtract on the VALU (5 -> 2 vector instructions per register pair, +3 MFMAs per section).
 template <int... I, class F>
 __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
     (f(std::integral_constant<int, I>{}), ...);
 }
-// sub-step SUB (0: activation, 1: leading bf16 piece + remainder, 2: second piece) of register pair J of a point
-// tile: z0, z1 are the raw pre-activations of registers 2J, 2J+1 (HAS1: the second one is live); a0, a1 carry the
-// pair between sub-steps; the packed pieces land in dword J%4 of bf[J/4][piece].
-template <int J, int SUB, bool HAS1>
-__device__ __forceinline__ void pack_step(float z0, float z1, float slope, float& a0, float& a1, u32x4 (&bf)[2][2]) {
-    if constexpr (SUB == 0) {
-        a0 = hidden_act_f(z0, slope);
-        a1 = HAS1 ? hidden_act_f(z1, slope) : 0.f;
-    } else if constexpr (SUB == 1) {
-        const bf16x2 h = __builtin_convertvector(f32x2{a0, a1}, bf16x2);
-        const unsigned bits = __builtin_bit_cast(unsigned, h);
-        bf[J / 4][0][J % 4] = bits;
-        a0 -= __uint_as_float(bits << 16);
-        a1 -= __uint_as_float(bits & 0xffff0000u);
-    } else {
-        const bf16x2 h = __builtin_convertvector(f32x2{a0, a1}, bf16x2);
-        bf[J / 4][1][J % 4] = __builtin_bit_cast(unsigned, h);
-    }
-}
-
 // EXACT: every hidden layer fills exactly TMAX tiles, so tile / K-step counts are compile-time constants and the
 // wave-uniform guards (and the accumulator copies they force at every basic-block boundary) disappear.
 // NRL (EXACT only): live registers per lane = ceil((H+1)/4) for the common hidden width H; 0 = all 4*TMAX.
@@ -234,11 +219,10 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
 
         if constexpr (PIPE) {
             static_assert(TMAX == 4 && EXACT && NPARTS == 2 && P == 2, "pipelined loop: 4 tiles, 2 pieces, 2 point tiles");
-            constexpr int NPAIR = (NLIVE + 1) / 2;
             constexpr int NSLOT = 24;                               // MFMAs of one point tile in one layer
-            static_assert(3 * NPAIR <= NSLOT, "one sub-step per MFMA slot");
+            constexpr int NFULL = NLIVE / 4;                        // tiles with all four registers live
+            static_assert(NLIVE % 4 == 0 || (NLIVE % 4 == 1 && NFULL == 3), "pipelined loop: 13 or 16 live registers");
             using Slots = std::make_integer_sequence<int, NSLOT>;
-            float pa0[NPAIR], pa1[NPAIR];                           // a register pair between its packing sub-steps
             u32x4 wf[4][2][2];                                      // [tile][K-step][piece] of the layer in flight
             u32x4 bf[2][2][2];                                      // [point tile][K-step][piece]
 #pragma unroll
@@ -247,6 +231,17 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2) bf[pt][ks][k2] = u32x4{0u, 0u, 0u, 0u};
+            // 0/-1 selection fragments: row rho of an output tile picks k-slot 8*(rho>>2) + (rho&3) (even tile of the
+            // K-step) or + 4 (odd tile) -- the slot in which lane group rho>>2 packed that very feature
+            u32x4 sel[2];
+            {
+                const unsigned rho = lane & 15, slot = rho & 3;
+                const unsigned v = ((unsigned)(lane >> 4) == (rho >> 2)) ? (0xBF80u << (16 * (slot & 1))) : 0u;   // bf16(-1)
+                sel[0] = u32x4{slot < 2 ? v : 0u, slot < 2 ? 0u : v, 0u, 0u};
+                sel[1] = u32x4{0u, 0u, slot < 2 ? v : 0u, slot < 2 ? 0u : v};
+            }
+            float rem_a = 0.f;                                      // the single live register of tile 3 (13-register shape)
+            unsigned rem_hi = 0u;
             auto frag = [&](int l, int t, int ks, int k2) {
                 return *reinterpret_cast<const u32x4*>(lds16 + args.pl.off16[l] + lane * 8 + ((t * 2 + ks) * 2 + k2) * 512);
             };
@@ -272,11 +267,48 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 if constexpr (term == 1) wf[t][ks][0] = frag(lnext, t, ks, 0);
                 if constexpr (term == 2) wf[t][ks][1] = frag(lnext, t, ks, 1);
             };
-            auto pack_slot = [&](auto ic, const f32x4 (&z)[4], u32x4 (&bfout)[2][2]) {
+            // The packing work of one point tile, in place on its raw pre-activations z[4], one slice per MFMA slot so that
+            // (almost) every slice fits the two-instruction issue shadow of the slot's MFMA:
+            //   act(t,r)  register r of tile t:  z <- LeakyReLU(z)   (FIRST: z = w1x*t_k + c first)         2-3 VALU
+            //   hi(t)     leading pieces of tile t packed into bf[t/2][0], then  z[t] <- z[t] - bf16(z[t])  on the matrix
+            //             pipe                                                                       2 VALU + 1 MFMA
+            //   lo(t)     second pieces packed into bf[t/2][1] (two slots after hi(t): the MFMA has landed)    2 VALU
+            // slots   tile 0: act 0-3, hi 4, lo 10     tile 1: act 5-8, hi 9, lo 16     tile 2: act 11-14, hi 15, lo 20
+            //         tile 3: act 17-20, hi 21, lo 23  -- or, with one live register, split on the VALU in slots 17, 18
+            auto pack_slot = [&](auto ic, auto first, f32x4 (&z)[4], u32x4 (&bfout)[2][2], float tkv, const f32x4 (&cv)[TMAX]) {
                 constexpr int i = decltype(ic)::value;
-                if constexpr (i < 3 * NPAIR) {
-                    constexpr int j = i / 3, sub = i % 3;
-                    pack_step<j, sub, (2 * j + 1 < NLIVE)>(z[j / 2][2 * (j % 2)], z[j / 2][2 * (j % 2) + 1], slope, pa0[j], pa1[j], bfout);
+                constexpr bool FIRST = decltype(first)::value;
+                constexpr int t_act = i <= 3 ? 0 : (i >= 5 && i <= 8) ? 1 : (i >= 11 && i <= 14) ? 2 : (NFULL == 4 && i >= 17 && i <= 20) ? 3 : -1;
+                constexpr int r_act = t_act == 0 ? i : t_act == 1 ? i - 5 : t_act == 2 ? i - 11 : i - 17;
+                constexpr int t_hi = i == 4 ? 0 : i == 9 ? 1 : i == 15 ? 2 : (NFULL == 4 && i == 21) ? 3 : -1;
+                constexpr int t_lo = i == 10 ? 0 : i == 16 ? 1 : i == 20 ? 2 : (NFULL == 4 && i == 23) ? 3 : -1;
+                if constexpr (t_act >= 0) {
+                    if constexpr (FIRST) z[t_act][r_act] = fmaf(w1x[t_act][r_act], tkv, cv[t_act][r_act]);
+                    z[t_act][r_act] = hidden_act_f(z[t_act][r_act], slope);
+                }
+                if constexpr (t_hi >= 0) {
+                    const bf16x2 h0 = __builtin_convertvector(f32x2{z[t_hi][0], z[t_hi][1]}, bf16x2);
+                    const bf16x2 h1 = __builtin_convertvector(f32x2{z[t_hi][2], z[t_hi][3]}, bf16x2);
+                    bfout[t_hi / 2][0][2 * (t_hi % 2)] = __builtin_bit_cast(unsigned, h0);
+                    bfout[t_hi / 2][0][2 * (t_hi % 2) + 1] = __builtin_bit_cast(unsigned, h1);
+                    z[t_hi] = mfma_bf16(sel[t_hi % 2], bfout[t_hi / 2][0], z[t_hi]);          // exact remainders
+                }
+                if constexpr (t_lo >= 0) {
+                    const bf16x2 l0 = __builtin_convertvector(f32x2{z[t_lo][0], z[t_lo][1]}, bf16x2);
+                    const bf16x2 l1 = __builtin_convertvector(f32x2{z[t_lo][2], z[t_lo][3]}, bf16x2);
+                    bfout[t_lo / 2][1][2 * (t_lo % 2)] = __builtin_bit_cast(unsigned, l0);
+                    bfout[t_lo / 2][1][2 * (t_lo % 2) + 1] = __builtin_bit_cast(unsigned, l1);
+                }
+                if constexpr (NFULL == 3 && i == 17) {           // tile 3 has one live register: split it on the VALU
+                    if constexpr (FIRST) z[3][0] = fmaf(w1x[3][0], tkv, cv[3][0]);
+                    rem_a = hidden_act_f(z[3][0], slope);
+                    const bf16x2 h = __builtin_convertvector(f32x2{rem_a, 0.f}, bf16x2);
+                    rem_hi = __builtin_bit_cast(unsigned, h);
+                    bfout[1][0][2] = rem_hi;
+                }
+                if constexpr (NFULL == 3 && i == 18) {
+                    const bf16x2 l = __builtin_convertvector(f32x2{rem_a - __uint_as_float(rem_hi << 16), 0.f}, bf16x2);
+                    bfout[1][1][2] = __builtin_bit_cast(unsigned, l);
                 }
             };
 
@@ -287,37 +319,30 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) tk[pt] = k == 0 ? xv[pt] : __fadd_rn(x0v[pt], __fmul_rn(dxv[pt], u) * 0.5f);
                 f32x4 acc0[4], acc1[4];
+                constexpr std::true_type kFirst{};
+                constexpr std::false_type kLater{};
                 // first tile: layer 1 on the VALU, nothing to hide behind yet
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc0[t][r] = 4 * t + r < NLIVE ? fmaf(w1x[t][r], tk[0], c[0][t][r]) : 0.f;
-                static_for(Slots{}, [&](auto ic) { pack_slot(ic, acc0, bf[0]); });
+                static_for(Slots{}, [&](auto ic) { pack_slot(ic, kFirst, acc0, bf[0], tk[0], c[0]); });
                 __builtin_amdgcn_sched_barrier(0);
                 // section A of layer 1: first tile on the matrix pipe, second tile's layer 1 + packing on the VALU
                 static_for(Slots{}, [&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     mfma_slot(ic, bf[0], acc0);
-                    if constexpr (i < 3 * NPAIR && i % 3 == 0) {
-                        constexpr int j = i / 3, t = j / 2, r = 2 * (j % 2);
-                        acc1[t][r] = fmaf(w1x[t][r], tk[1], c[1][t][r]);
-                        acc1[t][r + 1] = 4 * t + r + 1 < NLIVE ? fmaf(w1x[t][r + 1], tk[1], c[1][t][r + 1]) : 0.f;
-                    }
-                    pack_slot(ic, acc1, bf[1]);
+                    pack_slot(ic, kFirst, acc1, bf[1], tk[1], c[1]);
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 for (int l = 1; l + 1 < L; ++l) {
                     // section B of layer l: second tile on the matrix pipe, first tile's output packed for layer l+1
                     static_for(Slots{}, [&](auto ic) {
                         mfma_slot(ic, bf[1], acc1);
-                        pack_slot(ic, acc0, bf[0]);
+                        pack_slot(ic, kLater, acc0, bf[0], 0.f, c[0]);
                         reload_slot(ic, l + 1);
                         __builtin_amdgcn_sched_barrier(0);
                     });
                     // section A of layer l+1
                     static_for(Slots{}, [&](auto ic) {
                         mfma_slot(ic, bf[0], acc0);
-                        pack_slot(ic, acc1, bf[1]);
+                        pack_slot(ic, kLater, acc1, bf[1], 0.f, c[1]);
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 }
