@@ -215,11 +215,13 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
         # FLOPs the matrix pipe actually executes per launch in the bf16-split kernels: per hidden->hidden layer
         # ceil((H_out+1)/16) output tiles x ceil(ceil((H_in+1)/16)/2) K-steps x 3|6 cross terms of 16x16x32 MFMAs
-        # (2*16*16*32 FLOPs each) per 16 integrals and node
+        # (2*16*16*32 FLOPs each) per 16 integrals and node (+ the split-remainder MFMAs of the pipelined loop)
         executed = None
         if on_bf16:
             hd, terms = cfg["hd"], (3 if "PARTS=2" in kernel_name else 6)
             per_tile_node = sum(-(-(hd[i + 1] + 1) // 16) * -(-(-(-(hd[i] + 1) // 16)) // 2) * terms for i in range(len(hd) - 1))
+            if "PIPE" in kernel_name:     # + one remainder MFMA per fully live tile and split (see cc_forward_bf16.hip)
+                per_tile_node += sum((-(-(hd[i] + 1) // 4)) // 4 for i in range(len(hd) - 1))
             tiles = -(-cfg["rows"] * cfg["d"] // 16)
             executed = per_tile_node * 16384.0 * tiles * (cfg["n"] + 1) / max(avg_kernel_ms, 1e-9) / 1e9
         dtype = {"fp32": "f32", "bf16x3": "f32 via bf16x3-split MFMA (fp32 accumulate)",
