@@ -310,3 +310,38 @@ def test_exact_wide_backward_families_match_the_oracle(hid, dev):
     assert U.rel_err(dx0.cpu().numpy(), ref[0]) < TOL and U.rel_err(dx.cpu().numpy(), ref[1]) < TOL
     assert U.scaled_err(dh.cpu().numpy(), ref[2]) < TOL
     assert U.scaled_err(dth.cpu().numpy(), ref[5]) < TOL
+
+
+def _dirty_the_gpu(dev, trial):
+    """Run unrelated work so that stale registers / LDS contents differ between two otherwise identical calls."""
+    from umnn_amd import integral as I, IntegrandNetwork
+    from umnn_amd.nets import mlp_spec
+    junk = torch.randn(2048, 2048, device=dev) * (10.0 ** trial)
+    (junk @ junk).sum().item()
+    if trial % 2:
+        big = IntegrandNetwork(7, 31, [50] * 4, 1).to(dev)
+        I.hip_forward(mlp_spec(big), None, torch.randn(2000, 7, device=dev) * 50, torch.randn(2000, 210, device=dev) * 50, 30)
+
+
+@pytest.mark.parametrize("hid,B,d,E,n", [([50, 50, 50], 100, 3, 8, 20), ([50] * 4, 300, 6, 30, 100), ([40, 40], 64, 5, 4, 30),
+                                         ([100] * 3, 40, 2, 2, 25), ([64, 64], 50, 3, 4, 20)])
+def test_results_do_not_depend_on_what_ran_before(hid, B, d, E, n, dev):
+    """Every kernel must initialise what it reads: the same forward / backward call, repeated after unrelated kernels
+    have left other data in registers and LDS, returns the same bits (this caught an experimental split variant whose
+    three-hidden-layer instantiation read stale state)."""
+    from umnn_amd import integral as I, IntegrandNetwork
+    from umnn_amd.nets import mlp_spec
+    torch.manual_seed(3)
+    net = IntegrandNetwork(d, 1 + E, hid, 1).to(dev)
+    spec = mlp_spec(net)
+    x, h, g, gf = (torch.randn(B, d, device=dev), torch.randn(B, E * d, device=dev), torch.randn(B, d, device=dev),
+                   torch.randn(B, d, device=dev))
+    ref_b = I.hip_backward(spec, None, x, h, g, gf, n)
+    ref_f = I.hip_forward(spec, None, x, h, n)
+    for trial in range(4):
+        _dirty_the_gpu(dev, trial)
+        out_b = I.hip_backward(spec, None, x, h, g, gf, n)
+        _dirty_the_gpu(dev, trial + 1)
+        out_f = I.hip_forward(spec, None, x, h, n)
+        assert all(torch.equal(a, b) for a, b in zip(out_b, ref_b))
+        assert all(torch.equal(a, b) for a, b in zip(out_f, ref_f))

@@ -506,3 +506,27 @@ def test_exact_wide_variants_against_oracle(hid, T, dev):
     assert U.rel_err(F.cpu().numpy(), O.integrate_parallel(net, x0, x, h, n)) < TOL
     assert U.rel_err(fx.cpu().numpy(), O.integrand(net, x, h)) < TOL
     assert U.rel_err(fx0.cpu().numpy(), O.integrand(net, x0, h)) < TOL
+
+
+@pytest.mark.parametrize("hid", [[50] * 4, [56, 60, 63], [50, 50], [40, 33, 48]])
+def test_pipelined_forward_does_not_depend_on_what_ran_before(hid, dev):
+    """The two-tile pipelined loop (matrix-pipe remainders, persistent fragment registers) at a size that selects it:
+    identical bits whatever ran before."""
+    import umnn_amd
+    from umnn_amd import integral as I, IntegrandNetwork, _lib
+    from umnn_amd.nets import mlp_spec
+    if umnn_amd.get_forward_precision() != "bf16x3":
+        pytest.skip("the pipelined loop exists for bf16x3 only")
+    torch.manual_seed(8)
+    net = IntegrandNetwork(8, 31, hid, 1).to(dev)
+    spec = mlp_spec(net)
+    x, h = torch.randn(5000, 8, device=dev), torch.randn(5000, 240, device=dev)
+    ref = I.hip_forward(spec, None, x, h, 40)
+    assert "PIPE" in _lib.lib().umnn_last_kernel_name().decode()
+    for trial in range(4):
+        junk = torch.randn(3000, 3000, device=dev) * (10.0 ** trial)
+        (junk @ junk).sum().item()
+        wide = IntegrandNetwork(3, 11, [100] * 4, 1).to(dev)
+        I.hip_forward(mlp_spec(wide), None, torch.randn(3000, 3, device=dev) * 30, torch.randn(3000, 30, device=dev) * 30, 20)
+        out = I.hip_forward(spec, None, x, h, 40)
+        assert all(torch.equal(a, b) for a, b in zip(out, ref))
