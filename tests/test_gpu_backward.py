@@ -324,7 +324,8 @@ def _dirty_the_gpu(dev, trial):
 
 
 @pytest.mark.parametrize("hid,B,d,E,n", [([50, 50, 50], 100, 3, 8, 20), ([50] * 4, 300, 6, 30, 100), ([40, 40], 64, 5, 4, 30),
-                                         ([100] * 3, 40, 2, 2, 25), ([64, 64], 50, 3, 4, 20)])
+                                         ([100] * 3, 40, 2, 2, 25), ([64, 64], 50, 3, 4, 20), ([40, 36, 44], 90, 4, 6, 20),
+                                         ([56, 60, 52, 63], 70, 5, 8, 30), ([20, 20], 33, 3, 4, 15)])
 def test_results_do_not_depend_on_what_ran_before(hid, B, d, E, n, dev):
     """Every kernel must initialise what it reads: the same forward / backward call, repeated after unrelated kernels
     have left other data in registers and LDS, returns the same bits (this caught an experimental split variant whose
