@@ -530,3 +530,47 @@ def test_pipelined_forward_does_not_depend_on_what_ran_before(hid, dev):
         I.hip_forward(mlp_spec(wide), None, torch.randn(3000, 3, device=dev) * 30, torch.randn(3000, 30, device=dev) * 30, 20)
         out = I.hip_forward(spec, None, x, h, 40)
         assert all(torch.equal(a, b) for a, b in zip(out, ref))
+
+
+@pytest.mark.parametrize("hid,relu,sigmoid,inv_f,n", [
+    ([50, 50, 50, 50], False, False, False, 100),
+    ([50, 50], False, False, True, 33),
+    ([56, 60, 63], True, True, False, 20),
+    ([40, 33, 48], False, False, False, 25),
+    ([50, 50, 50, 50, 50, 50], False, False, False, 12),
+])
+def test_x32_layout_against_oracle(hid, relu, sigmoid, inv_f, n, dev, monkeypatch):
+    """The 32x32x16 large-batch layout (two groups of 32 integrals per wave), forced at a small ragged batch, against the
+    oracle -- and bit-stable across contexts."""
+    import umnn_amd
+    from umnn_amd import integral as I, _lib
+    from umnn_amd.nets import MlpSpec
+    if umnn_amd.get_forward_precision() != "bf16x3":
+        pytest.skip("the 32x32 layout exists for bf16x3")
+    monkeypatch.setenv("UMNN_FWD_X32", os.environ.get("UMNN_TEST_X32", "1"))
+    B, d, E = 41, 5, 7                       # 205 integrals: three full work items and a ragged fourth
+    rng = np.random.RandomState(len(hid) * 19 + n)
+    sizes = [1 + E] + hid + [1]
+    Ws = [(rng.randn(sizes[i + 1], sizes[i]) * (1.6 / np.sqrt(sizes[i]))).astype(np.float32) for i in range(len(sizes) - 1)]
+    bs = [(rng.randn(sizes[i + 1]) * 0.3).astype(np.float32) for i in range(len(sizes) - 1)]
+    lin = []
+    for W, b in zip(Ws, bs):
+        m = torch.nn.Linear(W.shape[1], W.shape[0])
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(W))
+            m.bias.copy_(torch.from_numpy(b))
+        lin.append(m.to(dev))
+    spec = MlpSpec(lin, _lib.ACT_RELU if relu else _lib.ACT_LEAKY_RELU, _lib.OUT_SIGMOID if sigmoid else _lib.OUT_ELU_PLUS_ONE)
+    net = O.Net(Ws, bs, O.RELU if relu else O.LEAKY, O.SIGMOID if sigmoid else O.ELU1)
+    x = (rng.randn(B, d) * 2).astype(np.float32)
+    x0 = (rng.randn(B, d) * 0.5).astype(np.float32)
+    h = rng.randn(B, E * d).astype(np.float32)
+    F, fx, fx0 = I.hip_forward(spec, t(x0, dev), t(x, dev), t(h, dev), n, inv_f=inv_f)
+    assert "x32" in _lib.lib().umnn_last_kernel_name().decode() or os.environ.get("UMNN_TEST_X32") == "0"
+    assert U.rel_err(F.cpu().numpy(), O.integrate_parallel(net, x0, x, h, n, inv_f=inv_f)) < TOL
+    assert U.rel_err(fx.cpu().numpy(), O.integrand(net, x, h)) < TOL
+    assert U.rel_err(fx0.cpu().numpy(), O.integrand(net, x0, h)) < TOL
+    junk = torch.randn(2048, 2048, device=dev) * 1e3
+    (junk @ junk).sum().item()
+    F2, fx2, fx02 = I.hip_forward(spec, t(x0, dev), t(x, dev), t(h, dev), n, inv_f=inv_f)
+    assert torch.equal(F, F2) and torch.equal(fx, fx2) and torch.equal(fx0, fx02)

@@ -235,6 +235,7 @@ static const FwdVariant kFwdVariants[] = {
 };
 
 int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps, hipStream_t stream);
+int umnn_launch_forward_x32(FwdArgs& a, const umnn_mlp* net, int nb_steps, hipStream_t stream);
 
 // forward arithmetic: 0 = exact fp32 MFMA, 1 = bf16 split with 3 cross terms, 2 = bf16 split with 6 cross terms
 static int g_fwd_precision = -1;
@@ -291,6 +292,11 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
     // bf16-split kernels (default): hidden GEMMs on the bf16 matrix cores; falls through to fp32 MFMA when the
     // shape does not fit them (a single hidden layer has no hidden->hidden GEMM at all)
     const int prec = fwd_precision();
+    if (prec == UMNN_PRECISION_BF16X3 && !getenv("UMNN_FWD_P") && !getenv("UMNN_FWD_NS")) {
+        // large batches of nets up to 63 wide: the 32x32x16 layout (two groups of 32 integrals per wave)
+        const int rc = umnn_launch_forward_x32(a, net, nb_steps, stream);
+        if (rc != UMNN_EUNSUPPORTED) return rc;
+    }
     if (prec != UMNN_PRECISION_FP32 && a.m.n_linear - 1 >= 2) {
         a.ns = ns;
         const int rc = umnn_launch_forward_bf16(a, net, prec == UMNN_PRECISION_BF16X3 ? 2 : 3, P, ns, nb_steps, stream);
