@@ -574,3 +574,29 @@ def test_x32_layout_against_oracle(hid, relu, sigmoid, inv_f, n, dev, monkeypatc
     (junk @ junk).sum().item()
     F2, fx2, fx02 = I.hip_forward(spec, t(x0, dev), t(x, dev), t(h, dev), n, inv_f=inv_f)
     assert torch.equal(F, F2) and torch.equal(fx, fx2) and torch.equal(fx0, fx02)
+
+
+def test_mnist_width_d784_against_oracle(dev):
+    """BASELINE config C4's dimension count: d = 784 (one embedding row is 784 floats apart from the next), MNIST
+    integrand 31-100-50-50-50-50-1, a ragged handful of samples, forward and backward against the oracle."""
+    from umnn_amd import integral as I, IntegrandNetwork
+    from umnn_amd.nets import mlp_spec
+    torch.manual_seed(12)
+    B, d, E, n = 3, 784, 30, 50
+    net = IntegrandNetwork(d, 1 + E, [100, 50, 50, 50, 50], 1)
+    lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    onet = O.Net([m.weight.detach().numpy() for m in lin], [m.bias.detach().numpy() for m in lin], O.LEAKY, O.ELU1)
+    net.to(dev)
+    spec = mlp_spec(net)
+    x, h, g = torch.randn(B, d), torch.randn(B, E * d), torch.randn(B, d)
+    F, fx, _ = I.hip_forward(spec, None, x.to(dev), h.to(dev), n)
+    x0 = np.zeros((B, d), np.float32)
+    assert U.rel_err(F.cpu().numpy(), O.integrate_parallel(onet, x0, x.numpy(), h.numpy(), n)) < TOL
+    assert U.rel_err(fx.cpu().numpy(), O.integrand(onet, x.numpy(), h.numpy())) < TOL
+    xr, hr = x.to(dev).requires_grad_(True), h.to(dev).requires_grad_(True)
+    Fa = I.ParallelNeuralIntegral.apply(torch.zeros_like(xr), xr, net, I._flatten(net.parameters()), hr, n)
+    Fa.backward(g.to(dev))
+    ref = O.integrate_backward(onet, x0, x.numpy(), h.numpy(), n, g.numpy())
+    assert U.scaled_err(hr.grad.cpu().numpy(), ref[2]) < TOL
+    dth = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
+    assert U.scaled_err(dth, ref[5]) < TOL
