@@ -1,17 +1,19 @@
 #!/usr/bin/env python
 """Headline benchmark: UMNN-MAF log-density evals/s (BASELINE.json metric) on MI355X.
 
-  python bench.py [--gpus N --steps K --warmup W --workload bsds300|power|toy]
+  python bench.py [--gpus N --steps K --warmup W --workload bsds300|power|toy|vae --mode eval|train]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
 A step = one ``UMNNMAFFlow.compute_ll`` pass (MADE conditioner + fused HIP quadrature, all flow blocks) over one
 synthetic batch already resident in HBM.  Default workload: BASELINE config C3 -- BSDS300-shaped (d=63), 8192 rows
 per GPU (65536 rows sharded over 8 GPUs), n_steps=100, 5 blocks, MADE [512,512], E=30, integrand 31-50^4-1, fp32.
-Weak scaling: the per-GPU shard is fixed; no collective on the forward path.  One JSON line on rank 0.
+Weak scaling: the per-GPU shard is fixed; no collective on the forward path.  One JSON line on rank 0.  At N=1 the
+line also carries ``full_batch_n1`` (the un-sharded 65536-row C3 batch on one GPU: the strong-scaling anchor of the
+N=8 point), ``exact_fp32`` (same workload, reference arithmetic) and ``cpu_baseline`` (both reference solvers).
 """
 import argparse
-import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -23,16 +25,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: nb_flow, d, hidden_embedding, hidden_derivative, E, n_steps, rows per GPU
-    "bsds300": dict(nb_flow=5, d=63, he=[512, 512], hd=[50] * 4, E=30, n=100, rows=8192,
+    # name: nb_flow, d, hidden_embedding, hidden_derivative, E, n_steps, rows per GPU (, cond_in)
+    "bsds300": dict(nb_flow=5, d=63, he=[512, 512], hd=[50] * 4, E=30, n=100, rows=8192, cond=0,
                     desc="C3 BSDS300-shaped UMNN-MAF compute_ll: d=63, 8192 rows/GPU (65536 over 8), n_steps=100"),
-    "power": dict(nb_flow=5, d=6, he=[512, 512], hd=[50] * 4, E=30, n=100, rows=10000,
+    "power": dict(nb_flow=5, d=6, he=[512, 512], hd=[50] * 4, E=30, n=100, rows=10000, cond=0,
                   desc="C2 POWER-shaped UMNN-MAF compute_ll: d=6, batch 10000, n_steps=100"),
-    "toy": dict(nb_flow=1, d=2, he=[100] * 4, hd=[100] * 4, E=10, n=50, rows=4096,
+    "toy": dict(nb_flow=1, d=2, he=[100] * 4, hd=[100] * 4, E=10, n=50, rows=4096, cond=0,
                 desc="C1 2-moons UMNN-MAF compute_ll: d=2, batch 4096, n_steps=50"),
+    "vae": dict(nb_flow=4, d=64, he=[512, 512], hd=[50] * 4, E=30, n=50, rows=1024, cond=320,
+                desc="C4 TrainVaeFlow prior flow: d=64 latent, cond_in=320, 4 blocks, n_steps=50, 1024 rows/GPU"),
 }
+FULL_BATCH_ROWS = 65536            # BASELINE config C3's un-sharded batch
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 2:1-sparse figure is never used)
+# sources that define the dominant forward kernel: profiles/hbm_traffic.json is only trusted while their hash matches
+TRAFFIC_SOURCES = ["umnn_amd/csrc/cc_forward_bf16.hip", "umnn_amd/csrc/cc_fwd_shared.h", "umnn_amd/csrc/cc_common.h",
+                   "umnn_amd/csrc/cc_bf16.h", "umnn_amd/csrc/cc_forward.hip"]
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for rel in TRAFFIC_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def build_model(cfg, device, seed=0):
@@ -40,13 +56,22 @@ def build_model(cfg, device, seed=0):
     torch.manual_seed(seed)
     m = umnn_amd.UMNNMAFFlow(nb_flow=cfg["nb_flow"], nb_in=cfg["d"], hidden_derivative=cfg["hd"],
                              hidden_embedding=cfg["he"], embedding_s=cfg["E"], nb_steps=cfg["n"],
-                             solver="CCParallel")
+                             solver="CCParallel", cond_in=cfg.get("cond", 0))
     return m.to(device).eval()
 
 
-def cpu_baseline(cfg, model, budget_s=20.0):
-    """Time the torch port of the reference's ParallelNeuralIntegral-based compute_ll on the host cores, on a
-    bounded sample of the same workload (chunks of 128 rows; the un-chunked node axis would need terabytes)."""
+def make_inputs(cfg, rows, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(rows, cfg["d"], generator=g).to(device)
+    ctx = torch.randn(rows, cfg["cond"], generator=g).to(device) if cfg.get("cond", 0) else None
+    return x, ctx
+
+
+def cpu_baseline(cfg, model, budget_s=26.0):
+    """Time the torch port of the reference's compute_ll with BOTH of its quadrature solvers -- the materialised
+    ``ParallelNeuralIntegral`` (ParallelNeuralIntegral.py:37-65) and the node-by-node ``NeuralIntegral``
+    (NeuralIntegral.py:37-66) -- on the host cores, on a bounded sample of the same workload (row chunks; the un-chunked
+    node axis of the parallel solver would need terabytes).  ``value`` is the FASTER solver."""
     from oracle import torch_port as TP
     ncpu = os.cpu_count() or 1
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
@@ -54,31 +79,69 @@ def cpu_baseline(cfg, model, budget_s=20.0):
     chunk = 128 if cfg["d"] > 8 else 1024
     torch.manual_seed(123)
     x = torch.randn(chunk, cfg["d"])
+    ctx = torch.randn(chunk, cfg["cond"]) if cfg.get("cond", 0) else None
+    solvers = {}
+    old_threads = torch.get_num_threads()
     with torch.no_grad():
-        # torch's default (all cores) is pathological on many-core hosts for these skinny GEMMs: give the CPU
-        # its best thread count among a few candidates, then spend the budget at that setting
-        best = (float("inf"), 1)
-        for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
-            torch.set_num_threads(th)
-            TP.flow_compute_ll(blocks, x, cfg["n"])             # warm-up at this setting
-            t0 = time.perf_counter()
-            TP.flow_compute_ll(blocks, x, cfg["n"])
-            dt = time.perf_counter() - t0
-            if dt < best[0]:
-                best = (dt, th)
-            if dt > 4 * best[0]:
-                break
-        one, threads = best
-        torch.set_num_threads(threads)
-        reps = max(1, min(8, int(budget_s / max(one, 1e-3))))
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            TP.flow_compute_ll(blocks, x, cfg["n"])
-        dt = time.perf_counter() - t0
-    return {"value": chunk * reps / dt, "unit": "evals/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x {chunk}-row chunks of the same flow through oracle/torch_port.py "
-                      f"(reference ParallelNeuralIntegral algorithm, torch CPU, {threads} threads)",
-            "integrals_per_s": chunk * reps * cfg["d"] * cfg["nb_flow"] / dt}
+        for name, solver, share in (("parallel", "CCParallel", 0.6), ("sequential", "CC", 0.4)):
+            run = lambda: TP.flow_compute_ll(blocks, x, cfg["n"], solver=solver, context=ctx)      # noqa: E731
+            # torch's default (all cores) is pathological on many-core hosts for these skinny GEMMs: give the CPU its
+            # best thread count among a few candidates, then spend the rest of this solver's budget at that setting
+            t_start = time.perf_counter()
+            best = (float("inf"), 1)
+            for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+                torch.set_num_threads(th)
+                run()                                               # warm-up at this setting
+                t0 = time.perf_counter()
+                run()
+                dt = time.perf_counter() - t0
+                if dt < best[0]:
+                    best = (dt, th)
+                if dt > 1.5 * best[0] or time.perf_counter() - t_start > 0.6 * share * budget_s:
+                    break
+            one, threads = best
+            torch.set_num_threads(threads)
+            left = share * budget_s - (time.perf_counter() - t_start)
+            reps = max(2, min(10, int(left / max(one, 1e-3))))
+            times = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                run()
+                times.append(time.perf_counter() - t0)
+            med = sorted(times)[len(times) // 2]
+            solvers[name] = {"evals_per_s": chunk / med, "threads": threads, "chunk_rows": chunk, "reps": reps,
+                             "integrals_per_s": chunk * cfg["d"] * cfg["nb_flow"] / med,
+                             "reference": "models/UMNN/ParallelNeuralIntegral.py:37-65" if name == "parallel"
+                             else "models/UMNN/NeuralIntegral.py:37-66"}
+    torch.set_num_threads(old_threads)
+    fast = max(solvers, key=lambda k: solvers[k]["evals_per_s"])
+    return {"value": solvers[fast]["evals_per_s"], "unit": "evals/s", "cores": solvers[fast]["threads"], "kind": "port",
+            "solver": fast, "solvers": solvers, "host_cores": ncpu,
+            "sample": f"{chunk}-row chunks of the same flow through oracle/torch_port.py (torch CPU port of the reference's "
+                      f"compute_ll), median of {solvers[fast]['reps']} calls per solver at its best thread count; value = the "
+                      f"faster solver ({fast})"}
+
+
+def hbm_traffic(workload, live, extra_args):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; one counter per
+    pass; gfx950 corrections per MI355X_MICROARCH.md).  ``live``: collect now (tools/measure_traffic.py, two child runs of
+    this script under rocprofv3).  Otherwise the committed profiles/hbm_traffic.json -- trusted only while the kernel
+    sources hash to what was profiled; else null."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if live:
+        try:
+            from tools import measure_traffic
+            rec = measure_traffic.measure(workload, extra_args)
+            return rec.get("hbm_bytes_per_launch"), "live rocprofv3 PMC passes in this run"
+        except Exception as e:      # profiler missing / refused: report null, never a stale number
+            return None, f"live collection failed: {e}"
+    try:
+        rec = json.load(open(path)).get(workload, {})
+    except Exception:
+        return None, "profiles/hbm_traffic.json missing"
+    if rec.get("source_sha256") != kernel_source_hash():
+        return None, "profiles/hbm_traffic.json was collected for different kernel sources (stale): re-run tools/profile_bench.sh"
+    return rec.get("hbm_bytes_per_launch"), f"profiles/hbm_traffic.json (sources {rec.get('source_sha256')})"
 
 
 def main():
@@ -89,6 +152,9 @@ def main():
     ap.add_argument("--workload", default="bsds300", choices=sorted(WORKLOADS))
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the exact_fp32 and full_batch_n1 records (profiling runs)")
+    ap.add_argument("--live-traffic", action="store_true",
+                    help="measure roofline.traffic now with two rocprofv3 PMC child runs instead of reading profiles/")
     ap.add_argument("--mode", default="eval", choices=["eval", "train"],
                     help="eval: compute_ll forward (the headline metric). train: forward + backward + one flattened "
                          "RCCL gradient all-reduce + Adam step per step (reported as training samples/s)")
@@ -114,25 +180,19 @@ def main():
     precision = _lib.get_forward_precision()
 
     model = build_model(cfg, device)
-    torch.manual_seed(1000 + rank)                      # every rank owns a different shard of the global batch
-    x = torch.randn(cfg["rows"], cfg["d"], device=device)
+    x, ctx = make_inputs(cfg, cfg["rows"], device, 1000 + rank)    # every rank owns a different shard of the global batch
+
+    def ll_of(xb, cb):
+        return model.compute_ll(xb, context=cb) if cb is not None else model.compute_ll(xb)
 
     if args.mode == "train":
         model.train()
         sharding.broadcast_parameters(model)
         opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, capturable=bool(args.graph))
-
-        def step():
-            opt.zero_grad(set_to_none=True)
-            ll, z = model.compute_ll(x)
-            (-ll.mean()).backward()
-            sharding.allreduce_gradients(model, world)          # one flattened all-reduce, before clipping
-            torch.nn.utils.clip_grad_value_(model.parameters(), 10.0)
-            opt.step()
-            return ll.detach(), z
+        step = make_train_step(model, opt, x, ctx, world)
         if args.graph:      # the whole step (fwd, HIP bwd, all-reduce hook, clipping, Adam) as one replayed hipGraph
             import umnn_amd
-            gstep = umnn_amd.GraphedTrainStep(model, opt, x, clip_value=10.0,
+            gstep = umnn_amd.GraphedTrainStep(model, opt, x, context=ctx, clip_value=10.0,
                                               grad_hook=lambda mdl: sharding.allreduce_gradients(mdl, world))
 
             def step():         # noqa: F811
@@ -140,11 +200,11 @@ def main():
     else:
         def eager_step():
             with torch.no_grad():
-                return model.compute_ll(x)
+                return ll_of(x, ctx)
         step = eager_step
         if args.graph:
             import umnn_amd
-            graphed = umnn_amd.GraphedLL(model, x)
+            graphed = umnn_amd.GraphedLL(model, x, context=ctx)
             step = lambda: graphed()        # noqa: E731  (x is already in the captured buffer)
 
     for _ in range(args.warmup):
@@ -160,64 +220,86 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    k_ms, k_n, k_fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
-    lib.umnn_profile_read(ctypes.byref(k_ms), ctypes.byref(k_n), ctypes.byref(k_fl))
+    fwd = _lib.profile_read(_lib.PROF_FORWARD)
+    bwd = _lib.profile_read(_lib.PROF_BACKWARD)
+    fin = _lib.profile_read(_lib.PROF_FINISH)
     lib.umnn_profile_enable(0)
     if args.graph and args.mode == "eval":      # launches inside a replayed graph carry no events: time them eagerly
         lib.umnn_profile_enable(1)
         for _ in range(max(3, args.steps // 4)):
             eager_step()
         torch.cuda.synchronize()
-        lib.umnn_profile_read(ctypes.byref(k_ms), ctypes.byref(k_n), ctypes.byref(k_fl))
+        fwd = _lib.profile_read(_lib.PROF_FORWARD)
         lib.umnn_profile_enable(0)
     assert torch.isfinite(ll).all()
-    kernel_name = lib.umnn_last_kernel_name().decode()
+    kernel_name = lib.umnn_last_kernel_name_of(_lib.PROF_FORWARD if args.mode == "eval" else _lib.PROF_BACKWARD).decode()
 
+    extras = world == 1 and args.mode == "eval" and not args.no_extras
     # for the record: the same workload with the exact-fp32 MFMA kernels (N=1 eval only; a few untimed-by-the-driver steps)
     exact = None
-    if world == 1 and args.mode == "eval" and precision != "fp32":
-        _lib.set_forward_precision("fp32")
+    if extras and precision != "fp32":
+        import umnn_amd
+        umnn_amd.set_precision("fp32")              # forward kernels AND conditioner GEMMs in the reference's arithmetic
         for _ in range(2):
-            step()
+            eager_step()
         lib.umnn_profile_enable(1)
         torch.cuda.synchronize()
         te = time.perf_counter()
         for _ in range(3):
-            step()
+            eager_step()
         torch.cuda.synchronize()
         te = time.perf_counter() - te
-        e_ms, e_n, e_fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
-        lib.umnn_profile_read(ctypes.byref(e_ms), ctypes.byref(e_n), ctypes.byref(e_fl))
+        e_ms, e_n, e_fl = _lib.profile_read(_lib.PROF_FORWARD)
         lib.umnn_profile_enable(0)
-        tf = e_fl.value / max(e_ms.value, 1e-9) / 1e9
+        tf = e_fl / max(e_ms, 1e-9) / 1e9
         exact = {"value": cfg["rows"] * 3 / te, "ms_per_step": 1e3 * te / 3, "kernel": lib.umnn_last_kernel_name().decode(),
-                 "avg_launch_ms": e_ms.value / max(1, e_n.value), "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
-                 "frac": tf / PEAK_FP32_MFMA_TFLOPS}
-        _lib.set_forward_precision(precision)
+                 "avg_launch_ms": e_ms / max(1, e_n), "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
+                 "frac": tf / PEAK_FP32_MFMA_TFLOPS, "conditioner": "fp32 F.linear"}
+        umnn_amd.set_precision(precision)
+    # the un-sharded C3 batch on ONE GPU (65536 rows): the anchor the 8-GPU point of the sharded run is compared with
+    full = None
+    if extras and args.workload == "bsds300" and not args.rows and not args.graph:
+        xf, cf = make_inputs(cfg, FULL_BATCH_ROWS, device, 4242)
+        with torch.no_grad():
+            for _ in range(2):
+                ll_of(xf, cf)
+            torch.cuda.synchronize()
+            tfb = time.perf_counter()
+            for _ in range(3):
+                llf, _ = ll_of(xf, cf)
+            torch.cuda.synchronize()
+            tfb = time.perf_counter() - tfb
+        assert torch.isfinite(llf).all()
+        full = {"rows": FULL_BATCH_ROWS, "value": FULL_BATCH_ROWS * 3 / tfb, "unit": "evals/s", "ms_per_step": 1e3 * tfb / 3,
+                "steps": 3, "note": "BASELINE config C3's whole batch on one GPU (strong-scaling anchor for the N=8 run)"}
+        del xf, llf
+
+    ranks = [{"rank": rank, "device": torch.cuda.get_device_name(device),
+              "pci_bus_id": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None),
+              "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}]
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ranks[0])
+        ranks = gathered
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         value = world * cfg["rows"] * args.steps / elapsed
-        avg_kernel_ms = k_ms.value / max(1, k_n.value)
-        achieved = k_fl.value / max(k_ms.value, 1e-9) / 1e9            # TFLOP/s over the quadrature launches
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(args.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        dom = fwd if args.mode == "eval" else bwd           # (ms, launches, algorithmic FLOPs) of the dominant kernel class
+        avg_kernel_ms = dom[0] / max(1, dom[1])
+        achieved = dom[2] / max(dom[0], 1e-9) / 1e9                    # TFLOP/s over those launches
+        traffic, traffic_src = (None, "eval mode only") if args.mode != "eval" else \
+            hbm_traffic(args.workload, args.live_traffic, ["--precision", precision] if args.precision else [])
         on_bf16 = "bf16" in kernel_name
         peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
-        # FLOPs the matrix pipe actually executes per launch in the bf16-split kernels: per hidden->hidden layer
+        # FLOPs the matrix pipe actually executes per launch in the bf16-split FORWARD kernels: per hidden->hidden layer
         # ceil((H_out+1)/16) output tiles x ceil(ceil((H_in+1)/16)/2) K-steps x 3|6 cross terms of 16x16x32 MFMAs
         # (2*16*16*32 FLOPs each) per 16 integrals and node (+ the split-remainder MFMAs of the pipelined loop)
         executed = None
-        if on_bf16:
+        if on_bf16 and args.mode == "eval":
             hd, terms = cfg["hd"], (3 if "PARTS=2" in kernel_name else 6)
             per_tile_node = sum(-(-(hd[i + 1] + 1) // 16) * -(-(-(-(hd[i] + 1) // 16)) // 2) * terms for i in range(len(hd) - 1))
             if "PIPE" in kernel_name:     # + one remainder MFMA per fully live tile and split (see cc_forward_bf16.hip)
@@ -234,38 +316,65 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": cfg["desc"], "rows_per_gpu": cfg["rows"], "dim": cfg["d"], "n_steps": cfg["n"],
                        "nb_flow": cfg["nb_flow"], "embedding": cfg["E"], "integrand": cfg["hd"], "made": cfg["he"],
+                       "cond_in": cfg.get("cond", 0),
                        "sharding": f"batch x{world}, no forward collective",
                        "integrals_per_s": value * cfg["d"] * cfg["nb_flow"]},
-            # achieved = ALGORITHMIC fp32 FLOPs / kernel time; peak = dense MFMA peak of the dtype the
-            # matrix instructions execute.  The bf16-split kernels issue 3 (or 6) bf16 MFMAs per fp32 product on
-            # tiles padded 50->64, so their algorithmic fraction of the bf16 peak is small by construction; the
+            # achieved = ALGORITHMIC fp32 FLOPs (backward = 3 x forward) / kernel time; peak = dense MFMA peak
+            # of the dtype the matrix instructions execute.  The bf16-split kernels issue 3 (or 6) bf16 MFMAs per fp32
+            # product on tiles padded 50->64, so their algorithmic fraction of the bf16 peak is small by construction; the
             # fraction of the fp32-MFMA peak (what an exact-fp32 kernel could reach at best) is given alongside.
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "kernel": kernel_name, "avg_launch_ms": avg_kernel_ms,
-                         "launches": k_n.value,
-                         "flops_per_launch": k_fl.value / max(1, k_n.value),
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel_name, "kernel_class": "forward" if args.mode == "eval" else "backward (main pass)",
+                         "avg_launch_ms": avg_kernel_ms, "launches": dom[1],
+                         "flops_per_launch": dom[2] / max(1, dom[1]),
                          "kernel_share_of_step": (avg_kernel_ms * cfg["nb_flow"] / ms_step) if args.graph
-                         else k_ms.value / (1e3 * elapsed),
+                         else dom[0] / (1e3 * elapsed),
                          "peak_dtype": "bf16 dense MFMA" if on_bf16 else "fp32 MFMA",
                          "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "executed_mfma_tflops": executed,
                          "executed_frac_of_peak": executed / peak if executed else None},
+            "ranks_seen": len(ranks), "ranks": ranks,
+            "dist": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                     "backend": dist.get_backend() if dist.is_initialized() else None},
         }
         if args.graph:
             out["config"]["graph"] = "step replayed as one hipGraph; roofline timings from an eager pass after the timed region"
         if exact is not None:
             out["exact_fp32"] = exact
+        if full is not None:
+            out["full_batch_n1"] = full
         if args.mode == "train":
-            out["config"]["mode"] = "train: fwd + HIP bwd + flattened gradient all-reduce (RCCL) + Adam"
-            out["roofline"] = None      # the per-launch timing above mixes forward and backward launches
+            out["config"]["mode"] = "train: fwd + HIP bwd + flattened gradient all-reduce (RCCL) + value clipping + Adam"
+            out["train_kernels"] = {
+                "forward": {"ms": fwd[0], "launches": fwd[1], "avg_launch_ms": fwd[0] / max(1, fwd[1])},
+                "backward_main": {"ms": bwd[0], "launches": bwd[1], "avg_launch_ms": bwd[0] / max(1, bwd[1])},
+                "backward_finishing": {"ms": fin[0], "launches": fin[1], "avg_ms": fin[0] / max(1, fin[1])},
+                "share_of_step": (fwd[0] + bwd[0] + fin[0]) / (1e3 * elapsed)}
         if world == 1 and not args.no_cpu_baseline and args.mode == "eval":
             out["cpu_baseline"] = cpu_baseline(cfg, model)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            out["cpu_baseline"]["gpu_over_cpu_parallel_solver"] = value / out["cpu_baseline"]["solvers"]["parallel"]["evals_per_s"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def make_train_step(model, opt, x, ctx, world, clip_value=10.0):
+    """One data-parallel optimisation step as the reference's scripts do it (UCIExperiments.py:133-146): loss, backward,
+    ONE flattened gradient all-reduce, value clipping AFTER the reduction (:143), Adam."""
+    from umnn_amd import sharding
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        ll, z = model.compute_ll(x, context=ctx) if ctx is not None else model.compute_ll(x)
+        (-ll.mean()).backward()
+        sharding.allreduce_gradients(model, world)          # one flattened all-reduce, before clipping
+        torch.nn.utils.clip_grad_value_(model.parameters(), clip_value)
+        opt.step()
+        return ll.detach(), z
+    return step
 
 
 if __name__ == "__main__":

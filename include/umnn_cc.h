@@ -91,6 +91,21 @@ int umnn_flow_stack_block_forward(const umnn_mlp* net, const float* x, const flo
                                   long long B, int d, int E, int reverse_z, const float* log_jac_in,
                                   float* z, float* log_jac, float* f_x, float* f_x0, void* stream);
 
+/* One link of UMNNMAFFlow.compute_ll (UMNNMAFFlow.py:109-119) with the WHOLE log-likelihood arithmetic inside the
+ * launch: besides z (reversed for the next block when reverse_z != 0) the kernel keeps the per-sample running sum
+ *   ll[b]  = (first ? 0 : ll[b]) + sum_i log_jac[b,i]            (UMNNMAF.compute_log_jac, UMNNMAF.py:136-139)
+ *   ll[b] += -1/2 * sum_i (log(2 pi) + z[b,i]^2)   when last != 0  (UMNNMAFFlow.py:116-118)
+ * so a flow's compute_ll is exactly nb_flow x (conditioner + this launch): no [B,d] log_jac accumulation between
+ * blocks, no elementwise epilogue kernels.  The row sum is taken by the last tile to deliver a piece of the row
+ * (arrival counters + device-scope fences), in a fixed order: bit-reproducible, no floating-point atomics.
+ *   log_jac_scratch  [B,d] write-then-read scratch of this launch (this block's log_jac; may be reused by the next)
+ *   row_counters     [B] uint32, ZERO on entry; the kernel leaves them zero again
+ *   z must not alias x. */
+int umnn_flow_ll_block_forward(const umnn_mlp* net, const float* x, const float* h, const float* scaling,
+                               const float* cc_w, const float* cc_s, int nb_steps,
+                               long long B, int d, int E, int reverse_z, int first, int last,
+                               float* z, float* log_jac_scratch, float* ll, unsigned* row_counters, void* stream);
+
 /* Replaces integrate(..., compute_grad=True) + the Leibniz terms -- ParallelNeuralIntegral.py:66-94,
  * 110-123 (NeuralIntegral.py:47-58,69-75,90-99).  g is grad_output [B,d] (cotangent of F).
  *   g_fx    nullable [B,d]: cotangent of the f_x output of umnn_cc_forward.  The reference gets this
@@ -149,11 +164,30 @@ int umnn_cc_backward_kind(const umnn_mlp* net, int E);
 int umnn_set_backward_precision(int mode);
 int umnn_get_backward_precision(void);
 
+/* Launch options.  The UMNN_* environment variables are read once per process -- at first use or on
+ * umnn_reload_env() -- and live in atomics afterwards, so the launch path never calls getenv.  Names:
+ * "fwd_precision", "bwd_precision" (UMNN_PRECISION_*), "fwd_p" (1|2), "fwd_ns" (1|2|4), "fwd_tail" (0|1), "fwd_pipe",
+ * "fwd_pad", "fwd_pad_min", "bwd_ns" (1..32); -1 = automatic for the tuning knobs. */
+int umnn_set_option(const char* name, int value);
+int umnn_get_option(const char* name, int* value);
+int umnn_reload_env(void);
+
 /* Per-launch timing: while enabled, every forward/backward launch is bracketed by hipEvents recorded on its own
  * launch stream.  umnn_profile_read synchronises on them and returns the summed kernel milliseconds, the number of
  * launches and the summed algorithmic FLOPs (forward launches only carry FLOPs).  enable(0/1) clears the records. */
 int umnn_profile_enable(int on);
 int umnn_profile_read(double* total_ms, long long* launches, double* total_flops);
+/* The same per class of launch: forward quadrature kernels (FLOPs = the algorithmic forward count), the main backward
+ * kernels (FLOPs = 3 x the forward count of the same integrals: 2 x for the two gradient GEMMs per forward GEMM + 1 x for the
+ * forward recompute, SURVEY 8d "Backward ~ 2x forward MACs + recompute"), and the finishing kernels of the backward
+ * (dc sum, d_h, dW1, d_theta reduction; bracketed as one record, no FLOPs). */
+#define UMNN_PROF_FORWARD 0
+#define UMNN_PROF_BACKWARD 1
+#define UMNN_PROF_FINISH 2
+int umnn_profile_read_tag(int tag, double* total_ms, long long* launches, double* total_flops);
+/* Variant name of the last launch of that class by ANY thread (umnn_last_kernel_name is per calling thread, and the
+ * backward runs on autograd worker threads). */
+const char* umnn_last_kernel_name_of(int tag);
 
 /* MADE conditioner operand builder (reference models/UMNN/made.py:16-27: MaskedLinear chains around ReLU).  Reads the
  * previous layer's raw fp32 output x [rows, cols] and writes, per row, the bf16 operand

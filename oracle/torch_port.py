@@ -65,17 +65,28 @@ def made(Ws, bs, masks, x):
     return a
 
 
-def flow_compute_ll(blocks, x, n, solver="CCParallel"):
+def _embedding(blk, x, context, cond_in):
+    """MADE pass of one block; with a context, the reference's ConditionnalMADE (made.py:165-168): MADE over
+    [context, x], then every output chunk drops its cond_in context columns."""
+    if context is None:
+        return made(blk["mW"], blk["mb"], blk["mm"], x)
+    out = made(blk["mW"], blk["mb"], blk["mm"], torch.cat((context, x), 1))
+    B, nin = x.shape[0], x.shape[1] + cond_in
+    return out.contiguous().view(B, out.shape[1] // nin, nin)[:, :, cond_in:].contiguous().view(B, -1)
+
+
+def flow_compute_ll(blocks, x, n, solver="CCParallel", context=None):
     """blocks: list of dicts {mW, mb, mm, iW, ib, scaling} of CPU tensors.  Follows the reference call structure:
     per block forward (MADE + integral) and compute_log_jac (MADE again + one integrand evaluation)."""
     quad = integrate_parallel if solver == "CCParallel" else integrate_sequential
     d = x.shape[1]
+    cond_in = context.shape[1] if context is not None else 0
     log_jac = 0.
     for blk in blocks:
-        h = made(blk["mW"], blk["mb"], blk["mm"], x)
+        h = _embedding(blk, x, context, cond_in)
         z0 = h.view(h.shape[0], -1, d)[:, 0, :]
         z = torch.exp(blk["scaling"]).unsqueeze(0) * (quad(blk["iW"], blk["ib"], torch.zeros_like(x), x, h, n) + z0)
-        h2 = made(blk["mW"], blk["mb"], blk["mm"], x)
+        h2 = _embedding(blk, x, context, cond_in)
         log_jac = log_jac + torch.log(integrand(blk["iW"], blk["ib"], x, h2, d) + 1e-10) + blk["scaling"].unsqueeze(0)
         x = torch.flip(z, [1])
     z = torch.flip(x, [1])

@@ -62,3 +62,27 @@ def scaled_err(a, b):
     """max |a-b| / max|b| -- for gradient tensors whose entries span many magnitudes."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30)) if a.size else 0.0
+
+
+def kink_margin(net, x0, x, h, nb_steps):
+    """Smallest |pre-activation| of any hidden unit at any quadrature node, RELATIVE to the sum of the magnitudes of the
+    terms that form it (what rounding error scales with).  The backward multiplies by act'(z) = 1 or slope: where |z| is
+    below the rounding noise of the dot product (~sqrt(K) 2^-24 of sum|terms|, a few 1e-7 -- seed 19 of the random sweep has margin 2e-8 and the fp32 and fp64 ORACLES already differ by 7e-4 on it), the sign -- and with it one
+    unit's whole contribution at that point -- is decided by summation order, in the reference as much as here.  A case
+    whose margin is above the noise must meet the strict tolerance; a case below it is kink-ambiguous."""
+    x0, x, h = (np.asarray(a, np.float64) for a in (x0, x, h))
+    net64 = O.Net([W.astype(np.float64) for W in net.Ws], [b.astype(np.float64) for b in net.bs], net.hidden_act, net.out_act)
+    w, s = O.cc_tables(nb_steps, np.float64)
+    B, d = x.shape
+    t, _ = O._nodes(x0, x, s, nb_steps)
+    n1 = nb_steps + 1
+    hs = np.broadcast_to(h[:, None, :], (B, n1, h.shape[1])).reshape(B * n1, -1)
+    a = O.rows_from(t.reshape(B * n1, d), hs, d)
+    margin = np.inf
+    for l in range(len(net64.Ws) - 1):
+        W, b = net64.Ws[l], net64.bs[l]
+        z = a @ W.T + b
+        mag = np.abs(a) @ np.abs(W).T + np.abs(b)
+        margin = min(margin, float(np.min(np.abs(z) / np.maximum(mag, 1e-300))))
+        a = O._hidden(z, net64.hidden_act)
+    return margin

@@ -85,3 +85,50 @@ def test_shard_bounds_cover_everything():
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _bench_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import bench
+    sharding.init_from_env(backend="gloo")
+    model = _model()
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1.5)
+    sharding.broadcast_parameters(model, src=0)
+    model.train()
+    torch.manual_seed(5)
+    x = torch.randn(12, 3) * 3            # large inputs: some raw gradients exceed the clip value
+    xs = sharding.shard_rows(x, rank, world).contiguous()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2)
+    step = bench.make_train_step(model, opt, xs, None, world, clip_value=0.05)     # bench.py's own step closure
+    for _ in range(3):
+        step()
+    torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, os.path.join(outdir, f"b{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_train_step_two_ranks_equals_single_process():
+    """bench.py's train step (loss -> backward -> ONE flattened all-reduce -> clip AFTER the reduction -> Adam,
+    UCIExperiments.py:133-146) on two gloo ranks reproduces single-process training on the whole batch."""
+    import bench
+    world = 2
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_bench_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        parts = [torch.load(os.path.join(out, f"b{r}.pt")) for r in range(world)]
+    model = _model()
+    model.train()
+    torch.manual_seed(5)
+    x = torch.randn(12, 3) * 3
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2)
+    step = bench.make_train_step(model, opt, x, None, 1, clip_value=0.05)
+    for _ in range(3):
+        step()
+    ref = model.state_dict()
+    for k in ref:
+        assert torch.allclose(parts[0][k], parts[1][k], atol=0, rtol=0), k             # replicas stay bit-identical
+        assert torch.allclose(parts[0][k], ref[k], atol=2e-6, rtol=1e-5), k

@@ -138,12 +138,12 @@ def test_flow_training_gradients_match_reference(name, dev):
     assert umnn_amd.path_taken() == "hip"
     (-ll.mean()).backward()
     assert U.rel_err(ll.detach().cpu().numpy(), G["ll_train"]) < TOL
-    assert U.scaled_err(x.grad.cpu().numpy(), G["grad/x"]) < 2e-4
+    assert U.scaled_err(x.grad.cpu().numpy(), G["grad/x"]) < TOL
     worst = 0.0
     for k, p in m.named_parameters():
         if p.grad is not None and ("grad/" + k) in G:
             worst = max(worst, U.scaled_err(p.grad.cpu().numpy(), G["grad/" + k]))
-    assert worst < 2e-4, worst
+    assert worst < TOL, worst
 
 
 @pytest.mark.parametrize("n", [50, 100])
@@ -158,9 +158,9 @@ def test_monotonic_nn_matches_reference(n, dev):
     assert umnn_amd.path_taken() == "hip"
     (y ** 2).mean().backward()
     assert U.rel_err(y.detach().cpu().numpy(), G["y"]) < TOL
-    assert U.scaled_err(x.grad.cpu().numpy(), G["grad/x"]) < 2e-4
+    assert U.scaled_err(x.grad.cpu().numpy(), G["grad/x"]) < TOL
     for k, p in m.named_parameters():
-        assert U.scaled_err(p.grad.cpu().numpy(), G["grad/" + k]) < 2e-4, k
+        assert U.scaled_err(p.grad.cpu().numpy(), G["grad/" + k]) < TOL, k
 
 
 def test_backward_deterministic(dev):
@@ -250,7 +250,7 @@ def test_mixed_wide_nets_take_the_aten_backward_and_match_the_oracle(hid, dev, m
         (F * g).sum().add((torch.log(fx) * g.flip(0)).sum()).backward()
         outs.append((xr.grad.clone(), hr.grad.clone(), torch.cat([p.grad.reshape(-1) for p in net.parameters()])))
     for a, b in zip(*outs):
-        assert (a - b).abs().max() <= 2e-4 * b.abs().max()
+        assert (a - b).abs().max() <= 1e-4 * b.abs().max()
 
 
 def test_full_size_backward_properties_bsds300_shard(dev):
@@ -306,7 +306,9 @@ def test_exact_wide_backward_families_match_the_oracle(hid, dev):
     h, g = torch.randn(B, E * d, device=dev), torch.randn(B, d, device=dev)
     ref = O.integrate_backward(onet, x0.cpu().numpy(), x.cpu().numpy(), h.cpu().numpy(), n, g.cpu().numpy())
     dx0, dx, dh, dth = I.hip_backward(spec, x0, x, h, g, None, n)
-    assert "KS=" in _lib.lib().umnn_last_kernel_name().decode() or True
+    kname = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+    ks = {64: "T=5", 100: "T=7"}[hid[0]]
+    assert kname.startswith("cc_bwd<") and ks in kname and "KS=0" not in kname, kname      # the shape-exact family ran
     assert U.rel_err(dx0.cpu().numpy(), ref[0]) < TOL and U.rel_err(dx.cpu().numpy(), ref[1]) < TOL
     assert U.scaled_err(dh.cpu().numpy(), ref[2]) < TOL
     assert U.scaled_err(dth.cpu().numpy(), ref[5]) < TOL

@@ -1,0 +1,162 @@
+"""Parity of the EXACT models bench.py times (BASELINE configs C1-C4), at the benchmarked batch sizes, through the default
+arithmetic (bf16x3 quadrature kernels, K-concatenated bf16 conditioner GEMMs, the one-pass log-likelihood epilogue) against the
+pinned CPU oracle on sampled rows (rows are independent; the oracle needs seconds for 32 of them).
+
+Reference arithmetic being matched: UMNNMAFFlow.compute_ll / compute_log_jac_bis (models/UMNN/UMNNMAFFlow.py:109-130),
+UMNNMAF.forward / compute_log_jac (models/UMNN/UMNNMAF.py:76-139).  Tolerance: the path's 1e-4 in every mode,
+including the default; bf16 *callers* (configuration C4) state their own tolerance below.
+"""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from oracle import cc_oracle as O
+from tests import _util as U
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+# bf16 callers (C4): x, context and the results are rounded to bf16 (8 significant bits, relative 2^-9 = 2e-3 per value);
+# z is a sum of an integral and an offset of similar size, log_jac sums d values.  Stated bound vs the fp32 oracle:
+BF16_TOL = 2e-2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _oracle_blocks(model, cfg):
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    blocks = []
+    for i in range(cfg["nb_flow"]):
+        mW, mb, mm = U._seq(sd, f"Flow{i}.net.made.net.", np.float32)
+        iW, ib, _ = U._seq(sd, f"Flow{i}.net.parallel_nets.net.", np.float32)
+        blocks.append(O.Block(mW, mb, mm, O.Net(iW, ib, O.LEAKY, O.ELU1), sd[f"Flow{i}.scaling"].astype(np.float32),
+                              cfg.get("cond", 0)))
+    return blocks
+
+
+def _sample_rows(B, k=32, seed=5):
+    rows = np.sort(np.random.RandomState(seed).choice(B, k, replace=False))
+    rows[0], rows[-1] = 0, B - 1                       # first and last row: tile / shard edges
+    return rows
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("workload", ["bsds300", "power", "toy", "vae"])
+def test_benchmarked_model_matches_oracle_at_full_batch(workload, precision, dev):
+    import umnn_amd
+    from umnn_amd import _lib
+    cfg = dict(bench.WORKLOADS[workload])
+    model = bench.build_model(cfg, dev)
+    x, ctx = bench.make_inputs(cfg, cfg["rows"], dev, 1000)          # bench.py's own inputs for rank 0
+    old = umnn_amd.get_forward_precision()
+    umnn_amd.set_precision(precision)
+    try:
+        launches = _lib.lib().umnn_launch_count()
+        with torch.no_grad():
+            ll, z = model.compute_ll(x, context=ctx) if ctx is not None else model.compute_ll(x)
+            assert _lib.lib().umnn_launch_count() - launches == cfg["nb_flow"], \
+                "compute_ll must be nb_flow x (conditioner + ONE quadrature launch)"
+            zb, lj = model.compute_log_jac_bis(x, context=ctx) if ctx is not None else model.compute_log_jac_bis(x)
+            llb, _ = model.compute_ll_bis(x, context=ctx) if ctx is not None else model.compute_ll_bis(x)
+        assert umnn_amd.path_taken() == "hip"
+        kname = _lib.lib().umnn_last_kernel_name().decode()
+        assert ("bf16" in kname) == (precision != "fp32"), kname
+    finally:
+        umnn_amd.set_precision(old)
+    rows = _sample_rows(cfg["rows"])
+    xs = x[rows].cpu().numpy()
+    cs = ctx[rows].cpu().numpy() if ctx is not None else None
+    blocks = _oracle_blocks(model, cfg)
+    ll_ref, z_ref = O.flow_compute_ll(blocks, xs, cfg["n"], context=cs)
+    _, lj_ref = O.flow_log_jac(blocks, xs, cfg["n"], context=cs)
+    assert U.rel_err(z.cpu().numpy()[rows], z_ref) < TOL
+    assert U.rel_err(ll.cpu().numpy()[rows], ll_ref) < TOL
+    assert U.rel_err(zb.cpu().numpy()[rows], z_ref) < TOL
+    got_lj = lj.cpu().numpy()[rows]
+    assert np.all(np.abs(got_lj - lj_ref) <= TOL * np.maximum(1.0, np.abs(lj_ref)))
+    # one-pass ll (in-kernel row sums) == elementwise route summed on the host, to fp32 summation noise
+    ll_from_bis = llb.sum(1)
+    assert U.rel_err(ll.cpu().numpy(), ll_from_bis.cpu().numpy()) < 2e-6 * max(1, cfg["d"] // 8)
+
+
+def test_one_pass_ll_is_bit_reproducible_and_matches_elementwise_route(dev):
+    """The in-kernel log-likelihood (arrival counters + last-arriver row sums, umnn_flow_ll_block_forward) against the
+    elementwise kernels + ATen sums, over shapes whose rows straddle tiles, waves and workgroups in every way; repeated
+    launches must return identical bits (one writer per row, fixed order) and leave the counters clean."""
+    import umnn_amd
+    from umnn_amd import integral as I
+    for (B, d, nb_flow, hid, E, n) in [(1, 1, 1, [20, 20], 2, 10), (37, 3, 2, [50] * 4, 5, 20), (257, 63, 3, [50] * 4, 30, 20),
+                                       (100, 784, 1, [50, 50], 4, 6), (4096, 2, 1, [100] * 4, 10, 50), (999, 17, 2, [40, 33], 6, 12),
+                                       (5000, 6, 5, [50] * 4, 30, 20)]:
+        torch.manual_seed(B + d)
+        m = umnn_amd.UMNNMAFFlow(nb_flow=nb_flow, nb_in=d, hidden_derivative=hid, hidden_embedding=[64, 64], embedding_s=E,
+                                 nb_steps=n, solver="CCParallel").to(dev).eval()
+        with torch.no_grad():
+            for net in m.nets:
+                net.scaling.copy_(torch.linspace(-0.2, 0.3, d))
+        x = torch.randn(B, d, device=dev)
+        with torch.no_grad():
+            ll, z = m.compute_ll(x)
+            z2, lj = m.compute_log_jac_bis(x)
+            ref = lj.double().sum(1) - 0.5 * (np.log(2 * np.pi) + z2.double() ** 2).sum(1)
+            assert torch.equal(z, z2)
+            assert float(((ll.double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) < 3e-6, (B, d)
+            for _ in range(3):
+                ll2, _ = m.compute_ll(x)
+                assert torch.equal(ll2, ll), (B, d)
+        for t in I._row_counters.values():
+            assert int(t.abs().sum()) == 0, "arrival counters must be zero again after every launch"
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16])
+def test_vae_prior_flow_with_bf16_callers(dt, dev):
+    """BASELINE configuration C4 as the VAE calls it (models/vae_lib/models/flows.py:305-323): compute_log_jac_bis(z, h_context)
+    with bf16 activations (autocast-style): the tolerance of that configuration, stated against the fp32 oracle."""
+    cfg = dict(bench.WORKLOADS["vae"])
+    model = bench.build_model(cfg, dev)
+    x, ctx = bench.make_inputs(cfg, 100, dev, 7)                # the script's batch of 100
+    with torch.no_grad():
+        z, lj = model.compute_log_jac_bis(x.to(dt), ctx.to(dt))
+    blocks = _oracle_blocks(model, cfg)
+    xs, cs = x.to(dt).float().cpu().numpy(), ctx.to(dt).float().cpu().numpy()     # the oracle sees the same rounded inputs
+    z_ref, lj_ref = O.flow_log_jac(blocks, xs, cfg["n"], context=cs)
+    assert U.rel_err(z.float().cpu().numpy(), z_ref) < BF16_TOL
+    assert np.all(np.abs(lj.float().cpu().numpy() - lj_ref) <= BF16_TOL * np.maximum(1.0, np.abs(lj_ref)))
+
+
+def test_block_level_compute_ll_and_bis_on_the_hip_path(dev):
+    """UMNNMAF.compute_ll / compute_ll_bis (block level, with the in-place clamp of z, UMNNMAF.py:141-162) on the HIP path."""
+    import umnn_amd
+    G = U.load("g4_flow2_power_cc")
+    blocks = U.blocks_from_g4(G)
+    m = umnn_amd.UMNNMAFFlow(nb_flow=int(G["nb_flow"]), nb_in=int(G["d"]),
+                             hidden_derivative=[int(v) for v in G["hidden_derivative"]],
+                             hidden_embedding=[int(v) for v in G["hidden_embedding"]], embedding_s=int(G["E"]),
+                             nb_steps=int(G["n"]), solver=str(G["solver"]))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in U.state_dict_of(G).items()})
+    m.to(dev).eval()
+    x = torch.from_numpy(G["x"]).to(dev) * 4                      # large inputs so that the clamp at +-10 bites
+    xs = x.cpu().numpy()
+    blk = blocks[0]
+    z_ref, h = O.block_forward(blk, xs, int(G["n"]))
+    lj_ref = O.block_log_jac(blk, xs, h)
+    zc = np.clip(z_ref, -10., 10.)
+    ll_ref = lj_ref.sum(1) - .5 * (np.log(2 * np.pi) + zc ** 2).sum(1)
+    with torch.no_grad():
+        ll, z = m.nets[0].compute_ll(x)
+        assert umnn_amd.path_taken() == "hip"
+        ljb, zb = m.nets[0].compute_ll_bis(x)
+    assert float(z.abs().max()) <= 10.0
+    assert U.rel_err(z.cpu().numpy(), zc) < TOL and U.rel_err(zb.cpu().numpy(), zc) < TOL
+    assert U.rel_err(ll.cpu().numpy(), ll_ref) < TOL
+    assert np.all(np.abs(ljb.cpu().numpy() - lj_ref) <= TOL * np.maximum(1.0, np.abs(lj_ref)))
+    # flow-level compute_ll_bis (per-dimension log-likelihood terms, UMNNMAFFlow.py:121-130)
+    ll_full_ref, z_full_ref = O.flow_compute_ll(blocks, G["x"], int(G["n"]))
+    with torch.no_grad():
+        llb, zf = m.compute_ll_bis(torch.from_numpy(G["x"]).to(dev))
+    assert U.rel_err(zf.cpu().numpy(), z_full_ref) < TOL
+    assert U.rel_err(llb.sum(1).cpu().numpy(), ll_full_ref) < TOL

@@ -85,14 +85,12 @@ def test_forward_matches_golden_and_oracle(name, dev, precision):
 @pytest.mark.parametrize("TAIL", [0, 1])
 @pytest.mark.parametrize("P,NS", [(1, 1), (2, 1), (1, 2), (1, 4), (2, 4), (2, 2)])
 @pytest.mark.parametrize("name", ["g2_power_d6_w2", "g2_toy_d2_w2", "g2_mnist_mixed_d8", "g2_odd_n_d3", "g2_bsds_d63_w2"])
-def test_every_kernel_variant_agrees(name, P, NS, TAIL, dev, monkeypatch, precision):
+def test_every_kernel_variant_agrees(name, P, NS, TAIL, dev, opts, precision):
     """Point tiles per wave (P), node-split factor (NS) and the VALU-tail variant are launch choices: all must give
     the same answer."""
     from umnn_amd import integral as I, _lib
     from umnn_amd.nets import mlp_spec
-    monkeypatch.setenv("UMNN_FWD_P", str(P))
-    monkeypatch.setenv("UMNN_FWD_NS", str(NS))
-    monkeypatch.setenv("UMNN_FWD_TAIL", str(TAIL))
+    opts(fwd_p=P, fwd_ns=NS, fwd_tail=TAIL)
     G = U.load(name)
     net = build_integrand(G, dev)
     F, fx, fx0 = I.hip_forward(mlp_spec(net), t(G["x0"], dev), t(G["x"], dev), t(G["h"], dev), int(G["n"]))
@@ -332,9 +330,13 @@ def test_random_mlp_shapes_forward_and_backward(seed, dev):
         return
     rdx0, rdx, rdh, _, _, rflat = O.integrate_backward(onet, x0, x, h, n, g)
     assert U.rel_err(dx0.cpu().numpy(), rdx0) < TOL and U.rel_err(dx.cpu().numpy(), rdx) < TOL
-    # ReLU nets at random init have kinks exactly where fp32 summation order decides the sign: allow a few 1e-4
-    assert U.scaled_err(dh.cpu().numpy(), rdh) < 5e-4
-    assert U.scaled_err(dth.cpu().numpy(), rflat) < 5e-4
+    # gradients: the stated 1e-4 -- unless some hidden pre-activation of this very case sits inside the rounding noise
+    # of its own dot product (kink distance below 5e-7 of sum|terms|, i.e. a few ulps of the fp32 dot product): there the SIGN, hence act'(z), is decided by
+    # summation order in the reference as much as here, and one flipped unit at one of the few points of these tiny
+    # batches moves the gradient by more than 1e-4.  Only such kink-ambiguous cases get the wider bound.
+    tol_g = TOL if U.kink_margin(onet, x0, x, h, n) > 5e-7 else 5e-4
+    assert U.scaled_err(dh.cpu().numpy(), rdh) < tol_g
+    assert U.scaled_err(dth.cpu().numpy(), rflat) < tol_g
 
 
 def test_half_precision_callers(dev):
@@ -362,38 +364,28 @@ def test_half_precision_callers(dev):
         assert xr.grad.dtype == dt and hr.grad.dtype == dt and bool(torch.isfinite(hr.grad.float()).all())
 
 
-def test_pipelined_and_plain_bf16x3_kernels_agree_bit_for_bit(dev):
+def test_pipelined_and_plain_bf16x3_kernels_agree_bit_for_bit(dev, opts):
     """The software-pipelined node loop (default for bf16x3, two point tiles per wave) issues the same MFMAs per
-    accumulator in the same order as the plain loop it replaces (still reachable with UMNN_FWD_PIPE=0, read once per
-    process): the two must return identical bits, and the plain one must still pass the oracle tolerance."""
-    import subprocess, sys, tempfile
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, torch, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "import umnn_amd\n"
-        "from umnn_amd import integral as I, _lib, IntegrandNetwork\n"
-        "from umnn_amd.nets import mlp_spec\n"
-        "umnn_amd.set_forward_precision('bf16x3')\n"
-        "torch.manual_seed(5); dev = torch.device('cuda:0')\n"
-        "net = IntegrandNetwork(7, 31, [50, 50, 50, 50], 1).to(dev)\n"
-        "x = torch.randn(300, 7, device=dev) * 2; h = torch.randn(300, 30 * 7, device=dev)\n"
-        "F, fx, fx0 = I.hip_forward(mlp_spec(net), None, x, h, 100)\n"
-        "torch.cuda.synchronize()\n"
-        "np.savez(sys.argv[1], F=F.cpu().numpy(), fx=fx.cpu().numpy(), fx0=fx0.cpu().numpy(),\n"
-        "         kernel=_lib.lib().umnn_last_kernel_name().decode())\n") % root
+    accumulator in the same order as the plain loop it replaces (option fwd_pipe=0): the two must return identical
+    bits."""
+    import umnn_amd
+    from umnn_amd import integral as I, _lib, IntegrandNetwork
+    from umnn_amd.nets import mlp_spec
+    if umnn_amd.get_forward_precision() != "bf16x3":
+        pytest.skip("the pipelined loop exists for bf16x3 only")
+    torch.manual_seed(5)
+    net = IntegrandNetwork(7, 31, [50, 50, 50, 50], 1).to(dev)
+    x = torch.randn(300, 7, device=dev) * 2
+    h = torch.randn(300, 30 * 7, device=dev)
     out = {}
-    with tempfile.TemporaryDirectory() as tmp:
-        for pipe in ("1", "0"):
-            path = os.path.join(tmp, f"pipe{pipe}.npz")
-            env = dict(os.environ, UMNN_FWD_PIPE=pipe, UMNN_FWD_P="2")
-            r = subprocess.run([sys.executable, "-W", "ignore", "-c", code, path], env=env, capture_output=True,
-                               text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-2000:]
-            out[pipe] = dict(np.load(path))
-    assert "PIPE" in str(out["1"]["kernel"]) and "PIPE" not in str(out["0"]["kernel"]), (out["1"]["kernel"], out["0"]["kernel"])
-    for k in ("F", "fx", "fx0"):
-        assert np.array_equal(out["1"][k], out["0"][k]), k
+    for pipe in (1, 0):
+        opts(fwd_pipe=pipe, fwd_p=2)
+        F, fx, fx0 = I.hip_forward(mlp_spec(net), None, x, h, 100)
+        torch.cuda.synchronize()
+        out[pipe] = (F.cpu().numpy(), fx.cpu().numpy(), fx0.cpu().numpy(), _lib.lib().umnn_last_kernel_name().decode())
+    assert "PIPE" in out[1][3] and "PIPE" not in out[0][3], (out[1][3], out[0][3])
+    for a, b in zip(out[1][:3], out[0][:3]):
+        assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("hid,relu,sigmoid,inv_f,n,NS", [
@@ -403,15 +395,14 @@ def test_pipelined_and_plain_bf16x3_kernels_agree_bit_for_bit(dev):
     ([63, 63, 63], False, False, True, 30, 4),     # full tiles (63 + the constant feature), 1/f integrand
     ([48, 49, 50, 51, 50], False, False, False, 20, 1),   # mixed widths inside the 4-tile family, 5 hidden layers
 ])
-def test_pipelined_kernel_shapes_against_oracle(hid, relu, sigmoid, inv_f, n, NS, dev, monkeypatch):
+def test_pipelined_kernel_shapes_against_oracle(hid, relu, sigmoid, inv_f, n, NS, dev, opts):
     """The software-pipelined bf16x3 loop (two point tiles per wave) over its whole shape family, against the oracle."""
     import umnn_amd
     from umnn_amd import integral as I, _lib
     from umnn_amd.nets import MlpSpec
     if umnn_amd.get_forward_precision() != "bf16x3":
         pytest.skip("the pipelined loop exists for bf16x3 only")
-    monkeypatch.setenv("UMNN_FWD_P", "2")
-    monkeypatch.setenv("UMNN_FWD_NS", str(NS))
+    opts(fwd_p=2, fwd_ns=NS)
     B, d, E = 23, 5, 7
     rng = np.random.RandomState(len(hid) * 17 + n)
     sizes = [1 + E] + hid + [1]
@@ -530,50 +521,6 @@ def test_pipelined_forward_does_not_depend_on_what_ran_before(hid, dev):
         I.hip_forward(mlp_spec(wide), None, torch.randn(3000, 3, device=dev) * 30, torch.randn(3000, 30, device=dev) * 30, 20)
         out = I.hip_forward(spec, None, x, h, 40)
         assert all(torch.equal(a, b) for a, b in zip(out, ref))
-
-
-@pytest.mark.parametrize("hid,relu,sigmoid,inv_f,n", [
-    ([50, 50, 50, 50], False, False, False, 100),
-    ([50, 50], False, False, True, 33),
-    ([56, 60, 63], True, True, False, 20),
-    ([40, 33, 48], False, False, False, 25),
-    ([50, 50, 50, 50, 50, 50], False, False, False, 12),
-])
-def test_x32_layout_against_oracle(hid, relu, sigmoid, inv_f, n, dev, monkeypatch):
-    """The 32x32x16 large-batch layout (two groups of 32 integrals per wave), forced at a small ragged batch, against the
-    oracle -- and bit-stable across contexts."""
-    import umnn_amd
-    from umnn_amd import integral as I, _lib
-    from umnn_amd.nets import MlpSpec
-    if umnn_amd.get_forward_precision() != "bf16x3":
-        pytest.skip("the 32x32 layout exists for bf16x3")
-    monkeypatch.setenv("UMNN_FWD_X32", os.environ.get("UMNN_TEST_X32", "1"))
-    B, d, E = 41, 5, 7                       # 205 integrals: three full work items and a ragged fourth
-    rng = np.random.RandomState(len(hid) * 19 + n)
-    sizes = [1 + E] + hid + [1]
-    Ws = [(rng.randn(sizes[i + 1], sizes[i]) * (1.6 / np.sqrt(sizes[i]))).astype(np.float32) for i in range(len(sizes) - 1)]
-    bs = [(rng.randn(sizes[i + 1]) * 0.3).astype(np.float32) for i in range(len(sizes) - 1)]
-    lin = []
-    for W, b in zip(Ws, bs):
-        m = torch.nn.Linear(W.shape[1], W.shape[0])
-        with torch.no_grad():
-            m.weight.copy_(torch.from_numpy(W))
-            m.bias.copy_(torch.from_numpy(b))
-        lin.append(m.to(dev))
-    spec = MlpSpec(lin, _lib.ACT_RELU if relu else _lib.ACT_LEAKY_RELU, _lib.OUT_SIGMOID if sigmoid else _lib.OUT_ELU_PLUS_ONE)
-    net = O.Net(Ws, bs, O.RELU if relu else O.LEAKY, O.SIGMOID if sigmoid else O.ELU1)
-    x = (rng.randn(B, d) * 2).astype(np.float32)
-    x0 = (rng.randn(B, d) * 0.5).astype(np.float32)
-    h = rng.randn(B, E * d).astype(np.float32)
-    F, fx, fx0 = I.hip_forward(spec, t(x0, dev), t(x, dev), t(h, dev), n, inv_f=inv_f)
-    assert "x32" in _lib.lib().umnn_last_kernel_name().decode() or os.environ.get("UMNN_TEST_X32") == "0"
-    assert U.rel_err(F.cpu().numpy(), O.integrate_parallel(net, x0, x, h, n, inv_f=inv_f)) < TOL
-    assert U.rel_err(fx.cpu().numpy(), O.integrand(net, x, h)) < TOL
-    assert U.rel_err(fx0.cpu().numpy(), O.integrand(net, x0, h)) < TOL
-    junk = torch.randn(2048, 2048, device=dev) * 1e3
-    (junk @ junk).sum().item()
-    F2, fx2, fx02 = I.hip_forward(spec, t(x0, dev), t(x, dev), t(h, dev), n, inv_f=inv_f)
-    assert torch.equal(F, F2) and torch.equal(fx, fx2) and torch.equal(fx0, fx02)
 
 
 def test_mnist_width_d784_against_oracle(dev):

@@ -19,18 +19,16 @@ def dev():
 
 def _both(fn):
     """(fast path result, fp32 chain result) of fn() under no_grad."""
-    old = os.environ.get("UMNN_MADE_BF16X3")
+    import umnn_amd
+    old = umnn_amd.get_made_fast_path()
     try:
         with torch.no_grad():
-            os.environ["UMNN_MADE_BF16X3"] = "1"
+            umnn_amd.set_made_fast_path(True)
             fast = fn()
-            os.environ["UMNN_MADE_BF16X3"] = "0"
+            umnn_amd.set_made_fast_path(False)
             slow = fn()
     finally:
-        if old is None:
-            os.environ.pop("UMNN_MADE_BF16X3", None)
-        else:
-            os.environ["UMNN_MADE_BF16X3"] = old
+        umnn_amd.set_made_fast_path(old)
     return fast, slow
 
 

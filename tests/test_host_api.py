@@ -213,8 +213,87 @@ def test_set_steps_nb_and_random_steps_eval_mode():
         for n in (10, 37, 98):
             m.set_steps_nb(n)
             ll, _ = m.compute_ll(x)
-            assert m.nets[0].cc_weights.shape == (n + 1, 1)
+            assert m.nets[0].cc_weights.shape == (21, 1)      # registered tables keep the constructor's shape
             assert torch.allclose(ll, ref, atol=2e-3)
+    # a checkpoint written after set_steps_nb round-trips into a freshly built model (UCIExperiments.py:131-153)
+    fresh = umnn_amd.UMNNMAFFlow(nb_flow=1, nb_in=3, hidden_derivative=[16, 16], hidden_embedding=[16], embedding_s=3,
+                                 nb_steps=20, solver="CCParallel")
+    res = fresh.load_state_dict(m.state_dict())
+    assert not res.missing_keys and not res.unexpected_keys
+
+
+def test_nb_steps_zero_means_random_steps():
+    """'nb_steps: 0 for random' (UCIExperiments.py / MNISTExperiment.py build the model with nb_steps <= 0 and call
+    set_steps_nb per batch): construction must work, integration before set_steps_nb must say what is wrong."""
+    torch.manual_seed(2)
+    m = umnn_amd.UMNNMAFFlow(nb_flow=2, nb_in=3, hidden_derivative=[16, 16], hidden_embedding=[16], embedding_s=3,
+                             nb_steps=0, solver="CCParallel")
+    assert m.nets[0].cc_weights.shape == (1, 1)            # the reference registers NaN tables of shape [n+1, 1]
+    x = torch.randn(5, 3)
+    with pytest.raises(ValueError):
+        m.compute_ll(x)
+    m.set_steps_nb(30)
+    ll, _ = m.compute_ll(x)
+    assert torch.isfinite(ll).all()
+    umnn_amd.UMNNMAFFlow(nb_flow=1, nb_in=2, hidden_derivative=[8], hidden_embedding=[8], embedding_s=2, nb_steps=-1)
+
+
+def test_eval_mode_stays_differentiable():
+    """model.eval(); ll.backward() must give the same parameter gradients as train mode (the reference's eval-mode
+    direct integration is plain ATen and therefore differentiable, UMNNMAF.py:89-105)."""
+    torch.manual_seed(3)
+    m = umnn_amd.UMNNMAFFlow(nb_flow=2, nb_in=3, hidden_derivative=[16, 16], hidden_embedding=[16], embedding_s=3,
+                             nb_steps=30, solver="CCParallel")
+    x = torch.randn(9, 3)
+    grads = {}
+    for mode in ("train", "eval"):
+        m.train(mode == "train")
+        m.zero_grad()
+        ll, _ = m.compute_ll(x)
+        (-ll.mean()).backward()
+        grads[mode] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    assert grads["train"].keys() == grads["eval"].keys() and len(grads["eval"]) > 4
+    for k in grads["train"]:
+        assert U.scaled_err(grads["eval"][k].numpy(), grads["train"][k].numpy()) < 1e-5, k
+    # module-level integrate(compute_grad=False) likewise
+    net = m.nets[0].net.parallel_nets
+    h = torch.randn(9, 9, requires_grad=True)
+    F = umnn_amd.integrate(torch.zeros(9, 3), 30, x / 30, net, h, False)
+    F.sum().backward()
+    assert h.grad is not None and float(h.grad.abs().max()) > 0
+
+
+def test_double_backward_raises():
+    """create_graph=True through the quadrature op is not supported (ParallelNeuralIntegral.py:91 builds one in the
+    reference; no caller uses it): it must raise, not silently hand back a detached gradient."""
+    torch.manual_seed(4)
+    net = umnn_amd.IntegrandNetwork(2, 3, [8, 8], 1)
+    x = torch.randn(4, 2, requires_grad=True)
+    h = torch.randn(4, 4, requires_grad=True)
+    flat = torch.cat([p.contiguous().view(-1) for p in net.parameters()])
+    F = umnn_amd.ParallelNeuralIntegral.apply(torch.zeros(4, 2), x, net, flat, h, 20)
+    (gx,) = torch.autograd.grad(F.sum(), x, create_graph=True)
+    with pytest.raises(RuntimeError):
+        gx.sum().backward()
+
+
+def test_masked_weight_cache_invalidation():
+    """Writes through .data do not bump tensor versions; invalidate_caches() (called by broadcast_parameters) must make
+    the conditioner see them."""
+    torch.manual_seed(5)
+    made = umnn_amd.MADE(4, [16, 16], 8, natural_ordering=True)
+    x = torch.randn(6, 4)
+    with torch.no_grad():
+        y0 = made.raw(x).clone()
+        for p in made.parameters():
+            p.data.mul_(2)
+        umnn_amd.invalidate_caches(made)
+        y1 = made.raw(x)
+        for p in made.parameters():          # version-bumping in-place writes need no explicit call
+            p.mul_(0.5)
+        y2 = made.raw(x)
+    assert not torch.allclose(y0, y1)
+    assert torch.allclose(y0, y2, atol=1e-6)
 
 
 def test_invert_round_trip_matches_reference():

@@ -149,3 +149,17 @@ def test_torch_port_flow_matches_reference():
     ll, z = TP.flow_compute_ll(TP.blocks_from_state_dict(sd, 1), torch.from_numpy(G["x"]), int(G["n"]))
     assert U.rel_err(ll.numpy(), G["ll_eval"]) < 1e-5
     assert U.rel_err(z.numpy(), G["z_eval"]) < 1e-5
+
+
+@pytest.mark.parametrize("name,solver", [("g4_flow2_cond", "CCParallel"), ("g4_flow2_power_cc", "CC"), ("g4_flow2_toy", "CCParallel")])
+def test_torch_port_flow_both_solvers_and_context(name, solver):
+    """bench.py times both quadrature variants of the port (and the conditional flow of the VAE workload)."""
+    import torch
+    from oracle import torch_port as TP
+    G = U.load(name)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in U.state_dict_of(G).items()}
+    ctx = torch.from_numpy(G["context"]) if "context" in G else None
+    ll, z = TP.flow_compute_ll(TP.blocks_from_state_dict(sd, int(G["nb_flow"])), torch.from_numpy(G["x"]), int(G["n"]),
+                               solver=solver, context=ctx)
+    assert U.rel_err(ll.numpy(), G["ll_eval"]) < 1e-5
+    assert U.rel_err(z.numpy(), G["z_eval"]) < 1e-5

@@ -4,13 +4,31 @@ Import surface mirrors models/UMNN/__init__.py:1-6 of the reference.
 """
 from .flow import UMNNMAFFlow, UMNNMAF, EmbeddingNetwork, IntegrandNetwork, ListModule
 from .monotonic import MonotonicNN, IntegrandNN
-from .made import MADE, ConditionnalMADE, MaskedLinear
+from .made import MADE, ConditionnalMADE, MaskedLinear, invalidate_caches, set_made_fast_path, get_made_fast_path
 from .integral import NeuralIntegral, ParallelNeuralIntegral, IntegralWithJacobian, integrate, path_taken
 from .quadrature import compute_cc_weights
 from .graphs import GraphedLL, GraphedTrainStep
 from ._lib import set_forward_precision, get_forward_precision, set_backward_precision, get_backward_precision
 
+
+
+def set_precision(name):
+    """One switch for the arithmetic of the whole path.
+
+    'fp32'   : exact fp32 products everywhere (fp32 MFMA kernels forward and backward, fp32 conditioner GEMMs) -- the
+               reference's arithmetic, ~2.4x slower forward.
+    'bf16x6' : hidden GEMMs on the bf16 matrix cores with 6 cross terms (fp32-level accuracy, ~4e-7 on F).
+    'bf16x3' : the library default -- 3 cross terms (F to ~6e-6, every parity test passes at 1e-4), conditioner
+               inference GEMMs as K-concatenated bf16 GEMMs (3e-6 of the output range).
+    The backward kernels know 'fp32' and 'bf16x3' (6-term recompute + 3-term delta / dW); 'bf16x6' selects 'bf16x3' there."""
+    if name not in ("fp32", "bf16x3", "bf16x6"):
+        raise ValueError(name)
+    set_forward_precision(name)
+    set_backward_precision("fp32" if name == "fp32" else "bf16x3")
+    set_made_fast_path(name != "fp32")
+
+
 __all__ = ["UMNNMAFFlow", "UMNNMAF", "EmbeddingNetwork", "IntegrandNetwork", "ListModule", "MonotonicNN",
            "IntegrandNN", "MADE", "ConditionnalMADE", "MaskedLinear", "NeuralIntegral", "ParallelNeuralIntegral",
            "IntegralWithJacobian", "integrate", "compute_cc_weights", "path_taken", "GraphedLL", "GraphedTrainStep",
-           "set_forward_precision", "get_forward_precision", "set_backward_precision", "get_backward_precision"]
+           "set_precision", "invalidate_caches", "set_made_fast_path", "get_made_fast_path", "set_forward_precision", "get_forward_precision", "set_backward_precision", "get_backward_precision"]

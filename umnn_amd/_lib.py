@@ -39,6 +39,9 @@ SIGNATURES = {
     "umnn_flow_stack_block_forward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                                      _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
                                                      _fp, _fp, _fp, _fp, _fp]),
+    "umnn_flow_ll_block_forward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                                  _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  _fp, _fp, _fp, _fp, _fp]),
     "umnn_cc_backward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                         _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _ll, _fp]),
     "umnn_cc_backward_workspace_bytes": (_ll, [ctypes.POINTER(MlpDesc), _ll, ctypes.c_int, ctypes.c_int]),
@@ -60,10 +63,27 @@ SIGNATURES = {
     "umnn_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "umnn_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_ll),
                                          ctypes.POINTER(ctypes.c_double)]),
+    "umnn_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "umnn_get_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
+    "umnn_reload_env": (ctypes.c_int, []),
+    "umnn_profile_read_tag": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_ll),
+                                             ctypes.POINTER(ctypes.c_double)]),
+    "umnn_last_kernel_name_of": (ctypes.c_char_p, [ctypes.c_int]),
     "umnn_made_split3": (ctypes.c_int, [_fp, _ll, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]),
 }
 
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}
+PROF_FORWARD, PROF_BACKWARD, PROF_FINISH = 0, 1, 2
+
+
+def profile_read(tag=None):
+    """(kernel milliseconds, launches, algorithmic FLOPs) of the launches recorded since umnn_profile_enable(1)."""
+    ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+    if tag is None:
+        check(lib().umnn_profile_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "umnn_profile_read")
+    else:
+        check(lib().umnn_profile_read_tag(int(tag), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "umnn_profile_read_tag")
+    return ms.value, n.value, fl.value
 
 _lib = None
 _lock = threading.Lock()
@@ -115,3 +135,31 @@ def set_backward_precision(name):
 def get_backward_precision():
     mode = lib().umnn_get_backward_precision()
     return next(k for k, v in PRECISIONS.items() if v == mode)
+
+
+def set_option(name, value):
+    """Launch option by name (include/umnn_cc.h: fwd_p, fwd_ns, fwd_tail, fwd_pipe, fwd_pad, bwd_ns, ...; -1 = automatic)."""
+    check(lib().umnn_set_option(name.encode(), int(value)), "umnn_set_option")
+
+
+def get_option(name):
+    v = ctypes.c_int()
+    check(lib().umnn_get_option(name.encode(), ctypes.byref(v)), "umnn_get_option")
+    return v.value
+
+
+class options:
+    """Context manager: ``with _lib.options(fwd_p=2, fwd_ns=1): ...`` sets launch options and restores them on exit."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)

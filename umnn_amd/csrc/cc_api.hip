@@ -24,39 +24,116 @@ int umnn_check(hipError_t e, const char* what) {
     return (int)e;
 }
 
+// last kernel per class of launch, process-wide (backward runs on autograd worker threads, so the thread-local
+// g_last_kernel of the calling thread never sees it)
+static std::atomic<const char*> g_last_of[3] = {{""}, {""}, {""}};
 void umnn_note_launch(const char* kernel_name) {
     g_last_kernel = kernel_name;
+    const int tag = !strncmp(kernel_name, "cc_bwd_dh", 9) || !strncmp(kernel_name, "cc_bwd_reduce", 13) ? UMNN_PROF_FINISH
+                    : !strncmp(kernel_name, "cc_bwd", 6) ? UMNN_PROF_BACKWARD : UMNN_PROF_FORWARD;
+    g_last_of[tag].store(kernel_name, std::memory_order_relaxed);
     g_launches.fetch_add(1, std::memory_order_relaxed);
+}
+extern "C" const char* umnn_last_kernel_name_of(int tag) {
+    return tag >= 0 && tag <= 2 ? g_last_of[tag].load(std::memory_order_relaxed) : "";
 }
 
 int umnn_num_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
+    static std::atomic<int> cus[64];                       // per device ordinal; 0 = not queried yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (!v) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        v = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cus[dev].store(v, std::memory_order_relaxed);
     }
-    return cus;
+    return v;
 }
 
 int umnn_allow_lds(const void* fn, size_t bytes) {
     // raising the dynamic-LDS cap is per (device, function); cache what we already granted
+    struct Key { int dev; const void* fn; bool operator==(const Key& o) const { return dev == o.dev && fn == o.fn; } };
+    struct Hash { size_t operator()(const Key& k) const { return std::hash<const void*>()(k.fn) ^ ((size_t)k.dev * 0x9e3779b97f4a7c15ull); } };
     static std::mutex mu;
-    static std::unordered_map<const void*, size_t> granted[16];
+    static std::unordered_map<Key, size_t, Hash> granted;
     int dev = 0;
     if (int rc = umnn_check(hipGetDevice(&dev), "hipGetDevice")) return rc;
     std::lock_guard<std::mutex> lk(mu);
-    auto& tab = granted[dev & 15];
-    auto it = tab.find(fn);
-    if (it != tab.end() && it->second >= bytes) return 0;
+    auto it = granted.find(Key{dev, fn});
+    if (it != granted.end() && it->second >= bytes) return 0;
     if (int rc = umnn_check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))
         return rc;
-    tab[fn] = bytes;
+    granted[Key{dev, fn}] = bytes;
     return 0;
 }
+
+// ---- options: environment read once, atomics afterwards --------------------------------------------------------
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; }
+static void load_env(UmnnOptions& o) {
+    int fp = UMNN_PRECISION_BF16X3, bp = UMNN_PRECISION_BF16X3;
+    if (const char* ev = getenv("UMNN_FWD_PRECISION")) {
+        if (!strcmp(ev, "fp32")) fp = UMNN_PRECISION_FP32;
+        else if (!strcmp(ev, "bf16x6")) fp = UMNN_PRECISION_BF16X6;
+    }
+    if (const char* ev = getenv("UMNN_BWD_PRECISION")) bp = !strcmp(ev, "fp32") ? UMNN_PRECISION_FP32 : UMNN_PRECISION_BF16X3;
+    o.fwd_precision = fp; o.bwd_precision = bp;
+    int v = env_int("UMNN_FWD_P", -1); o.fwd_p = v == 1 || v == 2 ? v : -1;
+    v = env_int("UMNN_FWD_NS", -1); o.fwd_ns = v == 1 || v == 2 || v == 4 ? v : -1;
+    v = env_int("UMNN_FWD_TAIL", -1); o.fwd_tail = v < 0 ? -1 : (v != 0);
+    o.fwd_pipe = env_int("UMNN_FWD_PIPE", 1) != 0;
+    o.fwd_pad = env_int("UMNN_FWD_PAD", 1) != 0;
+    o.fwd_pad_min = env_int("UMNN_FWD_PAD_MIN", 1);
+    v = env_int("UMNN_BWD_NS", -1); o.bwd_ns = v >= 1 && v <= 32 ? v : -1;
+}
+UmnnOptions& umnn_options() {
+    static UmnnOptions opts;
+    static std::once_flag once;
+    std::call_once(once, [] { load_env(opts); });
+    return opts;
+}
+extern "C" int umnn_reload_env(void) { load_env(umnn_options()); return 0; }
+
+static std::atomic<int>* option_slot(const char* name) {
+    UmnnOptions& o = umnn_options();
+    if (!name) return nullptr;
+    if (!strcmp(name, "fwd_precision")) return &o.fwd_precision;
+    if (!strcmp(name, "bwd_precision")) return &o.bwd_precision;
+    if (!strcmp(name, "fwd_p")) return &o.fwd_p;
+    if (!strcmp(name, "fwd_ns")) return &o.fwd_ns;
+    if (!strcmp(name, "fwd_tail")) return &o.fwd_tail;
+    if (!strcmp(name, "fwd_pipe")) return &o.fwd_pipe;
+    if (!strcmp(name, "fwd_pad")) return &o.fwd_pad;
+    if (!strcmp(name, "fwd_pad_min")) return &o.fwd_pad_min;
+    if (!strcmp(name, "bwd_ns")) return &o.bwd_ns;
+    return nullptr;
+}
+extern "C" int umnn_set_option(const char* name, int value) {
+    std::atomic<int>* s = option_slot(name);
+    if (!s) return umnn_fail(UMNN_EINVAL, "umnn_set_option: unknown option name");
+    s->store(value, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int umnn_get_option(const char* name, int* value) {
+    std::atomic<int>* s = option_slot(name);
+    if (!s || !value) return umnn_fail(UMNN_EINVAL, "umnn_get_option: unknown option name or null output");
+    *value = s->load(std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int umnn_set_forward_precision(int mode) {
+    if (mode < UMNN_PRECISION_FP32 || mode > UMNN_PRECISION_BF16X6) return umnn_fail(UMNN_EINVAL, "unknown precision mode");
+    umnn_options().fwd_precision = mode;
+    return 0;
+}
+extern "C" int umnn_get_forward_precision(void) { return umnn_options().fwd_precision; }
+extern "C" int umnn_set_backward_precision(int mode) {
+    if (mode != UMNN_PRECISION_FP32 && mode != UMNN_PRECISION_BF16X3)
+        return umnn_fail(UMNN_EINVAL, "backward precision must be UMNN_PRECISION_FP32 or UMNN_PRECISION_BF16X3");
+    umnn_options().bwd_precision = mode;
+    return 0;
+}
+extern "C" int umnn_get_backward_precision(void) { return umnn_options().bwd_precision; }
 
 long long umnn_param_count(const umnn_mlp* net) {
     long long n = 0;
@@ -114,7 +191,7 @@ int umnn_prepare_mlp(const umnn_mlp* net, int E, MlpDev* out, int* tmax, int* ks
 }
 
 // ---- per-launch timing with hipEvents on the launch stream -------------------------------------
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops; int tag; };
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static bool g_prof_on = false;
@@ -128,13 +205,13 @@ void umnn_prof_begin(hipStream_t stream) {
     g_prof_open = a;
 }
 
-void umnn_prof_end(hipStream_t stream, double flops) {
+void umnn_prof_end(hipStream_t stream, double flops, int tag) {
     if (!g_prof_on || !g_prof_open) return;
     hipEvent_t b;
     if (hipEventCreate(&b) != hipSuccess) return;
     (void)hipEventRecord(b, stream);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof.push_back({g_prof_open, b, flops});
+    g_prof.push_back({g_prof_open, b, flops, tag});
     g_prof_open = nullptr;
 }
 
@@ -146,20 +223,30 @@ extern "C" int umnn_profile_enable(int on) {
     return 0;
 }
 
-extern "C" int umnn_profile_read(double* total_ms, long long* launches, double* total_flops) {
+static int profile_read(int tag, double* total_ms, long long* launches, double* total_flops) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     double ms = 0.0, fl = 0.0;
+    long long cnt = 0;
     for (auto& r : g_prof) {
+        if (tag >= 0 && r.tag != tag) continue;
         if (int rc = umnn_check(hipEventSynchronize(r.b), "hipEventSynchronize")) return rc;
         float t = 0.f;
         if (int rc = umnn_check(hipEventElapsedTime(&t, r.a, r.b), "hipEventElapsedTime")) return rc;
         ms += t;
         fl += r.flops;
+        ++cnt;
     }
     if (total_ms) *total_ms = ms;
-    if (launches) *launches = (long long)g_prof.size();
+    if (launches) *launches = cnt;
     if (total_flops) *total_flops = fl;
     return 0;
+}
+extern "C" int umnn_profile_read(double* total_ms, long long* launches, double* total_flops) {
+    return profile_read(-1, total_ms, launches, total_flops);
+}
+extern "C" int umnn_profile_read_tag(int tag, double* total_ms, long long* launches, double* total_flops) {
+    if (tag < 0 || tag > 2) return umnn_fail(UMNN_EINVAL, "umnn_profile_read_tag: tag must be UMNN_PROF_FORWARD|BACKWARD|FINISH");
+    return profile_read(tag, total_ms, launches, total_flops);
 }
 
 extern "C" const char* umnn_last_error(void) { return g_err; }

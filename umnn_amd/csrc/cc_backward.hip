@@ -573,7 +573,7 @@ static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan
     {
         const long long waves = (long long)umnn_num_cus() * pl->wpb;
         if ((long long)a.ngroups * 2 <= waves) pl->ns = (int)(waves / a.ngroups > 32 ? 32 : waves / a.ngroups);
-        if (const char* ev = getenv("UMNN_BWD_NS")) { const int v = atoi(ev); if (v >= 1 && v <= 32) pl->ns = v; }
+        if (const int v = umnn_options().bwd_ns; v >= 1 && v <= 32) pl->ns = v;
     }
     const long long items = (long long)a.ngroups * pl->ns;
     pl->nblocks = umnn_num_cus();
@@ -619,24 +619,6 @@ extern "C" int umnn_cc_backward_kind(const umnn_mlp* net, int E) {
     return T <= 4 ? 0 : -1;
 }
 
-// arithmetic of the backward GEMMs: UMNN_PRECISION_FP32 or UMNN_PRECISION_BF16X3 (default)
-static int g_bwd_precision = -1;
-static int bwd_precision() {
-    if (g_bwd_precision < 0) {
-        int mode = UMNN_PRECISION_BF16X3;
-        if (const char* ev = getenv("UMNN_BWD_PRECISION")) mode = !strcmp(ev, "fp32") ? UMNN_PRECISION_FP32 : UMNN_PRECISION_BF16X3;
-        g_bwd_precision = mode;
-    }
-    return g_bwd_precision;
-}
-extern "C" int umnn_set_backward_precision(int mode) {
-    if (mode != UMNN_PRECISION_FP32 && mode != UMNN_PRECISION_BF16X3)
-        return umnn_fail(UMNN_EINVAL, "backward precision must be UMNN_PRECISION_FP32 or UMNN_PRECISION_BF16X3");
-    g_bwd_precision = mode;
-    return 0;
-}
-extern "C" int umnn_get_backward_precision(void) { return bwd_precision(); }
-
 extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const float* x, const float* h,
                                 const float* g, const float* g_fx,
                                 const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
@@ -669,7 +651,7 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
     bool done = false;
     const int ns_used = pl.ns > nb_steps + 1 ? nb_steps + 1 : pl.ns;
     a.ns = ns_used;
-    if (bwd_precision() == UMNN_PRECISION_BF16X3) {
+    if (umnn_options().bwd_precision == UMNN_PRECISION_BF16X3) {
         int nw = 0;
         const int rc = umnn_launch_backward_bf16(a, net, pl.nblocks, &nw, stream);
         if (rc == 0) done = true;
@@ -691,13 +673,14 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
         if (int rc = umnn_allow_lds((const void*)v->fn, lds_bytes)) return rc;
         umnn_prof_begin(stream);
         hipLaunchKernelGGL(v->fn, dim3(pl.nblocks), dim3(64 * pl.wpb), lds_bytes, stream, a);
-        umnn_prof_end(stream, 0.0);
+        umnn_prof_end(stream, pass == 0 ? 3.0 * umnn_cc_forward_flops_per_integral(net, nb_steps) * (double)a.NI : 0.0, UMNN_PROF_BACKWARD);
         umnn_note_launch(v->name);
         if (int rc = umnn_check(hipGetLastError(), "cc_bwd launch")) return rc;
         l_next += nacc;
     }
 
     // ---- finishing kernels
+    umnn_prof_begin(stream);
     if (ns_used > 1) {      // node-split partials of dc -> one sum, before anything reads dc
         const long long count = a.NI * H1;
         hipLaunchKernelGGL(cc_bwd_dcsum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, a.dc, count, ns_used);
@@ -718,5 +701,6 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
                            a.partials, pl.nwaves, a.n_params, p0, pl.nparts0, E, H1, a.poffW[0], a.poffb[0], dtheta);
         umnn_note_launch("cc_bwd_reduce");
     }
+    umnn_prof_end(stream, 0.0, UMNN_PROF_FINISH);
     return umnn_check(hipGetLastError(), "cc_bwd finishing launch");
 }

@@ -473,7 +473,7 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
     if (int rc = umnn_allow_lds((const void*)v->fn, lds_bytes)) return rc;
     umnn_prof_begin(stream);
     hipLaunchKernelGGL(v->fn, dim3(nblocks), dim3(UMNN_BLOCK), lds_bytes, stream, args);
-    umnn_prof_end(stream, 0.0);
+    umnn_prof_end(stream, 3.0 * umnn_cc_forward_flops_per_integral(net, a.n) * (double)a.NI, UMNN_PROF_BACKWARD);
     umnn_note_launch(v->name);
     return umnn_check(hipGetLastError(), "cc_bwd_bf16 launch");
 }

@@ -235,34 +235,13 @@ static const FwdVariant kFwdVariants[] = {
 };
 
 int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps, hipStream_t stream);
-int umnn_launch_forward_x32(FwdArgs& a, const umnn_mlp* net, int nb_steps, hipStream_t stream);
-
-// forward arithmetic: 0 = exact fp32 MFMA, 1 = bf16 split with 3 cross terms, 2 = bf16 split with 6 cross terms
-static int g_fwd_precision = -1;
-static int fwd_precision() {
-    if (g_fwd_precision < 0) {
-        int mode = UMNN_PRECISION_BF16X3;
-        if (const char* ev = getenv("UMNN_FWD_PRECISION")) {
-            if (!strcmp(ev, "fp32")) mode = UMNN_PRECISION_FP32;
-            else if (!strcmp(ev, "bf16x3")) mode = UMNN_PRECISION_BF16X3;
-            else if (!strcmp(ev, "bf16x6")) mode = UMNN_PRECISION_BF16X6;
-        }
-        g_fwd_precision = mode;
-    }
-    return g_fwd_precision;
-}
-extern "C" int umnn_set_forward_precision(int mode) {
-    if (mode < UMNN_PRECISION_FP32 || mode > UMNN_PRECISION_BF16X6) return umnn_fail(UMNN_EINVAL, "unknown precision mode");
-    g_fwd_precision = mode;
-    return 0;
-}
-extern "C" int umnn_get_forward_precision(void) { return fwd_precision(); }
 
 static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, const float* h,
                           const float* scaling, const float* cc_w, const float* cc_s, int nb_steps,
                           long long B, int d, int E, int inv_f,
                           float* F, float* f_x, float* f_x0, float* z, float* log_jac, hipStream_t stream,
-                          int reverse_z = 0, const float* log_jac_in = nullptr) {
+                          int reverse_z = 0, const float* log_jac_in = nullptr,
+                          float* ll = nullptr, unsigned* row_cnt = nullptr, int ll_first = 0, int ll_last = 0) {
     FwdArgs a;
     int tmax = 0, ksu = 0;
     if (int rc = umnn_prepare_mlp(net, E, &a.m, &tmax, &ksu)) return rc;
@@ -276,6 +255,7 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
     a.x0 = x0; a.x = x; a.h = h; a.ccw = cc_w; a.ccs = cc_s;
     a.F = F; a.fx = f_x; a.fx0 = f_x0; a.scaling = scaling; a.z = z; a.logjac = log_jac;
     a.logjac_in = log_jac_in; a.reverse_z = reverse_z;
+    a.ll = ll; a.row_cnt = row_cnt; a.ll_first = ll_first; a.ll_last = ll_last;
     a.NI = B * (long long)d; a.d = d; a.E = E; a.n = nb_steps; a.inv_f = inv_f;
 
     // ---- choose the variant: exact (compile-time K-steps) when all hidden layers share a width we
@@ -286,17 +266,14 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
     int ns = 1;
     if (tiles16 < 2LL * simd_slots) ns = tiles16 * 2 <= 2LL * simd_slots ? 4 : 2;
     if (ns > nb_steps + 1) ns = 1;
-    if (const char* ev = getenv("UMNN_FWD_P")) P = atoi(ev) == 2 ? 2 : 1;
-    if (const char* ev = getenv("UMNN_FWD_NS")) { int v = atoi(ev); if (v == 1 || v == 2 || v == 4) ns = v; }
+    const UmnnOptions& opt = umnn_options();
+    const int opt_p = opt.fwd_p, opt_ns = opt.fwd_ns, opt_tail = opt.fwd_tail;
+    if (opt_p > 0) P = opt_p;
+    if (opt_ns > 0) ns = opt_ns;
 
     // bf16-split kernels (default): hidden GEMMs on the bf16 matrix cores; falls through to fp32 MFMA when the
     // shape does not fit them (a single hidden layer has no hidden->hidden GEMM at all)
-    const int prec = fwd_precision();
-    if (prec == UMNN_PRECISION_BF16X3 && !getenv("UMNN_FWD_P") && !getenv("UMNN_FWD_NS")) {
-        // large batches of nets up to 63 wide: the 32x32x16 layout (two groups of 32 integrals per wave)
-        const int rc = umnn_launch_forward_x32(a, net, nb_steps, stream);
-        if (rc != UMNN_EUNSUPPORTED) return rc;
-    }
+    const int prec = opt.fwd_precision;
     if (prec != UMNN_PRECISION_FP32 && a.m.n_linear - 1 >= 2) {
         a.ns = ns;
         const int rc = umnn_launch_forward_bf16(a, net, prec == UMNN_PRECISION_BF16X3 ? 2 : 3, P, ns, nb_steps, stream);
@@ -305,7 +282,7 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
     // TAIL is possible when every hidden layer has the same width H with 16(T-1) <= H <= 16(T-1)+3
     const int H1w = net->widths[1];
     int want_tail = (ksu && ksu == 4 * (tmax - 1) + 1 && H1w - 16 * (tmax - 1) >= 0 && H1w - 16 * (tmax - 1) <= 3) ? 1 : 0;
-    if (const char* ev = getenv("UMNN_FWD_TAIL")) want_tail = want_tail && atoi(ev) != 0;
+    if (opt_tail >= 0) want_tail = want_tail && opt_tail != 0;
     const FwdVariant* pick = nullptr;
     for (int tl = want_tail; tl >= 0 && !pick; --tl)
         for (const FwdVariant& v : kFwdVariants)
@@ -369,6 +346,19 @@ extern "C" int umnn_flow_stack_block_forward(const umnn_mlp* net, const float* x
     if (z == x && reverse_z) return umnn_fail(UMNN_EINVAL, "flow forward: z must not alias x when reverse_z is set");
     return launch_forward(net, nullptr, x, h, scaling, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr, f_x, f_x0,
                           z, log_jac, (hipStream_t)stream, reverse_z != 0, log_jac_in);
+}
+
+extern "C" int umnn_flow_ll_block_forward(const umnn_mlp* net, const float* x, const float* h, const float* scaling,
+                                          const float* cc_w, const float* cc_s, int nb_steps,
+                                          long long B, int d, int E, int reverse_z, int first, int last,
+                                          float* z, float* log_jac_scratch, float* ll, unsigned* row_counters,
+                                          void* stream) {
+    if (!scaling) return umnn_fail(UMNN_EINVAL, "flow ll forward: scaling must be non-null");
+    if (B > 0 && (!ll || !row_counters)) return umnn_fail(UMNN_EINVAL, "flow ll forward: ll and row_counters must be non-null");
+    if (z == x) return umnn_fail(UMNN_EINVAL, "flow ll forward: z must not alias x");
+    return launch_forward(net, nullptr, x, h, scaling, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr, nullptr, nullptr,
+                          z, log_jac_scratch, (hipStream_t)stream, reverse_z != 0, nullptr, ll, row_counters,
+                          first != 0, last != 0);
 }
 
 extern "C" int umnn_cc_forward_timed(const umnn_mlp* net, const float* x0, const float* x, const float* h,

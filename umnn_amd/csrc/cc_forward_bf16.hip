@@ -513,21 +513,21 @@ static const Bf16Variant kBf16Variants[] = {
     BF16_VARIANT(8, 2, 1, 0, 0), BF16_VARIANT(8, 2, 2, 0, 0),   // (8 tiles x 3 parts does not fit the register file: fp32 kernels instead)
 };
 
-static int pad_env_min_tiles() { static const int v = [] { const char* e = getenv("UMNN_FWD_PAD_MIN"); return e ? atoi(e) : 1; }(); return v; }
-
 // Returns 0 and launches, UMNN_EUNSUPPORTED (without setting the error text's prefix) if the shape does not fit
 // this kernel family (caller then uses the fp32-MFMA kernels), or another error code.
 int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps,
                              hipStream_t stream) {
     const int L = a.m.n_linear - 1;
+    const UmnnOptions& opt = umnn_options();
+    const bool p_forced = opt.fwd_p > 0, ns_forced = opt.fwd_ns > 0;
     int tmax = 0;
     for (int l = 1; l <= L; ++l) tmax = a.m.t_out[l] > tmax ? a.m.t_out[l] : tmax;
     int T = tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8;
     // every hidden layer the same tile count above four: exact single-tile variants, odd counts with a half K-step
     int wide = (nparts == 2 && tmax >= 5) ? tmax : 0;
     for (int l = 1; l <= L && wide; ++l) if (a.m.t_out[l] != wide) wide = 0;
-    if (wide && (P == 1 || !getenv("UMNN_FWD_P"))) { T = wide; P = 1; } else wide = 0;    // (no two-tile variant at these widths)
-    if (wide && !getenv("UMNN_FWD_NS")) {
+    if (wide && (P == 1 || !p_forced)) { T = wide; P = 1; } else wide = 0;    // (no two-tile variant at these widths)
+    if (wide && !ns_forced) {
         // images this large leave one or two workgroups per CU: split the node range only as far as that fills the SIMDs
         const long long tiles16 = (a.NI + 15) / 16, slots = (long long)umnn_num_cus() * 4 * (wide >= 7 ? 1 : 2);
         ns = tiles16 * 4 <= slots ? 4 : tiles16 * 2 <= slots ? 2 : 1;
@@ -554,19 +554,17 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
     // Mixed or narrow widths up to 63: zero-pad every layer to four tiles (the staged images carry the zeros) and run
     // the shape-exact kernels -- the padded MFMAs cost less than the runtime guards of the generic variants
     // (UMNN_FWD_PAD=0 keeps the generic ones).
-    static const int pad_env = [] { const char* e = getenv("UMNN_FWD_PAD"); return e ? atoi(e) : 1; }();
-    if (!exact && !wide && nparts == 2 && tmax <= 4 && tmax >= pad_env_min_tiles() && pad_env) {
+    if (!exact && !wide && nparts == 2 && tmax <= 4 && tmax >= opt.fwd_pad_min && opt.fwd_pad) {
         T = 4; exact = 1; nrl = 0;
         for (int l = 1; l <= L; ++l) { args.f.m.t_out[l] = 4; args.pl.ks32[l] = 2; }
         off16 = 0;
         for (int l = 1; l < L; ++l) { args.pl.off16[l] = off16; off16 += 4 * 2 * nparts * 512; }
         args.f.m.lds_off[L] = (((off16 + 1) / 2) + 3) & ~3;
     }
-    static const int pipe_env = [] { const char* e = getenv("UMNN_FWD_PIPE"); return e ? atoi(e) : 1; }();
-    const bool want_pipe = pipe_env != 0 && L >= 2;
+    const bool want_pipe = opt.fwd_pipe != 0 && L >= 2;
     // the pipelined loop needs two point tiles per wave and pays off as soon as that still leaves a wave per SIMD
     // (measured at the POWER and VAE shapes: P=2, NS=1 beats every P=1 split by 6-7 %)
-    if (want_pipe && exact && T == 4 && nparts == 2 && !getenv("UMNN_FWD_P") && !getenv("UMNN_FWD_NS") &&
+    if (want_pipe && exact && T == 4 && nparts == 2 && !p_forced && !ns_forced &&
         (a.NI + 15) / 16 >= 2LL * umnn_num_cus() * 4) { P = 2; ns = 1; }
     const size_t lds_bytes = ((size_t)args.f.m.lds_off[L] + (ns > 1 ? UMNN_WAVES_PER_BLOCK * 3 * P * 16 : 0)) * sizeof(float);
     if (lds_bytes > 160 * 1024) return UMNN_EUNSUPPORTED;

@@ -17,6 +17,10 @@ struct FwdArgs {
     float* logjac;
     const float* logjac_in;   // nullable: running sum of the previous blocks' log_jac (may alias logjac)
     int reverse_z;            // write z with the dimensions reversed (the flip between the blocks of a flow)
+    // one-pass log-likelihood (umnn_flow_ll_block_forward): ll[b] (+)= sum_i log_jac[b,i]  (- Gaussian term, last block)
+    float* ll;                // [B] running log-likelihood; nullable => off
+    unsigned* row_cnt;        // [B] arrival counters: zero on entry, zero again on exit
+    int ll_first, ll_last;    // first block overwrites ll; last block adds -1/2 sum_i (log 2pi + z^2)
     long long NI;      // B*d integrals
     int d, E, n, ns, inv_f;
     unsigned ngroups;  // tile groups (of 16*P integrals)
@@ -72,5 +76,57 @@ __device__ __forceinline__ void fwd_epilogue(const FwdArgs& a, float* lds, float
             }
         }
     }
+    // ---- one-pass log-likelihood: the LAST tile to deliver a piece of row b sums that row, in a fixed order ---------
+    // (UMNNMAFFlow.compute_ll, UMNNMAFFlow.py:109-119: ll = sum_blocks sum_i log_jac - 1/2 sum_i (log 2pi + z_i^2).)
+    // Every tile publishes its z / log_jac stores (release fence), then the head lane of each row segment adds the
+    // segment length to the row's arrival counter; whoever brings it to d owns the row: after an acquire fence the
+    // whole wave reads the d values back (L2 / HBM), reduces them with a fixed butterfly and updates ll[b].  One
+    // writer per row and launch, fixed summation order: bit-reproducible, no float atomics, no extra launch.
+    if (a.ll) {
+        // release (cdna_hip_programming.md Guideline 16): drain this wave's stores, agent-scope release, drain again
+        // (the compiler may drop the fence's own wait), THEN move the counters
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int lane = 16 * g + p;
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            const bool writer = live && part == 0 && g == 0 && ok[pt];
+            const long long q = qv[pt];
+            const long long bi = q / d;
+            const int i = (int)(q - bi * d);
+            bool fin = false;
+            if (writer && (p == 0 || i == 0)) {
+                long long cnt = d - i;
+                if (cnt > 16 - p) cnt = 16 - p;
+                if (cnt > a.NI - q) cnt = a.NI - q;
+                const unsigned old = __hip_atomic_fetch_add(a.row_cnt + bi, (unsigned)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fin = old + (unsigned)cnt == (unsigned)d;
+                // self-cleaning: the next launch on this stream starts from zero again
+                if (fin) __hip_atomic_store(a.row_cnt + bi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            unsigned long long todo = __ballot(fin);
+            if (todo) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE acquire, then plain vector loads
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const long long b = ((long long)__builtin_amdgcn_readlane((int)(bi >> 32), src) << 32) |
+                                    (unsigned)__builtin_amdgcn_readlane((int)bi, src);
+                float* ljr = a.logjac + b * d;
+                float* zr = a.z + b * d;
+                float s = 0.f;
+                for (int e = lane; e < d; e += 64) {
+                    float v = ljr[e];
+                    if (a.ll_last) {
+                        const float zz = zr[e];
+                        v -= 0.5f * (1.8378770664093453f + zz * zz);         // log(2 pi)
+                    }
+                    s += v;
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+                if (lane == 0) a.ll[b] = a.ll_first ? s : a.ll[b] + s;
+            }
+        }
+    }
 }
-

@@ -1,5 +1,6 @@
 // Host-side helpers shared by the translation units of libumnn_cc.so.
 #pragma once
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -10,11 +11,26 @@ int umnn_check(hipError_t e, const char* what);           // 0 or records + retu
 // Validates `net`, fills the device-side descriptor (tile / K-step counts, LDS offsets) and reports
 // tmax = max tiles over hidden layers and ksu = the common K-step count if all hidden layers agree (else 0).
 int umnn_prepare_mlp(const umnn_mlp* net, int E, MlpDev* out, int* tmax, int* ksu);
-int umnn_num_cus();
+int umnn_num_cus();                                      // CU count of the CURRENT device (cached per device)
+
+// Process-wide launch options.  The UMNN_* environment variables are read ONCE (first use, or umnn_reload_env());
+// after that every launch reads plain atomics -- no getenv on the launch path.  -1 = "auto" for the tuning knobs.
+struct UmnnOptions {
+    std::atomic<int> fwd_precision{UMNN_PRECISION_BF16X3};   // UMNN_FWD_PRECISION = fp32 | bf16x3 | bf16x6
+    std::atomic<int> bwd_precision{UMNN_PRECISION_BF16X3};   // UMNN_BWD_PRECISION = fp32 | bf16x3
+    std::atomic<int> fwd_p{-1};          // UMNN_FWD_P: point tiles per wave (1|2)
+    std::atomic<int> fwd_ns{-1};         // UMNN_FWD_NS: node-range split (1|2|4)
+    std::atomic<int> fwd_tail{-1};       // UMNN_FWD_TAIL: VALU-tail fp32 variant (0|1)
+    std::atomic<int> fwd_pipe{1};        // UMNN_FWD_PIPE: software-pipelined two-tile loop
+    std::atomic<int> fwd_pad{1};         // UMNN_FWD_PAD: zero-pad mixed 3..4-tile nets to the shape-exact kernels
+    std::atomic<int> fwd_pad_min{1};     // UMNN_FWD_PAD_MIN
+    std::atomic<int> bwd_ns{-1};         // UMNN_BWD_NS: node-range split of the backward (1..32)
+};
+UmnnOptions& umnn_options();
 int umnn_allow_lds(const void* fn, size_t bytes);         // hipFuncSetAttribute(MaxDynamicSharedMemorySize)
 void umnn_note_launch(const char* kernel_name);
 long long umnn_param_count(const umnn_mlp* net);
 
 // Optional per-launch timing (umnn_profile_enable): hipEvents recorded on the launch stream around each kernel.
 void umnn_prof_begin(hipStream_t stream);
-void umnn_prof_end(hipStream_t stream, double flops);
+void umnn_prof_end(hipStream_t stream, double flops, int tag = UMNN_PROF_FORWARD);

@@ -73,9 +73,18 @@ class UMNNMAF(nn.Module):
         self.nb_steps = nb_steps
         self.solver = solver
         self.register_buffer("pi", torch.tensor(math.pi))
-        w, s = compute_cc_weights(nb_steps)
-        self.register_buffer("cc_weights", w.clone())
-        self.register_buffer("cc_steps", s.clone())
+        # Registered tables keep the CONSTRUCTOR's shape for the whole life of the module, like the reference's
+        # (state_dict parity: UCIExperiments.py:131-153 saves after set_steps_nb).  They are checkpoint payload only:
+        # the kernels read quadrature.device_tables(self.nb_steps).  nb_steps <= 0 ("0 for random", the scripts then
+        # call set_steps_nb per batch) gets NaN placeholders of the reference's shape; n >= 1 is checked when integrating.
+        if nb_steps >= 1:
+            w, s = compute_cc_weights(nb_steps)
+            w, s = w.clone(), s.clone()
+        else:
+            w = torch.full((max(nb_steps + 1, 0), 1), float("nan"))
+            s = w.clone()
+        self.register_buffer("cc_weights", w)
+        self.register_buffer("cc_steps", s)
         self.scaling = nn.Parameter(torch.zeros(input_size, device=self.device), requires_grad=False)
 
     def to(self, device):
@@ -95,7 +104,14 @@ class UMNNMAF(nn.Module):
         d = x.shape[1]
         z0 = h.view(h.shape[0], -1, d)[:, 0, :]
         spec = mlp_spec(integrand)
-        no_graph = (not torch.is_grad_enabled()) or ((not self.training) and (not x.requires_grad))
+        if self.nb_steps < 1:
+            raise ValueError("UMNNMAF: nb_steps must be >= 1 when integrating (call set_steps_nb first)")
+        # No-graph fast path only when nothing can ask for a gradient.  The reference's eval-mode direct integration
+        # (UMNNMAF.py:89-105) stays differentiable through ordinary autograd; here eval + grad-requiring weights /
+        # embedding goes through the same autograd Function as training.
+        no_graph = (not torch.is_grad_enabled()) or not (
+            x.requires_grad or h.requires_grad or (x0 is not None and x0.requires_grad)
+            or any(p.requires_grad for p in integrand.parameters()))
         if _I._use_hip(spec, x):
             if no_graph and x0 is None:
                 z, log_jac, _, _ = _I.hip_flow_block(spec, x, h, self.scaling, self.nb_steps, reverse_z, log_jac_in)
@@ -153,12 +169,10 @@ class UMNNMAF(nn.Module):
         return bpp, ll, z
 
     def set_steps_nb(self, nb_steps):
+        # The registered cc_weights / cc_steps buffers stay at constructor shape (checkpoint round trip, see __init__);
+        # every integral reads the tables of the CURRENT nb_steps from the per-device cache, so the reference's
+        # stale-buffer crash in eval + CCParallel (UMNNMAF.py:48-50,104-106,172-173) cannot happen here.
         self.nb_steps = nb_steps
-        # keep the registered tables in step (the reference leaves them stale and then crashes in
-        # eval + CCParallel, UMNNMAF.py:48-50,104-106,172-173)
-        w, s = compute_cc_weights(nb_steps)
-        self.cc_weights = w.clone().to(self.cc_weights.device)
-        self.cc_steps = s.clone().to(self.cc_steps.device)
 
     def compute_lipschitz(self, nb_iter=10):
         return self.net.parallel_nets.compute_lipschitz(nb_iter)
@@ -287,7 +301,32 @@ class UMNNMAFFlow(nn.Module):
     def compute_log_jac_bis(self, x, context=None):
         return self._stack(x, context, True)
 
+    def _one_pass_ok(self, x):
+        """The fused one-pass log-likelihood (umnn_flow_ll_block_forward) applies: HIP path, fp32, nothing can ask for
+        a gradient (same rule as UMNNMAF._transform)."""
+        if len(self.nets) == 0 or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
+            return False
+        for net in self.nets:
+            if net.solver not in _SOLVERS or net.nb_steps < 1 or not _I._use_hip(mlp_spec(net.net.parallel_nets), x):
+                return False
+        if not torch.is_grad_enabled():
+            return True
+        return not (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+
     def compute_ll(self, x, context=None):
+        if self._one_pass_ok(x):
+            # nb_flow x (conditioner + ONE launch): z, the running per-sample log-likelihood and the Gaussian term all
+            # leave the quadrature kernel; no [B,d] log_jac accumulation, no elementwise epilogue (UMNNMAFFlow.py:109-119)
+            with torch.no_grad():
+                x = x.contiguous()
+                ll = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+                scratch = torch.empty_like(x)
+                nb = len(self.nets)
+                for i, net in enumerate(self.nets):
+                    h = net.net.make_embeding(x, context)
+                    x = _I.hip_flow_ll_block(mlp_spec(net.net.parallel_nets), x, h.contiguous(), net.scaling, net.nb_steps,
+                                             reverse_z=i + 1 < nb, first=i == 0, last=i + 1 == nb, ll=ll, scratch=scratch)
+            return ll, x
         z, log_jac = self._stack(x, context, True)
         log_prob_gauss = -.5 * (torch.log(self.pi * 2) + z ** 2).sum(1)
         return log_jac.sum(1) + log_prob_gauss, z

@@ -26,6 +26,7 @@ import threading
 import warnings
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from .nets import mlp_spec
@@ -65,22 +66,37 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_desc_cache = {}      # id(spec.linears[0]) -> (key, MlpDesc, keep-alive tensors)
+
+
 def _desc(spec):
-    """struct umnn_mlp for the current weights (read live: optimizer steps / force_lipschitz are seen)."""
+    """struct umnn_mlp for the current weights.  The weights are read live (optimizer steps / force_lipschitz write in
+    place and are seen through the same pointers); the ctypes struct itself is rebuilt only when a pointer moved."""
+    lins = spec.linears
+    key = tuple((lin.weight.data_ptr(), lin.bias.data_ptr()) for lin in lins) + (spec.hidden_act, spec.out_act)
+    slot = id(lins[0])
+    hit = _desc_cache.get(slot)
+    if hit is not None and hit[0] == key and hit[3] is lins[0]:
+        return hit[1], hit[2]
     d = _lib.MlpDesc()
-    d.n_linear = len(spec.linears)
-    d.widths[0] = spec.linears[0].in_features
+    d.n_linear = len(lins)
+    d.widths[0] = lins[0].in_features
     keep = []
-    for l, lin in enumerate(spec.linears):
+    cacheable = True
+    for l, lin in enumerate(lins):
         w, b = lin.weight.detach(), lin.bias.detach()
         if not w.is_contiguous():
-            w = w.contiguous()
+            w, cacheable = w.contiguous(), False       # a copy: its contents would go stale
         if not b.is_contiguous():
-            b = b.contiguous()
+            b, cacheable = b.contiguous(), False
         keep += [w, b]
         d.widths[l + 1] = lin.out_features
         d.W[l], d.b[l] = w.data_ptr(), b.data_ptr()
     d.hidden_act, d.out_act = spec.hidden_act, spec.out_act
+    if cacheable:
+        if len(_desc_cache) > 256:
+            _desc_cache.clear()
+        _desc_cache[slot] = (key, d, keep, lins[0])
     return d, keep
 
 
@@ -196,6 +212,37 @@ def hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z=False, log_jac_in=No
     if out_dtype != torch.float32:
         z, lj, fx, fx0 = z.to(out_dtype), lj.to(out_dtype), fx.to(out_dtype), fx0.to(out_dtype)
     return z, lj, fx, fx0
+
+
+_row_counters = {}     # (device index, stream handle) -> zeroed uint32 [>= B] arrival counters (kernel leaves them zero)
+
+
+def _counters(B, device, stream_handle):
+    key = (device.index, stream_handle)
+    t = _row_counters.get(key)
+    if t is None or t.numel() < B:
+        t = _row_counters[key] = torch.zeros(max(B, 1024), dtype=torch.int32, device=device)
+    return t
+
+
+def hip_flow_ll_block(spec, x, h, scaling, nb_steps, reverse_z, first, last, ll, scratch):
+    """One link of UMNNMAFFlow.compute_ll with the whole log-likelihood arithmetic inside the launch
+    (umnn_flow_ll_block_forward): -> z; ``ll`` [B] is updated in place, ``scratch`` [B,d] is this launch's own."""
+    lib = _lib.lib()
+    B, d, E = _shape(spec, x, h)
+    z = torch.empty_like(x)
+    w, s = device_tables(nb_steps, x.device)
+    desc, keep = _desc(spec)
+    with torch.cuda.device(x.device):
+        handle = torch.cuda.current_stream(x.device).cuda_stream
+        cnt = _counters(B, x.device, handle)
+        rc = lib.umnn_flow_ll_block_forward(ctypes.byref(desc), _ptr(x), _ptr(h), _ptr(scaling), _ptr(w), _ptr(s),
+                                            int(nb_steps), B, d, E, 1 if reverse_z else 0, 1 if first else 0,
+                                            1 if last else 0, _ptr(z), _ptr(scratch), _ptr(ll), _ptr(cnt),
+                                            ctypes.c_void_p(handle))
+    _lib.check(rc, "umnn_flow_ll_block_forward")
+    _state.path = "hip"
+    return z
 
 
 def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True)):
@@ -315,6 +362,7 @@ class IntegralWithJacobianParams(torch.autograd.Function):
         return F, fx
 
     @staticmethod
+    @once_differentiable        # double backward (create_graph=True through the quadrature) raises instead of silently detaching
     def backward(ctx, gF, gfx):
         if ctx.x0_none:
             (x, h), x0 = ctx.saved_tensors, None
@@ -348,8 +396,17 @@ def integrate(x0, nb_steps, step_sizes, integrand, h, compute_grad=False, x_tot=
     x = x0 + nb_steps * step_sizes
     spec = mlp_spec(integrand)
     if not compute_grad:
+        # The reference's direct integration is plain ATen, hence differentiable by ordinary autograd
+        # (ParallelNeuralIntegral.py:49-65).  Keep that: only when nothing can ask for a gradient is the graph skipped.
+        wants_graph = torch.is_grad_enabled() and (
+            x.requires_grad or (h is not None and h.requires_grad)
+            or (isinstance(integrand, torch.nn.Module) and any(p.requires_grad for p in integrand.parameters())))
         if _use_hip(spec, x):
+            if wants_graph:
+                return ParallelNeuralIntegral.apply(x0, x, integrand, _flatten(integrand.parameters()), h, nb_steps, inv_f)
             return hip_forward(spec, x0, x, h, nb_steps, inv_f)[0]
+        if wants_graph:
+            return aten_forward(integrand, x0, x, h, nb_steps, inv_f)
         with torch.no_grad():
             return aten_forward(integrand, x0, x, h, nb_steps, inv_f)
     if _use_hip(spec, x) and not inv_f and _hip_backward_ok(spec, x, h):
@@ -389,6 +446,7 @@ class ParallelNeuralIntegral(torch.autograd.Function):
         return _op_forward(ctx, x0, x, integrand, h, nb_steps, inv_f)
 
     @staticmethod
+    @once_differentiable        # double backward (create_graph=True through the quadrature) raises instead of silently detaching
     def backward(ctx, grad_output):
         dx0, dx, dtheta, dh = _op_backward(ctx, grad_output)
         return dx0, dx, None, dtheta, dh, None, None
@@ -400,6 +458,7 @@ class NeuralIntegral(torch.autograd.Function):
         return _op_forward(ctx, x0, x, integrand, h, nb_steps, False)
 
     @staticmethod
+    @once_differentiable        # double backward (create_graph=True through the quadrature) raises instead of silently detaching
     def backward(ctx, grad_output):
         dx0, dx, dtheta, dh = _op_backward(ctx, grad_output)
         return dx0, dx, None, dtheta, dh, None
@@ -422,6 +481,7 @@ class IntegralWithJacobian(torch.autograd.Function):
         return F, fx
 
     @staticmethod
+    @once_differentiable        # double backward (create_graph=True through the quadrature) raises instead of silently detaching
     def backward(ctx, gF, gfx):
         x0, x, h = ctx.saved_tensors
         if not _hip_backward_ok(ctx.spec, x, h):

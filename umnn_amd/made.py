@@ -38,9 +38,24 @@ class MaskedLinear(nn.Linear):
         self._cache = None
         self._packed = None
 
+    def invalidate_caches(self):
+        """Drop the cached masked / packed weights.  The caches are keyed on tensor versions; writes through ``.data``
+        (or any other route that does not bump ``_version``) are invisible to that key, so code doing such writes must
+        call this (``umnn_amd.invalidate_caches(model)`` does it for a whole model)."""
+        self._cache = None
+        self._packed = None
+
+    @staticmethod
+    def _capturing(t):
+        return t.is_cuda and torch.cuda.is_current_stream_capturing()
+
     def masked_weight(self):
         if torch.is_grad_enabled() and self.weight.requires_grad:
             return self.mask * self.weight
+        if self._capturing(self.weight):
+            # inside a hipGraph capture the product must be part of the graph: a cached tensor would be baked in as
+            # a constant and replays after an optimizer step would read stale conditioner weights
+            return (self.mask * self.weight).detach()
         key = (self.weight._version, self.weight.data_ptr(), self.mask._version, self.mask.data_ptr())
         if self._cache is None or self._cache[0] != key:
             self._cache = (key, (self.mask * self.weight).detach())
@@ -51,7 +66,8 @@ class MaskedLinear(nn.Linear):
         weight, mask and bias are unchanged).  ``rows``: optional output-row selection (ConditionnalMADE)."""
         key = (self.weight._version, self.weight.data_ptr(), self.mask._version, self.mask.data_ptr(),
                self.bias._version, self.bias.data_ptr(), None if rows is None else rows.data_ptr())
-        if self._packed is None or self._packed[0] != key:
+        capturing = self._capturing(self.weight)        # see masked_weight: recompute inside the graph, never cache
+        if capturing or self._packed is None or self._packed[0] != key:
             with torch.no_grad():
                 W, b = self.mask * self.weight, self.bias
                 if rows is not None:
@@ -62,6 +78,8 @@ class MaskedLinear(nn.Linear):
                 pad = (-(3 * K + 2)) % 8
                 packed = torch.cat([Wh, Wh, Wl, bh[:, None], bl[:, None],
                                     torch.zeros(W.shape[0], pad, dtype=torch.bfloat16, device=W.device)], 1).contiguous()
+            if capturing:
+                return packed
             self._packed = (key, packed)
         return self._packed[1]
 
@@ -69,14 +87,30 @@ class MaskedLinear(nn.Linear):
         return F.linear(input, self.masked_weight(), self.bias)
 
 
-_FAST = {"ok": None}
+def invalidate_caches(module):
+    """Drop every MaskedLinear cache under ``module`` (after writes that bypass tensor versioning, e.g. ``p.data``)."""
+    for m in module.modules():
+        if isinstance(m, MaskedLinear):
+            m.invalidate_caches()
+
+
+_FAST = {"ok": None, "enabled": os.environ.get("UMNN_MADE_BF16X3", "1") != "0"}
+
+
+def set_made_fast_path(enabled):
+    """Inference conditioner GEMMs as K-concatenated bf16 GEMMs (True, default) or plain fp32 ``F.linear`` (False)."""
+    _FAST["enabled"] = bool(enabled)
+
+
+def get_made_fast_path():
+    return _FAST["enabled"]
 
 
 def _fast_path_ok(x):
     """bf16x3 GEMM path: CUDA fp32 input, autograd off, HIP library present, torch.mm(out_dtype=) available."""
     if torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32:
         return False
-    if os.environ.get("UMNN_MADE_BF16X3", "1") == "0":
+    if not _FAST["enabled"]:
         return False
     if _FAST["ok"] is None:
         try:

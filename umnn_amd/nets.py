@@ -162,10 +162,33 @@ def mlp_spec(integrand):
 
     Also recognises the reference's own classes by structure (same class names, same module tree), so a model
     built from reference code can be handed to ``ParallelNeuralIntegral.apply`` of this package unchanged."""
+    if not isinstance(integrand, nn.Module):
+        return None
+    # cached on the module while its Sequential is the same object with the same children (the spec holds the Linear
+    # modules themselves, so in-place weight updates and .to(device) are seen through it)
+    net = getattr(integrand, "net", None)
+    hit = integrand.__dict__.get("_umnn_spec_cache")
+    if hit is not None and hit[0] is net and hit[1] == _spec_key(net):
+        return hit[2]
+    spec = _mlp_spec_uncached(integrand)
+    if isinstance(net, nn.Sequential):
+        integrand.__dict__["_umnn_spec_cache"] = (net, _spec_key(net), spec)
+    return spec
+
+
+def _spec_key(net):
+    if not isinstance(net, nn.Sequential):
+        return None
+    mods = tuple(net._modules.values())
+    w = getattr(mods[0], "weight", None) if mods else None
+    return mods + ((w.dtype, w.device) if w is not None else ())
+
+
+def _mlp_spec_uncached(integrand):
     fn = getattr(integrand, "_umnn_spec", None)
     if fn is not None:
         return fn()
-    if not isinstance(integrand, nn.Module) or not isinstance(getattr(integrand, "net", None), nn.Sequential):
+    if not isinstance(getattr(integrand, "net", None), nn.Sequential):
         return None
     cls = type(integrand).__name__
     if cls == "IntegrandNetwork":

@@ -49,20 +49,22 @@ def allreduce_gradients(module, world=None, average=True):
     for p in params:
         if p.grad is None:
             p.grad = torch.zeros_like(p)
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    grads = [p.grad for p in params]
+    flat = torch._utils._flatten_dense_tensors(grads)           # one message (a few MB: latency-bound on xGMI)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat /= world
-    off = 0
-    for p in params:
-        n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p))
-        off += n
+    # the gradients become views into the reduced flat buffer: no second pass of per-parameter copies
+    for p, v in zip(params, torch._utils._unflatten_dense_tensors(flat, grads)):
+        p.grad = v
 
 
 def broadcast_parameters(module, src=0):
     """Make every replica start from rank src's weights (and buffers)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src)
+    from .made import invalidate_caches
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.detach(), src)      # detach() shares the version counter: the in-place receive bumps it
+    invalidate_caches(module)                    # belt and braces for the conditioner's masked / packed weight caches
