@@ -60,6 +60,19 @@ typedef struct umnn_mlp {
     int out_act;                          /* UMNN_OUT_* */
 } umnn_mlp;
 
+/* Storage types of the activation tensors (configuration C4, the bf16 VAE prior flow: models/vae_lib/models/flows.py:305-323).
+ * The arithmetic is fp32 in every case; the *_io entry points take a descriptor saying how the caller STORES
+ *   x-class tensors: x0, x, F, f_x, f_x0, z, log_jac, log_jac_in, g, g_fx, dx, dx0      (x_dtype)
+ *   h-class tensors: h (the [B, E*d] embedding the conditioner writes -- the large one), dh   (h_dtype)
+ * bf16 loads are exact widenings, bf16 stores round to nearest even.  io == NULL means fp32 everywhere (= the plain
+ * entry points).  d_theta, the quadrature tables, scaling and the weights are always fp32. */
+#define UMNN_DTYPE_F32 0
+#define UMNN_DTYPE_BF16 1
+typedef struct umnn_io {
+    int x_dtype;
+    int h_dtype;
+} umnn_io;
+
 /* Replaces integrate(..., compute_grad=False) -- ParallelNeuralIntegral.py:49-65 and
  * NeuralIntegral.py:53-66 (both solvers are the same arithmetic; the kernel never
  * materialises the node axis).  Quadrature node 0 is x and node n is x0, so the same pass
@@ -91,6 +104,20 @@ int umnn_flow_stack_block_forward(const umnn_mlp* net, const float* x, const flo
                                   long long B, int d, int E, int reverse_z, const float* log_jac_in,
                                   float* z, float* log_jac, float* f_x, float* f_x0, void* stream);
 
+/* umnn_cc_forward / umnn_flow_stack_block_forward / umnn_cc_backward with bf16 or fp32 activation storage (see umnn_io). */
+int umnn_cc_forward_io(const umnn_mlp* net, const umnn_io* io, const void* x0, const void* x, const void* h,
+                       const float* cc_w, const float* cc_s, int nb_steps,
+                       long long B, int d, int E, int inv_f, void* F, void* f_x, void* f_x0, void* stream);
+int umnn_flow_stack_block_forward_io(const umnn_mlp* net, const umnn_io* io, const void* x, const void* h,
+                                     const float* scaling, const float* cc_w, const float* cc_s, int nb_steps,
+                                     long long B, int d, int E, int reverse_z, const void* log_jac_in,
+                                     void* z, void* log_jac, void* f_x, void* f_x0, void* stream);
+int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const void* x0, const void* x, const void* h,
+                        const void* g, const void* g_fx,
+                        const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
+                        void* dx0, void* dx, void* dh, float* dtheta,
+                        void* workspace, long long workspace_bytes, void* stream);
+
 /* One link of UMNNMAFFlow.compute_ll (UMNNMAFFlow.py:109-119) with the WHOLE log-likelihood arithmetic inside the
  * launch: besides z (reversed for the next block when reverse_z != 0) the kernel keeps the per-sample running sum
  *   ll[b]  = (first ? 0 : ll[b]) + sum_i log_jac[b,i]            (UMNNMAF.compute_log_jac, UMNNMAF.py:136-139)
@@ -105,6 +132,17 @@ int umnn_flow_ll_block_forward(const umnn_mlp* net, const float* x, const float*
                                const float* cc_w, const float* cc_s, int nb_steps,
                                long long B, int d, int E, int reverse_z, int first, int last,
                                float* z, float* log_jac_scratch, float* ll, unsigned* row_counters, void* stream);
+
+/* Sampling direction, one flow dimension per call: replaces the inner loops of UMNNMAF.invert (UMNNMAF.py:195-231) for
+ * dimension j -- `iters` rounds of the 10-candidate bracket search on [-50, 50], each candidate's image being
+ * exp(scaling_j) * (h[b, 0*d+j] + int_0^cand f(t; h[b, :, j]) dt) -- for all B samples in ONE launch.
+ *   h      [B, E*d]  conditioner output for the current x_inv (dimensions < j already final; MADE is autoregressive,
+ *                    so the caller runs it once per dimension, exactly like the reference :198)
+ *   z      [B, d]    targets (column j is read);   x_inv [B, d]: column j is WRITTEN (the round's best candidate)
+ * UMNN_EUNSUPPORTED for nets with a single hidden layer or images beyond 160 KiB of LDS (callers keep their own loop). */
+int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const float* z, const float* scaling,
+                         const float* cc_w, const float* cc_s, int nb_steps,
+                         long long B, int d, int E, int j, int iters, float* x_inv, void* stream);
 
 /* Replaces integrate(..., compute_grad=True) + the Leibniz terms -- ParallelNeuralIntegral.py:66-94,
  * 110-123 (NeuralIntegral.py:47-58,69-75,90-99).  g is grad_output [B,d] (cotangent of F).

@@ -112,20 +112,64 @@ def test_one_pass_ll_is_bit_reproducible_and_matches_elementwise_route(dev):
             assert int(t.abs().sum()) == 0, "arrival counters must be zero again after every launch"
 
 
-@pytest.mark.parametrize("dt", [torch.bfloat16])
-def test_vae_prior_flow_with_bf16_callers(dt, dev):
-    """BASELINE configuration C4 as the VAE calls it (models/vae_lib/models/flows.py:305-323): compute_log_jac_bis(z, h_context)
-    with bf16 activations (autocast-style): the tolerance of that configuration, stated against the fp32 oracle."""
+@pytest.mark.parametrize("mode", ["bf16_embedding", "bf16_everything", "autocast"])
+def test_vae_prior_flow_bf16_storage(mode, dev):
+    """BASELINE configuration C4 as the VAE calls it (models/vae_lib/models/flows.py:305-323: compute_log_jac_bis(z, h_context),
+    d=64, cond_in=320, 4 blocks, n=50) with bf16 STORAGE around fp32 arithmetic -- the kernels load / store bf16 themselves
+    (umnn_*_io entry points), nothing is converted on the way:
+      bf16_embedding   fp32 x / context, the conditioner writes the [B, E*d] embedding in bf16 (set_embedding_dtype)
+      bf16_everything  x, context and every result in bf16 as well
+      autocast         torch.autocast(bfloat16) around the call, fp32 inputs
+    Stated tolerance vs the fp32 oracle (there is no bf16 reference): every stored value carries a relative rounding of
+    2^-9 = 2e-3; z = exp(s)(F + h_0) inherits it from h_0 and F, log_jac from f -- BF16_TOL = 2e-2 on max|d|/max(|ref|,1)."""
+    import umnn_amd
+    from umnn_amd import _lib
     cfg = dict(bench.WORKLOADS["vae"])
     model = bench.build_model(cfg, dev)
     x, ctx = bench.make_inputs(cfg, 100, dev, 7)                # the script's batch of 100
-    with torch.no_grad():
-        z, lj = model.compute_log_jac_bis(x.to(dt), ctx.to(dt))
     blocks = _oracle_blocks(model, cfg)
-    xs, cs = x.to(dt).float().cpu().numpy(), ctx.to(dt).float().cpu().numpy()     # the oracle sees the same rounded inputs
-    z_ref, lj_ref = O.flow_log_jac(blocks, xs, cfg["n"], context=cs)
+    try:
+        launches = _lib.lib().umnn_launch_count()
+        with torch.no_grad():
+            if mode == "bf16_embedding":
+                model.set_embedding_dtype(torch.bfloat16)
+                z, lj = model.compute_log_jac_bis(x, ctx)
+                xs, cs = x, ctx
+                assert z.dtype == torch.float32 and model.nets[0].net.m_embeding.dtype == torch.bfloat16
+            elif mode == "bf16_everything":
+                model.set_embedding_dtype(torch.bfloat16)
+                xs, cs = x.bfloat16(), ctx.bfloat16()
+                z, lj = model.compute_log_jac_bis(xs, cs)
+                assert z.dtype == torch.bfloat16 and lj.dtype == torch.bfloat16
+            else:
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    z, lj = model.compute_log_jac_bis(x, ctx)
+                xs, cs = x, ctx
+        assert umnn_amd.path_taken() == "hip" and _lib.lib().umnn_launch_count() - launches == cfg["nb_flow"]
+    finally:
+        model.set_embedding_dtype(None)
+    z_ref, lj_ref = O.flow_log_jac(blocks, xs.float().cpu().numpy(), cfg["n"], context=cs.float().cpu().numpy())
     assert U.rel_err(z.float().cpu().numpy(), z_ref) < BF16_TOL
     assert np.all(np.abs(lj.float().cpu().numpy() - lj_ref) <= BF16_TOL * np.maximum(1.0, np.abs(lj_ref)))
+
+
+def test_vae_prior_flow_bf16_embedding_training_gradients(dev):
+    """Training through the bf16-embedding storage mode (forward AND backward kernels read h as bf16, d_h leaves as bf16):
+    parameter gradients against the all-fp32 run of the same model, at the storage format's resolution."""
+    cfg = dict(bench.WORKLOADS["vae"])
+    model = bench.build_model(cfg, dev).train()
+    x, ctx = bench.make_inputs(cfg, 100, dev, 9)
+    grads = {}
+    for mode in ("fp32", "bf16"):
+        model.set_embedding_dtype(torch.bfloat16 if mode == "bf16" else None)
+        model.zero_grad()
+        z, lj = model.compute_log_jac_bis(x, ctx)
+        (0.5 * (z ** 2).sum(1) - lj.sum(1)).mean().backward()          # the VAE's flow term: -log p(z_K) - log|det J|
+        grads[mode] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.set_embedding_dtype(None)
+    assert grads["fp32"].keys() == grads["bf16"].keys() and len(grads["bf16"]) > 20
+    for k in grads["fp32"]:
+        assert U.scaled_err(grads["bf16"][k].cpu().numpy(), grads["fp32"][k].cpu().numpy()) < 5e-2, k
 
 
 def test_block_level_compute_ll_and_bis_on_the_hip_path(dev):

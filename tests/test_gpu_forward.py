@@ -259,6 +259,34 @@ def test_invert_on_gpu_matches_reference(dev):
     assert float((x_inv.cpu() - torch.from_numpy(G["x_inv"])).abs().max()) < tol
 
 
+@pytest.mark.parametrize("d,hid,E,n,nb_flow,B", [(7, [50] * 4, 30, 50, 2, 33), (2, [100] * 4, 10, 50, 1, 64),
+                                                 (5, [100, 50, 50, 50, 50], 8, 30, 1, 20), (3, [40, 33], 4, 20, 2, 17)])
+def test_in_kernel_inversion_round_trip(d, hid, E, n, nb_flow, B, dev):
+    """UMNNMAFFlow.invert with the whole bracket search of a dimension inside one launch (umnn_flow_invert_dim): exactly
+    d launches per block, x -> z -> x round trip within the search's own resolution 100 (2/9)^iter, and agreement with the
+    host-driven search (the same algorithm issued round by round through the generic quadrature)."""
+    import umnn_amd
+    from umnn_amd import _lib, integral as I
+    torch.manual_seed(d * 7 + len(hid))
+    m = umnn_amd.UMNNMAFFlow(nb_flow=nb_flow, nb_in=d, hidden_derivative=hid, hidden_embedding=[64, 64], embedding_s=E,
+                             nb_steps=n, solver="CCParallel").to(dev).eval()
+    x = torch.randn(B, d, device=dev) * 1.5
+    iters = 8
+    tol = 4 * 100.0 * (2.0 / 9.0) ** iters            # two bracket widths per block of slack
+    with torch.no_grad():
+        z = m(x)
+        before = _lib.lib().umnn_launch_count()
+        x_inv = m.invert(z, iter=iters)
+        assert _lib.lib().umnn_launch_count() - before == nb_flow * d
+        assert "cc_invert_bf16" in _lib.lib().umnn_last_kernel_name().decode()
+        assert float((x_inv - x).abs().max()) < tol * nb_flow
+        with I.force_generic():                       # host-driven search, ATen integrals
+            x_ref = m.invert(z, iter=iters)
+        assert float((x_inv - x_ref).abs().max()) < tol * nb_flow
+        z2 = m(x_inv)
+    assert U.rel_err(z2.cpu().numpy(), z.cpu().numpy()) < 5e-3
+
+
 def test_large_batch_65536_rows(dev):
     """The un-sharded C3 batch (65536 x 63 = 4.1M integrals) on one GPU: indexing stays in range, results finite,
     first and last rows agree with a small launch on the same rows."""
@@ -463,6 +491,34 @@ def test_graphed_compute_ll_replays_the_same_numbers(dev):
     assert torch.equal(out[0], ref1[0]) and torch.equal(out[1], ref1[1])
     out = g(x2)
     assert torch.equal(out[0], ref2[0]) and torch.equal(out[1], ref2[1])
+    # weights move between replays (an optimizer step): the graph must not keep serving the stale conditioner weights it
+    # baked in -- it re-captures when a version counter moved
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.01)
+        ref3 = [t.clone() for t in model.compute_ll(x2)]
+    assert not torch.equal(ref3[0], ref2[0])
+    out = g(x2)
+    assert g.captures == 2
+    assert torch.equal(out[0], ref3[0]) and torch.equal(out[1], ref3[1])
+    out = g(x1)
+    assert g.captures == 2                                            # unchanged weights: plain replay
+    # a user-level capture (no version tracking) must see live weights too: nothing cached is baked in
+    with torch.no_grad():
+        xs = x1.clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            model.compute_ll(xs)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            cap = model.compute_ll(xs)
+        for p in model.parameters():
+            p.mul_(0.99)
+        ref4 = [t.clone() for t in model.compute_ll(xs)]
+        graph.replay()
+    assert torch.allclose(cap[0], ref4[0], rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("hid,T", [([64, 64, 64], 5), ([70, 79, 64, 66], 5), ([90, 88, 95], 6), ([120, 112, 127], 8), ([100] * 4, 7)])

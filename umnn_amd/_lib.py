@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libumnn_cc.so")
 
 MAX_LINEAR = 8
+EINVAL, EUNSUPPORTED, ENODEVICE = -1, -2, -3
 ACT_LEAKY_RELU, ACT_RELU = 0, 1
 OUT_ELU_PLUS_ONE, OUT_SIGMOID = 0, 1
 
@@ -30,6 +31,13 @@ class MlpDesc(ctypes.Structure):
     ]
 
 
+class IoDesc(ctypes.Structure):
+    """struct umnn_io: storage dtype of the x-class tensors and of h (0 fp32, 1 bf16)"""
+    _fields_ = [("x_dtype", ctypes.c_int), ("h_dtype", ctypes.c_int)]
+
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+
 # name -> (restype, argtypes); must list every symbol include/umnn_cc.h declares
 SIGNATURES = {
     "umnn_cc_forward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
@@ -39,9 +47,18 @@ SIGNATURES = {
     "umnn_flow_stack_block_forward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                                      _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
                                                      _fp, _fp, _fp, _fp, _fp]),
+    "umnn_cc_forward_io": (ctypes.c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(IoDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                          _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]),
+    "umnn_flow_stack_block_forward_io": (ctypes.c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(IoDesc), _fp, _fp, _fp, _fp, _fp,
+                                                        ctypes.c_int, _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
+                                                        _fp, _fp, _fp, _fp, _fp]),
+    "umnn_cc_backward_io": (ctypes.c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(IoDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp,
+                                           ctypes.c_int, _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _ll, _fp]),
     "umnn_flow_ll_block_forward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                                   _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   _fp, _fp, _fp, _fp, _fp]),
+    "umnn_flow_invert_dim": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                            _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]),
     "umnn_cc_backward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                         _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _ll, _fp]),
     "umnn_cc_backward_workspace_bytes": (_ll, [ctypes.POINTER(MlpDesc), _ll, ctypes.c_int, ctypes.c_int]),

@@ -135,6 +135,13 @@ extern "C" int umnn_set_backward_precision(int mode) {
 }
 extern "C" int umnn_get_backward_precision(void) { return umnn_options().bwd_precision; }
 
+int umnn_check_io(const umnn_io* io) {
+    if (!io) return 0;
+    if ((io->x_dtype != UMNN_DTYPE_F32 && io->x_dtype != UMNN_DTYPE_BF16) || (io->h_dtype != UMNN_DTYPE_F32 && io->h_dtype != UMNN_DTYPE_BF16))
+        return umnn_fail(UMNN_EINVAL, "umnn_io: dtype codes are UMNN_DTYPE_F32 or UMNN_DTYPE_BF16");
+    return 0;
+}
+
 long long umnn_param_count(const umnn_mlp* net) {
     long long n = 0;
     for (int l = 0; l < net->n_linear; ++l) n += (long long)net->widths[l + 1] * net->widths[l] + net->widths[l + 1];

@@ -155,14 +155,14 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
         const long long q = (long long)grp * 16 + p;
         const bool ok = q < a.NI;
         const long long qq = ok ? q : a.NI - 1;
-        const float xv = a.x[qq];
-        const float x0v = a.x0 ? a.x0[qq] : 0.f;
+        const float xv = io_ld(a.x, qq, a.x_bf16);
+        const float x0v = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
         const float dxv = xv - x0v;
-        const float gv = ok ? a.g[qq] : 0.f;                       // dead lanes contribute nothing
-        const float gfxv = (ok && a.gfx) ? a.gfx[qq] : 0.f;
+        const float gv = ok ? io_ld(a.g, qq, a.x_bf16) : 0.f;                       // dead lanes contribute nothing
+        const float gfxv = (ok && a.gfx) ? io_ld(a.gfx, qq, a.x_bf16) : 0.f;
         const float cotbase = gv * dxv * 0.5f;
         const long long bi = qq / d;
-        const float* hb = a.h + bi * ((long long)E * d) + (qq - bi * d);
+        const IoView hb = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
 
         // hoisted first-layer term (same as the forward kernel)
         f32x4 c[TMAX];
@@ -329,8 +329,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
                     if (f < H1) a.dc[(size_t)part * a.NI * H1 + q * H1 + f] = dcs[t][r];
                 }
             if (g == 0) {       // Leibniz terms: from the work items that own node 0 / node n
-                if (a.dx && k_lo == 0) a.dx[q] = fmaf(gfxv, dfdt, fxv * gv);
-                if (a.dx0 && k_hi == n + 1) a.dx0[q] = -fx0v * gv;
+                if (a.dx && k_lo == 0) io_st(a.dx, q, fmaf(gfxv, dfdt, fxv * gv), a.x_bf16);
+                if (a.dx0 && k_hi == n + 1) io_st(a.dx0, q, -fx0v * gv, a.x_bf16);
             }
         }
     }
@@ -376,7 +376,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
 
 // d_h[b, e*d+i] = sum_f W1[f][1+e] dc[q][f]
 __global__ __launch_bounds__(256) void cc_bwd_dh_kernel(const float* __restrict__ dc, const float* __restrict__ W0,
-                                                        float* __restrict__ dh, long long NI, int d, int E, int H1, int qpb) {
+                                                        float* __restrict__ dh, long long NI, int d, int E, int H1, int qpb,
+                                                        int h_bf16) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sW = sm;                       // [H1][E]
     float* sdc = sm + H1 * E;             // [qpb][H1+1], qpb = integrals per block (64, or 16 for small batches)
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) void cc_bwd_dh_kernel(const float* __restrict_
         float s = 0.f;
         for (int f = 0; f < H1; ++f) s = fmaf(sW[f * E + e], sdc[ql * (H1 + 1) + f], s);
         const long long q = q0 + ql, bi = q / d;
-        dh[bi * ((long long)E * d) + (long long)e * d + (q - bi * d)] = s;
+        io_st(dh, bi * ((long long)E * d) + (long long)e * d + (q - bi * d), s, h_bf16);
     }
 }
 
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256) void cc_bwd_dcsum_kernel(float* __restrict__ d
 // partial[blk][f][e] = sum_{q in chunk} dc[q][f] * hext[q][e],  hext[q][E] = 1  (-> dW1[:,1:], db1)
 __global__ __launch_bounds__(256) void cc_bwd_dw0_kernel(const float* __restrict__ dc, const float* __restrict__ h,
                                                          float* __restrict__ partial, long long NI, int d, int E,
-                                                         int H1, int chunk) {
+                                                         int H1, int chunk, int h_bf16) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sdc = sm;                          // [chunk][H1]
     float* sh = sm + chunk * H1;              // [chunk][E+1]
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void cc_bwd_dw0_kernel(const float* __restrict
     for (int i = tid; i < nq * (E + 1); i += 256) {
         const int e = i / nq, ql = i - e * nq;
         const long long q = q0 + ql, bi = q / d;
-        sh[ql * (E + 1) + e] = e < E ? h[bi * ((long long)E * d) + (long long)e * d + (q - bi * d)] : 1.f;
+        sh[ql * (E + 1) + e] = e < E ? io_ld(h, bi * ((long long)E * d) + (long long)e * d + (q - bi * d), h_bf16) : 1.f;
     }
     __syncthreads();
     const int nout = H1 * (E + 1);
@@ -624,6 +625,18 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
                                 const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
                                 float* dx0, float* dx, float* dh, float* dtheta,
                                 void* workspace, long long workspace_bytes, void* stream_) {
+    return umnn_cc_backward_io(net, nullptr, x0, x, h, g, g_fx, cc_w, cc_s, nb_steps, B, d, E, dx0, dx, dh, dtheta,
+                               workspace, workspace_bytes, stream_);
+}
+
+extern "C" int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const void* x0_, const void* x_, const void* h_,
+                                   const void* g_, const void* g_fx_,
+                                   const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
+                                   void* dx0_, void* dx_, void* dh_, float* dtheta,
+                                   void* workspace, long long workspace_bytes, void* stream_) {
+    const float *x0 = (const float*)x0_, *x = (const float*)x_, *h = (const float*)h_, *g = (const float*)g_, *g_fx = (const float*)g_fx_;
+    float *dx0 = (float*)dx0_, *dx = (float*)dx_, *dh = (float*)dh_;
+    if (int rc = umnn_check_io(io)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     if (B < 0 || d < 1) return umnn_fail(UMNN_EINVAL, "backward: B must be >= 0 and d >= 1");
     if (nb_steps < 1) return umnn_fail(UMNN_EINVAL, "backward: nb_steps must be >= 1");
@@ -642,6 +655,7 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
     char* ws = (char*)workspace;
     a.x0 = x0; a.x = x; a.h = h; a.g = g; a.gfx = g_fx; a.ccw = cc_w; a.ccs = cc_s;
     a.dx0 = dx0; a.dx = dx; a.n = nb_steps;
+    a.x_bf16 = io && io->x_dtype == UMNN_DTYPE_BF16; a.h_bf16 = io && io->h_dtype == UMNN_DTYPE_BF16;
     a.partials = (float*)(ws + pl.ws_partials);
     a.dc = (float*)(ws + pl.ws_dc);
     float* p0 = (float*)(ws + pl.ws_p0);
@@ -690,13 +704,13 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
         const size_t sm = ((size_t)H1 * E + qpb * (H1 + 1)) * sizeof(float);
         const unsigned nb = (unsigned)((a.NI + qpb - 1) / qpb);
         if (int rc = umnn_allow_lds((const void*)cc_bwd_dh_kernel, sm)) return rc;
-        hipLaunchKernelGGL(cc_bwd_dh_kernel, dim3(nb), dim3(256), sm, stream, a.dc, net->W[0], dh, a.NI, d, E, H1, qpb);
+        hipLaunchKernelGGL(cc_bwd_dh_kernel, dim3(nb), dim3(256), sm, stream, a.dc, net->W[0], dh, a.NI, d, E, H1, qpb, a.h_bf16);
         umnn_note_launch("cc_bwd_dh");
     }
     if (dtheta) {
         const size_t sm = (size_t)pl.chunk0 * (H1 + E + 1) * sizeof(float);
         if (int rc = umnn_allow_lds((const void*)cc_bwd_dw0_kernel, sm)) return rc;
-        hipLaunchKernelGGL(cc_bwd_dw0_kernel, dim3(pl.nparts0), dim3(256), sm, stream, a.dc, h, p0, a.NI, d, E, H1, pl.chunk0);
+        hipLaunchKernelGGL(cc_bwd_dw0_kernel, dim3(pl.nparts0), dim3(256), sm, stream, a.dc, h, p0, a.NI, d, E, H1, pl.chunk0, a.h_bf16);
         hipLaunchKernelGGL(cc_bwd_reduce_kernel, dim3((a.n_params + 15) / 16), dim3(256), 0, stream,
                            a.partials, pl.nwaves, a.n_params, p0, pl.nparts0, E, H1, a.poffW[0], a.poffb[0], dtheta);
         umnn_note_launch("cc_bwd_reduce");

@@ -211,14 +211,14 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
         const long long q = (long long)grp * 16 + p;
         const bool ok = q < a.NI;
         const long long qq = ok ? q : a.NI - 1;
-        const float xv = a.x[qq];
-        const float x0v = a.x0 ? a.x0[qq] : 0.f;
+        const float xv = io_ld(a.x, qq, a.x_bf16);
+        const float x0v = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
         const float dxv = xv - x0v;
-        const float gv = ok ? a.g[qq] : 0.f;
-        const float gfxv = (ok && a.gfx) ? a.gfx[qq] : 0.f;
+        const float gv = ok ? io_ld(a.g, qq, a.x_bf16) : 0.f;
+        const float gfxv = (ok && a.gfx) ? io_ld(a.gfx, qq, a.x_bf16) : 0.f;
         const float cotbase = gv * dxv * 0.5f;
         const long long bi = qq / d;
-        const float* hb = a.h + bi * ((long long)E * d) + (qq - bi * d);
+        const IoView hb = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
 
         f32x4 c[BT];
         {
@@ -377,8 +377,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
                     if (f < H1) a.dc[(size_t)part * a.NI * H1 + q * H1 + f] = dcs[t][r];
                 }
             if (g == 0) {
-                if (a.dx && k_lo == 0) a.dx[q] = fmaf(gfxv, dfdt, fxv * gv);
-                if (a.dx0 && k_hi == n + 1) a.dx0[q] = -fx0v * gv;
+                if (a.dx && k_lo == 0) io_st(a.dx, q, fmaf(gfxv, dfdt, fxv * gv), a.x_bf16);
+                if (a.dx0 && k_hi == n + 1) io_st(a.dx0, q, -fx0v * gv, a.x_bf16);
             }
         }
     }

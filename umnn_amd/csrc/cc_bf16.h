@@ -10,10 +10,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned short bf16_rn_bits(float x) {
-    const unsigned u = __float_as_uint(x);
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
+__device__ __forceinline__ unsigned short bf16_rn_bits(float x) { return f32_to_bf16_rn(x); }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {

@@ -19,6 +19,7 @@ struct BwdArgs {
     float* dx;                      // nullable
     float* dc;                      // [NI][H1] (EDGE pass)
     float* partials;                // [nwaves][n_params]
+    int x_bf16, h_bf16;             // storage of x, x0, g, g_fx, dx, dx0 / of h (and dh): 0 fp32, 1 bf16
     long long NI;
     int d, E, n;
     unsigned ngroups;               // tiles of 16 integrals

@@ -52,6 +52,29 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- fp32 / bf16 tensor I/O (configuration C4: bf16 activations around fp32 arithmetic) -----------------------------
+// The kernels compute in fp32 whatever the storage type; `bf16` flags say how x-class tensors (x, x0, g, F, f, z, log_jac,
+// dx) and h-class tensors (h, dh) are stored.  bf16 loads are exact widenings; stores round to nearest even.
+__device__ __forceinline__ unsigned short f32_to_bf16_rn(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float io_ld(const float* p, long long i, int bf16) {
+    return bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p)[i] << 16) : p[i];
+}
+__device__ __forceinline__ void io_st(float* p, long long i, float v, int bf16) {
+    if (bf16) reinterpret_cast<unsigned short*>(p)[i] = f32_to_bf16_rn(v);
+    else p[i] = v;
+}
+struct IoView {          // read-only view of an fp32 or bf16 array: view[i], view + offset
+    const float* p;
+    int bf16;
+    __device__ __forceinline__ float operator[](long long i) const { return io_ld(p, i, bf16); }
+    __device__ __forceinline__ IoView operator+(long long o) const {
+        return IoView{bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p) + o) : p + o, bf16};
+    }
+};
+
 // v_max_f32 without the canonicalising v_max(v,v) hipcc puts in front of fmaxf on MFMA results (fmaxf must quiet
 // signalling NaNs; the hardware instruction on already-finite data does not need it).  One VALU op instead of two.
 __device__ __forceinline__ float vmax_f32(float a, float b) {

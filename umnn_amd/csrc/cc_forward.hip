@@ -54,18 +54,18 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_kernel(const FwdArgs a) {
     for (int pt = 0; pt < P; ++pt) { Facc[pt] = 0.f; fxv[pt] = 0.f; fx0v[pt] = 0.f; ok[pt] = false; qv[pt] = 0; dxv[pt] = 0.f; }
 
     if (live) {
-        const float* hb[P];
+        IoView hb[P];
 #pragma unroll
         for (int pt = 0; pt < P; ++pt) {
             const long long q = ((long long)grp * P + pt) * 16 + p;
             ok[pt] = q < a.NI;
             const long long qq = ok[pt] ? q : a.NI - 1;
             qv[pt] = qq;
-            xv[pt] = a.x[qq];
-            x0v[pt] = a.x0 ? a.x0[qq] : 0.f;
+            xv[pt] = io_ld(a.x, qq, a.x_bf16);
+            x0v[pt] = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
             dxv[pt] = xv[pt] - x0v[pt];
             const long long bi = qq / d;
-            hb[pt] = a.h + bi * ((long long)E * d) + (qq - bi * d);
+            hb[pt] = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
         }
 
         // ---- per-lane constants: first-layer x-column and output-layer row (+ its bias)
@@ -241,7 +241,9 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
                           long long B, int d, int E, int inv_f,
                           float* F, float* f_x, float* f_x0, float* z, float* log_jac, hipStream_t stream,
                           int reverse_z = 0, const float* log_jac_in = nullptr,
-                          float* ll = nullptr, unsigned* row_cnt = nullptr, int ll_first = 0, int ll_last = 0) {
+                          float* ll = nullptr, unsigned* row_cnt = nullptr, int ll_first = 0, int ll_last = 0,
+                          const umnn_io* io = nullptr) {
+    if (int rc = umnn_check_io(io)) return rc;
     FwdArgs a;
     int tmax = 0, ksu = 0;
     if (int rc = umnn_prepare_mlp(net, E, &a.m, &tmax, &ksu)) return rc;
@@ -256,6 +258,9 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
     a.F = F; a.fx = f_x; a.fx0 = f_x0; a.scaling = scaling; a.z = z; a.logjac = log_jac;
     a.logjac_in = log_jac_in; a.reverse_z = reverse_z;
     a.ll = ll; a.row_cnt = row_cnt; a.ll_first = ll_first; a.ll_last = ll_last;
+    a.x_bf16 = io && io->x_dtype == UMNN_DTYPE_BF16; a.h_bf16 = io && io->h_dtype == UMNN_DTYPE_BF16;
+    a.inv_z = nullptr; a.inv_x = nullptr; a.inv_j = 0; a.inv_iters = 0;
+    if (ll && a.x_bf16) return umnn_fail(UMNN_EINVAL, "flow ll forward: z / log_jac scratch must be fp32");
     a.NI = B * (long long)d; a.d = d; a.E = E; a.n = nb_steps; a.inv_f = inv_f;
 
     // ---- choose the variant: exact (compile-time K-steps) when all hidden layers share a width we
@@ -346,6 +351,25 @@ extern "C" int umnn_flow_stack_block_forward(const umnn_mlp* net, const float* x
     if (z == x && reverse_z) return umnn_fail(UMNN_EINVAL, "flow forward: z must not alias x when reverse_z is set");
     return launch_forward(net, nullptr, x, h, scaling, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr, f_x, f_x0,
                           z, log_jac, (hipStream_t)stream, reverse_z != 0, log_jac_in);
+}
+
+extern "C" int umnn_cc_forward_io(const umnn_mlp* net, const umnn_io* io, const void* x0, const void* x, const void* h,
+                                  const float* cc_w, const float* cc_s, int nb_steps,
+                                  long long B, int d, int E, int inv_f, void* F, void* f_x, void* f_x0, void* stream) {
+    return launch_forward(net, (const float*)x0, (const float*)x, (const float*)h, nullptr, cc_w, cc_s, nb_steps, B, d, E, inv_f,
+                          (float*)F, (float*)f_x, (float*)f_x0, nullptr, nullptr, (hipStream_t)stream, 0, nullptr,
+                          nullptr, nullptr, 0, 0, io);
+}
+
+extern "C" int umnn_flow_stack_block_forward_io(const umnn_mlp* net, const umnn_io* io, const void* x, const void* h,
+                                                const float* scaling, const float* cc_w, const float* cc_s, int nb_steps,
+                                                long long B, int d, int E, int reverse_z, const void* log_jac_in,
+                                                void* z, void* log_jac, void* f_x, void* f_x0, void* stream) {
+    if (!scaling) return umnn_fail(UMNN_EINVAL, "flow forward: scaling must be non-null");
+    if (z == x && reverse_z) return umnn_fail(UMNN_EINVAL, "flow forward: z must not alias x when reverse_z is set");
+    return launch_forward(net, nullptr, (const float*)x, (const float*)h, scaling, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr,
+                          (float*)f_x, (float*)f_x0, (float*)z, (float*)log_jac, (hipStream_t)stream, reverse_z != 0,
+                          (const float*)log_jac_in, nullptr, nullptr, 0, 0, io);
 }
 
 extern "C" int umnn_flow_ll_block_forward(const umnn_mlp* net, const float* x, const float* h, const float* scaling,

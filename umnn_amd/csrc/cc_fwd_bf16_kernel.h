@@ -1,0 +1,556 @@
+// Forward quadrature with the hidden-layer GEMMs on the bf16 matrix cores, fp32 accuracy recovered by splitting.
+//
+// Why: on gfx950 the fp32-input MFMA runs at the fp32 VECTOR rate and (measured) time-shares the
+// SIMD's fp32 lanes with ordinary VALU work, so the exact-fp32 kernel is bounded by 32 cycles per 16x16x4 MFMA
+// PLUS ~3 cycles per VALU instruction.  v_mfma_f32_16x16x32_bf16 has 16x the rate on a separate pipe.  Every fp32
+// operand is split into bf16 pieces x = hi + lo (+ lo2), each the round-to-nearest bf16 of the running remainder,
+// and the product W*a is formed from the significant cross terms, accumulated in fp32 inside the MFMA:
+//     NPARTS = 2 (3 terms):  Whi*ahi + Whi*alo + Wlo*ahi                 error ~2^-16 per product (F to ~5e-6)
+//     NPARTS = 3 (6 terms):  + Whi*alo2 + Wlo2*ahi + Wlo*alo             error ~2^-24: fp32-level (F to ~4e-7)
+// Layer 1 (one FMA per feature), the hoisted first-layer term, the output dot product, ELU and the quadrature sum
+// stay in fp32.  Same reference lines as cc_forward.hip.
+//
+// Layout: the same feature numbering as the fp32 kernels, lane (g,p) / tile t / component r <-> feature 16t + 4r + g
+// (accumulator row rho = 4g + r of tile t is given output feature 16t + 4(rho&3) + (rho>>2) when the weight image
+// is staged).  Features are therefore dense in the register index 4t + r: a layer of width H has only
+// ceil((H+1)/4) live registers per lane (13 of 16 for H = 50) and the activation / split VALU work of the dead
+// ones is skipped (NRL template parameter).  One K-step of 16x16x32 consumes 32 features = two tiles (2s, 2s+1);
+// lane group g supplies k-slots 8g..8g+7 = its own 4 components of tile 2s followed by its 4 components of tile
+// 2s+1 -- again the accumulators of one layer ARE (after activation, splitting and packing) the B operands of the
+// next, with no cross-lane movement.  Weight fragments are pre-split and pre-permuted into LDS: fragment (tile t', K-step s, part)
+// is 64 lanes x 8 bf16 = 1 KiB, read with one ds_read_b128 per lane.
+#pragma once
+#include <type_traits>
+#include <utility>
+#include "cc_bf16.h"
+#include "cc_fwd_shared.h"
+#include "cc_host.h"
+
+// Stage the pre-split, pre-permuted weight fragments.  img16 index: ((t'*ks + s)*NPARTS + part)*512 + lane*8 + j.
+// half_in[l] != 0: the input layer has an odd tile count; ks counts its FULL K-steps (tile pairs) only and the last
+// tile follows as half fragments (64 lanes x 4 bf16, for the K = 16 MFMA) at ((t'*NPARTS + part)*256 + lane*4 + j)
+// behind the full ones -- the padding tile of a full K-step would cost 7 KB of LDS per layer and part at width 100.
+template <int NPARTS>
+__device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks32, const int* off16, const int* half_in,
+                                                  unsigned short* lds16, int tid, int nthreads) {
+    const int L = m.n_linear - 1;
+    for (int l = 1; l < L; ++l) {
+        const int Hin = m.width[l], Hout = m.width[l + 1];
+        const int ks = ks32[l], to = m.t_out[l + 1];
+        const float* __restrict__ W = m.W[l];
+        const float* __restrict__ b = m.b[l];
+        unsigned short* img = lds16 + off16[l];
+        const int total = to * ks * 512;
+#pragma unroll 8
+        for (int idx = tid; idx < total; idx += nthreads) {      // (unrolled: the weight loads of 8 iterations in flight)
+            const int j = idx & 7, ln = (idx >> 3) & 63, ts = idx >> 9;
+            const int s = ts % ks, t = ts / ks;
+            const int fo = fout_of(t, ln & 15);
+            const int fi = feat_of(2 * s + (j >> 2), j & 3, ln >> 4);
+            float v = 0.f;
+            if (fo < Hout) {
+                if (fi < Hin) v = W[fo * Hin + fi];
+                else if (fi == Hin) v = b[fo];
+            } else if (fo == Hout && fi == Hin) {
+                v = 1.f;
+            }
+#pragma unroll
+            for (int part = 0; part < NPARTS; ++part) {
+                const unsigned short hb = bf16_rn_bits(v);
+                img[(ts * NPARTS + part) * 512 + ln * 8 + j] = hb;
+                v -= bf16_bits_to_f32(hb);
+            }
+        }
+        if (half_in[l]) {
+            unsigned short* himg = img + to * ks * NPARTS * 512;
+            for (int idx = tid; idx < to * 256; idx += nthreads) {
+                const int j = idx & 3, ln = (idx >> 2) & 63, t = idx >> 8;
+                const int fo = fout_of(t, ln & 15);
+                const int fi = feat_of(2 * ks, j, ln >> 4);
+                float v = 0.f;
+                if (fo < Hout) {
+                    if (fi < Hin) v = W[fo * Hin + fi];
+                    else if (fi == Hin) v = b[fo];
+                } else if (fo == Hout && fi == Hin) {
+                    v = 1.f;
+                }
+#pragma unroll
+                for (int part = 0; part < NPARTS; ++part) {
+                    const unsigned short hb = bf16_rn_bits(v);
+                    himg[(t * NPARTS + part) * 256 + ln * 4 + j] = hb;
+                    v -= bf16_bits_to_f32(hb);
+                }
+            }
+        }
+    }
+}
+
+struct Bf16Plan {
+    int ks32[UMNN_MAX_LINEAR];     // K-steps of 32 features when hidden layer l is the input
+    int off16[UMNN_MAX_LINEAR];    // ushort offset of image l
+    int half_in[UMNN_MAX_LINEAR];  // layer l has an odd tile count and its image ends in half fragments (see staging)
+    int scratch_off_floats;        // float offset of the NS-reduction scratch (after the images)
+};
+
+struct FwdBf16Args {
+    FwdArgs f;
+    Bf16Plan pl;
+};
+
+// ---- software-pipelined node loop (PIPE variants: four tiles, two bf16 pieces, two point tiles per wave) -----------
+// tools/ubench/fill.hip: a wave may issue about two independent VALU instructions in the shadow of each
+// v_mfma_f32_16x16x32_bf16 for free, while VALU work issued between the matrix phases costs full price -- and the
+// activation / split work of a layer is ~130 VALU instructions against 48 MFMAs.  So the two point tiles of a wave run
+// half a layer out of phase: while the matrix pipe multiplies tile A by layer l, the VALU activates, splits and packs
+// tile B's layer l-1 output, and vice versa.  Every MFMA is followed by its slice of that work and a scheduling fence.
+// The weight fragments of a layer stay in registers for both tiles (LDS is read once per layer, during the second
+// tile's section, into registers whose last use has passed).
+// The VALU is the scarce unit here (3.9 vector instructions per MFMA, the matrix pipe 56 % busy), so the remainder
+// a - bf16(a) of the split is taken on the matrix pipe as well: one extra MFMA per tile with C = a, B = the freshly packed
+// leading pieces and A = a 0/-1 selection fragment returns the exact fp32 remainders of 16 features x 16 points, which
+// replaces shift / and / subtract on the VALU (5 -> 2 vector instructions per register pair, +3 MFMAs per section).
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// EXACT: every hidden layer fills exactly TMAX tiles, so tile / K-step counts are compile-time constants and the
+// wave-uniform guards (and the accumulator copies they force at every basic-block boundary) disappear.
+// NRL (EXACT only): live registers per lane = ceil((H+1)/4) for the common hidden width H; 0 = all 4*TMAX.
+// PIPE (EXACT, TMAX = 4, at least two hidden layers): the node loop is software-pipelined, see pipe_layer.
+// INV (plain loop, P = 1): the sampling direction.  A tile is one sample of one flow dimension j, its lanes p = 0..9 are the
+// ten candidates x = left + p/9 (right - left) of the reference's bracket search (UMNNMAF.invert, UMNNMAF.py:182-232: [-50, 50]
+// to start with, `iter` rounds, the new bracket is the pair of candidates around the one whose image is closest to the
+// target); every round integrates all ten candidates with the node loop below, the search itself is a 16-lane butterfly.
+// The hoisted first-layer term depends on the sample only and is computed once for all rounds.
+template <int TMAX, int NPARTS, int P, bool EXACT, int NRL, bool PIPE = false, bool INV = false>
+__global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Args args) {
+    static_assert(!INV || (P == 1 && !PIPE), "inversion variants: plain loop, one tile per wave");
+    constexpr int KSM = TMAX / 2;
+    constexpr int NLIVE = NRL > 0 ? NRL : 4 * TMAX;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const FwdArgs& a = args.f;
+    const MlpDev& m = a.m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, p = lane & 15;
+    const int L = m.n_linear - 1;
+    const int H1 = m.width[1], HL = m.width[L];
+    const int E = a.E, d = a.d, n = a.n;
+    const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
+    unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
+
+    stage_bf16_images<NPARTS>(m, args.pl.ks32, args.pl.off16, args.pl.half_in, lds16, tid, UMNN_BLOCK);
+    __syncthreads();
+
+    const int ns = a.ns;
+    const int sub = wid / ns, part = wid % ns;
+    const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
+    const unsigned grp = xcd_remap(blockIdx.x, gridDim.x) * gpb + sub;
+    const bool live = grp < a.ngroups;
+    const int k_lo = (int)(((long long)part * (n + 1)) / ns);
+    const int k_hi = (int)(((long long)(part + 1) * (n + 1)) / ns);
+
+    float Facc[P], fxv[P], fx0v[P], xv[P], x0v[P], dxv[P];
+    bool ok[P];
+    long long qv[P];
+#pragma unroll
+    for (int pt = 0; pt < P; ++pt) { Facc[pt] = 0.f; fxv[pt] = 0.f; fx0v[pt] = 0.f; ok[pt] = false; qv[pt] = 0; dxv[pt] = 0.f; }
+
+    if (live) {
+        IoView hb[P];
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            if constexpr (INV) {
+                const long long b = (long long)grp * P + pt;             // the tile's sample
+                ok[pt] = b < a.NI;
+                qv[pt] = ok[pt] ? b : a.NI - 1;
+                xv[pt] = 0.f; x0v[pt] = 0.f; dxv[pt] = 0.f;              // set per round
+                hb[pt] = IoView{a.h, a.h_bf16} + (qv[pt] * ((long long)E * d) + a.inv_j);
+            } else {
+                const long long q = ((long long)grp * P + pt) * 16 + p;
+                ok[pt] = q < a.NI;
+                const long long qq = ok[pt] ? q : a.NI - 1;
+                qv[pt] = qq;
+                xv[pt] = io_ld(a.x, qq, a.x_bf16);
+                x0v[pt] = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
+                dxv[pt] = xv[pt] - x0v[pt];
+                const long long bi = qq / d;
+                hb[pt] = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
+            }
+        }
+
+        // per-lane constants and the hoisted first-layer term (fp32 MFMA, natural row order)
+        float w1x[TMAX][4], wout[TMAX][4];
+        f32x4 c[P][TMAX];
+        {
+            const float* __restrict__ W0 = m.W[0];
+            const float* __restrict__ b0 = m.b[0];
+            const float* __restrict__ WL = m.W[L];
+            const float bL = m.b[L][0];
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) {
+                f32x4 init;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = feat_of(t, r, g);
+                    w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
+                    wout[t][r] = f < HL ? WL[f] : (f == HL ? bL : 0.f);
+                    init[r] = f < H1 ? b0[f] : (f == H1 ? 1.f : 0.f);
+                }
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt) c[pt][t] = init;
+            }
+            const int t1 = EXACT ? TMAX : m.t_out[1];
+            // eight K-steps (32 embedding entries) at a time: all their h and W1 loads are issued before the first
+            // MFMA needs one -- one memory round trip per chunk instead of one per step (h comes from HBM)
+            const int nse = (E + 3) / 4;
+            for (int se0 = 0; se0 < nse; se0 += 8) {
+                float hv[P][8], Av[TMAX][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = 4 * (se0 + j) + g;
+                    const bool in = se0 + j < nse && e < E;
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt) hv[pt][j] = in ? hb[pt][(long long)e * d] : 0.f;
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) {
+                        const int fo = fout_of(t, p);
+                        Av[t][j] = (in && (EXACT || t < t1) && fo < H1) ? W0[fo * (1 + E) + 1 + e] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (se0 + j < nse) {
+#pragma unroll
+                        for (int t = 0; t < TMAX; ++t)
+                            if (EXACT || t < t1) {
+#pragma unroll
+                                for (int pt = 0; pt < P; ++pt) c[pt][t] = mfma16(Av[t][j], hv[pt][j], c[pt][t]);
+                            }
+                    }
+                }
+            }
+        }
+
+        if constexpr (PIPE) {
+            static_assert(TMAX == 4 && EXACT && NPARTS == 2 && P == 2, "pipelined loop: 4 tiles, 2 pieces, 2 point tiles");
+            constexpr int NSLOT = 24;                               // MFMAs of one point tile in one layer
+            constexpr int NFULL = NLIVE / 4;                        // tiles with all four registers live
+            static_assert(NLIVE % 4 == 0 || (NLIVE % 4 == 1 && NFULL == 3), "pipelined loop: 13 or 16 live registers");
+            using Slots = std::make_integer_sequence<int, NSLOT>;
+            u32x4 wf[4][2][2];                                      // [tile][K-step][piece] of the layer in flight
+            u32x4 bf[2][2][2];                                      // [point tile][K-step][piece]
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) bf[pt][ks][k2] = u32x4{0u, 0u, 0u, 0u};
+            // 0/-1 selection fragments: row rho of an output tile picks k-slot 8*(rho>>2) + (rho&3) (even tile of the
+            // K-step) or + 4 (odd tile) -- the slot in which lane group rho>>2 packed that very feature
+            u32x4 sel[2];
+            {
+                const unsigned rho = lane & 15, slot = rho & 3;
+                const unsigned v = ((unsigned)(lane >> 4) == (rho >> 2)) ? (0xBF80u << (16 * (slot & 1))) : 0u;   // bf16(-1)
+                sel[0] = u32x4{slot < 2 ? v : 0u, slot < 2 ? 0u : v, 0u, 0u};
+                sel[1] = u32x4{0u, 0u, slot < 2 ? v : 0u, slot < 2 ? 0u : v};
+            }
+            float rem_a = 0.f;                                      // the single live register of tile 3 (13-register shape)
+            unsigned rem_hi = 0u;
+            auto frag = [&](int l, int t, int ks, int k2) {
+                return *reinterpret_cast<const u32x4*>(lds16 + args.pl.off16[l] + lane * 8 + ((t * 2 + ks) * 2 + k2) * 512);
+            };
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) wf[t][ks][k2] = frag(1, t, ks, k2);
+            // slot i of a section: K-step i/12, cross term (i/4)%3 = (W piece, activation piece) (0,0),(0,1),(1,0), tile i%4
+            auto mfma_slot = [&](auto ic, const u32x4 (&bfin)[2][2], f32x4 (&acc)[4]) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / 12, term = (i / 4) % 3, t = i % 4;
+                constexpr int wa = term == 2 ? 1 : 0, ba = term == 1 ? 1 : 0;
+                if constexpr (i < 4) acc[t] = mfma_bf16(wf[t][ks][wa], bfin[ks][ba], f32x4{0.f, 0.f, 0.f, 0.f});
+                else acc[t] = mfma_bf16(wf[t][ks][wa], bfin[ks][ba], acc[t]);
+            };
+            // in the second tile's section: once a fragment has been used for the last time, fetch the same
+            // fragment of the layer that runs next into its registers
+            auto reload_slot = [&](auto ic, int lnext) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / 12, term = (i / 4) % 3, t = i % 4;
+                if constexpr (term == 1) wf[t][ks][0] = frag(lnext, t, ks, 0);
+                if constexpr (term == 2) wf[t][ks][1] = frag(lnext, t, ks, 1);
+            };
+            // The packing work of one point tile, in place on its raw pre-activations z[4], one slice per MFMA slot so that
+            // (almost) every slice fits the two-instruction issue shadow of the slot's MFMA:
+            //   act(t,r)  register r of tile t:  z <- LeakyReLU(z)   (FIRST: z = w1x*t_k + c first)         2-3 VALU
+            //   hi(t)     leading pieces of tile t packed into bf[t/2][0], then  z[t] <- z[t] - bf16(z[t])  on the matrix
+            //             pipe                                                                       2 VALU + 1 MFMA
+            //   lo(t)     second pieces packed into bf[t/2][1] (two slots after hi(t): the MFMA has landed)    2 VALU
+            // slots   tile 0: act 0-3, hi 4, lo 10     tile 1: act 5-8, hi 9, lo 16     tile 2: act 11-14, hi 15, lo 20
+            //         tile 3: act 17-20, hi 21, lo 23  -- or, with one live register, split on the VALU in slots 17, 18
+            auto pack_slot = [&](auto ic, auto first, f32x4 (&z)[4], u32x4 (&bfout)[2][2], float tkv, const f32x4 (&cv)[TMAX]) {
+                constexpr int i = decltype(ic)::value;
+                constexpr bool FIRST = decltype(first)::value;
+                constexpr int t_act = i <= 3 ? 0 : (i >= 5 && i <= 8) ? 1 : (i >= 11 && i <= 14) ? 2 : (NFULL == 4 && i >= 17 && i <= 20) ? 3 : -1;
+                constexpr int r_act = t_act == 0 ? i : t_act == 1 ? i - 5 : t_act == 2 ? i - 11 : i - 17;
+                constexpr int t_hi = i == 4 ? 0 : i == 9 ? 1 : i == 15 ? 2 : (NFULL == 4 && i == 21) ? 3 : -1;
+                constexpr int t_lo = i == 10 ? 0 : i == 16 ? 1 : i == 20 ? 2 : (NFULL == 4 && i == 23) ? 3 : -1;
+                if constexpr (t_act >= 0) {
+                    if constexpr (FIRST) z[t_act][r_act] = fmaf(w1x[t_act][r_act], tkv, cv[t_act][r_act]);
+                    z[t_act][r_act] = hidden_act_f(z[t_act][r_act], slope);
+                }
+                if constexpr (t_hi >= 0) {
+                    const bf16x2 h0 = __builtin_convertvector(f32x2{z[t_hi][0], z[t_hi][1]}, bf16x2);
+                    const bf16x2 h1 = __builtin_convertvector(f32x2{z[t_hi][2], z[t_hi][3]}, bf16x2);
+                    bfout[t_hi / 2][0][2 * (t_hi % 2)] = __builtin_bit_cast(unsigned, h0);
+                    bfout[t_hi / 2][0][2 * (t_hi % 2) + 1] = __builtin_bit_cast(unsigned, h1);
+                    z[t_hi] = mfma_bf16(sel[t_hi % 2], bfout[t_hi / 2][0], z[t_hi]);          // exact remainders
+                }
+                if constexpr (t_lo >= 0) {
+                    const bf16x2 l0 = __builtin_convertvector(f32x2{z[t_lo][0], z[t_lo][1]}, bf16x2);
+                    const bf16x2 l1 = __builtin_convertvector(f32x2{z[t_lo][2], z[t_lo][3]}, bf16x2);
+                    bfout[t_lo / 2][1][2 * (t_lo % 2)] = __builtin_bit_cast(unsigned, l0);
+                    bfout[t_lo / 2][1][2 * (t_lo % 2) + 1] = __builtin_bit_cast(unsigned, l1);
+                }
+                if constexpr (NFULL == 3 && i == 17) {           // tile 3 has one live register: split it on the VALU
+                    if constexpr (FIRST) z[3][0] = fmaf(w1x[3][0], tkv, cv[3][0]);
+                    rem_a = hidden_act_f(z[3][0], slope);
+                    const bf16x2 h = __builtin_convertvector(f32x2{rem_a, 0.f}, bf16x2);
+                    rem_hi = __builtin_bit_cast(unsigned, h);
+                    bfout[1][0][2] = rem_hi;
+                }
+                if constexpr (NFULL == 3 && i == 18) {
+                    const bf16x2 l = __builtin_convertvector(f32x2{rem_a - __uint_as_float(rem_hi << 16), 0.f}, bf16x2);
+                    bfout[1][1][2] = __builtin_bit_cast(unsigned, l);
+                }
+            };
+
+            for (int k = k_lo; k < k_hi; ++k) {
+                const float u = a.ccs[k] + 1.f;
+                const float wk = a.ccw[k];
+                float tk[2];
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) tk[pt] = k == 0 ? xv[pt] : __fadd_rn(x0v[pt], __fmul_rn(dxv[pt], u) * 0.5f);
+                f32x4 acc0[4], acc1[4];
+                constexpr std::true_type kFirst{};
+                constexpr std::false_type kLater{};
+                // first tile: layer 1 on the VALU, nothing to hide behind yet
+                static_for(Slots{}, [&](auto ic) { pack_slot(ic, kFirst, acc0, bf[0], tk[0], c[0]); });
+                __builtin_amdgcn_sched_barrier(0);
+                // section A of layer 1: first tile on the matrix pipe, second tile's layer 1 + packing on the VALU
+                static_for(Slots{}, [&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    mfma_slot(ic, bf[0], acc0);
+                    pack_slot(ic, kFirst, acc1, bf[1], tk[1], c[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                for (int l = 1; l + 1 < L; ++l) {
+                    // section B of layer l: second tile on the matrix pipe, first tile's output packed for layer l+1
+                    static_for(Slots{}, [&](auto ic) {
+                        mfma_slot(ic, bf[1], acc1);
+                        pack_slot(ic, kLater, acc0, bf[0], 0.f, c[0]);
+                        reload_slot(ic, l + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    // section A of layer l+1
+                    static_for(Slots{}, [&](auto ic) {
+                        mfma_slot(ic, bf[0], acc0);
+                        pack_slot(ic, kLater, acc1, bf[1], 0.f, c[1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                }
+                // section B of the last hidden layer: the first tile's output goes into the output dot product
+                float sd0 = 0.f, sd1 = 0.f;
+                static_for(Slots{}, [&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    mfma_slot(ic, bf[1], acc1);
+                    if constexpr (i < NLIVE) sd0 = fmaf(wout[i / 4][i % 4], hidden_act_f(acc0[i / 4][i % 4], slope), sd0);
+                    reload_slot(ic, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * t + r < NLIVE) sd1 = fmaf(wout[t][r], hidden_act_f(acc1[t][r], slope), sd1);
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const float sr = group_allreduce(pt == 0 ? sd0 : sd1);
+                    const float f = out_act_f(sr, m.out_act);
+                    Facc[pt] = fmaf(wk, a.inv_f ? 1.f / f : f, Facc[pt]);
+                    if (k == 0) fxv[pt] = f;
+                    if (k == n) fx0v[pt] = f;
+                }
+            }
+        } else {
+        // ---- bracket search state (INV): one sample per tile, candidate p on lane p ----
+        float br_left = -50.f, br_right = 50.f, br_best = 0.f, inv_target = 0.f, inv_off = 0.f, inv_scale = 1.f, frac = 1.f;
+        if constexpr (INV) {
+            frac = p < 10 ? (float)((double)p / 9.0) : 1.f;            // x_range of the reference: k * (1/9) in double, cast
+
+            inv_target = a.inv_z[qv[0] * d + a.inv_j];
+            inv_off = hb[0][0];                                        // embedding row 0 of dimension j: the offset
+            inv_scale = __expf(a.scaling[a.inv_j]);
+        }
+        const int rounds = INV ? a.inv_iters : 1;
+        for (int round = 0; round < rounds; ++round) {
+        if constexpr (INV) {
+            xv[0] = __fadd_rn(__fmul_rn(frac, br_right - br_left), br_left);      // x_range * (right - left) + left
+            dxv[0] = xv[0];
+            Facc[0] = 0.f;
+        }
+        for (int k = k_lo; k < k_hi; ++k) {
+            const float u = a.ccs[k] + 1.f;
+            const float wk = a.ccw[k];
+            f32x4 act[P][TMAX];
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) {
+                const float tk = k == 0 ? xv[pt] : __fadd_rn(x0v[pt], __fmul_rn(dxv[pt], u) * 0.5f);
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        act[pt][t][r] = 4 * t + r < NLIVE ? hidden_act_f(fmaf(w1x[t][r], tk, c[pt][t][r]), slope) : 0.f;
+            }
+
+            for (int l = 1; l < L; ++l) {
+                const int ks = EXACT ? KSM : args.pl.ks32[l], to = EXACT ? TMAX : m.t_out[l + 1];
+                const unsigned short* img = lds16 + args.pl.off16[l] + lane * 8;
+                // split + pack the activations into B fragments: K-step s <- tiles 2s, 2s+1
+                u32x4 bf[P][KSM][NPARTS];
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                    for (int s = 0; s < KSM; ++s) {
+                        unsigned q0[NPARTS], q1[NPARTS], q2[NPARTS], q3[NPARTS];
+#pragma unroll
+                        for (int k2 = 0; k2 < NPARTS; ++k2) q0[k2] = q1[k2] = q2[k2] = q3[k2] = 0u;
+                        if (8 * s + 0 < NLIVE) split_pair<NPARTS>(act[pt][2 * s][0], act[pt][2 * s][1], q0);
+                        if (8 * s + 2 < NLIVE) split_pair<NPARTS>(act[pt][2 * s][2], act[pt][2 * s][3], q1);
+                        if (8 * s + 4 < NLIVE) split_pair<NPARTS>(act[pt][2 * s + 1][0], act[pt][2 * s + 1][1], q2);
+                        if (8 * s + 6 < NLIVE) split_pair<NPARTS>(act[pt][2 * s + 1][2], act[pt][2 * s + 1][3], q3);
+#pragma unroll
+                        for (int k2 = 0; k2 < NPARTS; ++k2) bf[pt][s][k2] = u32x4{q0[k2], q1[k2], q2[k2], q3[k2]};
+                    }
+                // odd tile count (EXACT only): the last tile is a K = 16 step of its own
+                u32x2 hb[P][NPARTS];
+                if constexpr (EXACT && (TMAX & 1)) {
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt) {
+                        unsigned q0[NPARTS], q1[NPARTS];
+#pragma unroll
+                        for (int k2 = 0; k2 < NPARTS; ++k2) q0[k2] = q1[k2] = 0u;
+                        if (4 * (TMAX - 1) + 0 < NLIVE) split_pair<NPARTS>(act[pt][TMAX - 1][0], act[pt][TMAX - 1][1], q0);
+                        if (4 * (TMAX - 1) + 2 < NLIVE) split_pair<NPARTS>(act[pt][TMAX - 1][2], act[pt][TMAX - 1][3], q1);
+#pragma unroll
+                        for (int k2 = 0; k2 < NPARTS; ++k2) hb[pt][k2] = u32x2{q0[k2], q1[k2]};
+                    }
+                }
+                f32x4 acc[P][TMAX];
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) acc[pt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KSM; ++s) {
+                    if (EXACT || s < ks) {
+                        u32x4 wf[TMAX][NPARTS];
+#pragma unroll
+                        for (int t = 0; t < TMAX; ++t)
+                            if (EXACT || t < to) {
+#pragma unroll
+                                for (int k2 = 0; k2 < NPARTS; ++k2)
+                                    wf[t][k2] = *reinterpret_cast<const u32x4*>(img + ((t * ks + s) * NPARTS + k2) * 512);
+                            }
+                        // cross terms in order of decreasing magnitude; consecutive MFMAs hit different accumulators
+#pragma unroll
+                        for (int wa = 0; wa < NPARTS; ++wa)
+#pragma unroll
+                            for (int ba = 0; ba < NPARTS; ++ba) {
+                                if (wa + ba >= NPARTS) continue;      // 2 parts: hh,hl,lh ; 3 parts: + h l2, l2 h, l l
+#pragma unroll
+                                for (int t = 0; t < TMAX; ++t)
+                                    if (EXACT || t < to) {
+#pragma unroll
+                                        for (int pt = 0; pt < P; ++pt)
+                                            acc[pt][t] = mfma_bf16(wf[t][wa], bf[pt][s][ba], acc[pt][t]);
+                                    }
+                            }
+                    }
+                }
+                if constexpr (EXACT && (TMAX & 1)) {
+                    const unsigned short* himg = lds16 + args.pl.off16[l] + TMAX * KSM * NPARTS * 512 + lane * 4;
+                    u32x2 wh[TMAX][NPARTS];
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                        for (int k2 = 0; k2 < NPARTS; ++k2)
+                            wh[t][k2] = *reinterpret_cast<const u32x2*>(himg + (t * NPARTS + k2) * 256);
+#pragma unroll
+                    for (int wa = 0; wa < NPARTS; ++wa)
+#pragma unroll
+                        for (int ba = 0; ba < NPARTS; ++ba) {
+                            if (wa + ba >= NPARTS) continue;
+#pragma unroll
+                            for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                                for (int pt = 0; pt < P; ++pt)
+                                    acc[pt][t] = mfma_bf16_k16(wh[t][wa], hb[pt][ba], acc[pt][t]);
+                        }
+                }
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            act[pt][t][r] = ((EXACT || t < to) && 4 * t + r < NLIVE) ? hidden_act_f(acc[pt][t][r], slope) : 0.f;
+            }
+
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * t + r < NLIVE) s = fmaf(wout[t][r], act[pt][t][r], s);
+                s = group_allreduce(s);
+                const float f = out_act_f(s, m.out_act);
+                Facc[pt] = fmaf(wk, a.inv_f ? 1.f / f : f, Facc[pt]);
+                if (k == 0) fxv[pt] = f;
+                if (k == n) fx0v[pt] = f;
+            }
+        }
+        if constexpr (INV) {
+            // image of every candidate, then argmin_p |z_est - target| over the ten candidate lanes (ties: lower p)
+            const float z_est = inv_scale * (inv_off + Facc[0] * dxv[0] * 0.5f);
+            float dist = p < 10 ? fabsf(z_est - inv_target) : __builtin_inff();
+            float zm = z_est;
+            int m = p;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const float d2 = __shfl_xor(dist, o, 16), z2 = __shfl_xor(zm, o, 16);
+                const int m2 = __shfl_xor(m, o, 16);
+                const bool take = d2 < dist || (d2 == dist && m2 < m);
+                dist = take ? d2 : dist; zm = take ? z2 : zm; m = take ? m2 : m;
+            }
+            const float span = br_right - br_left;
+            const float lo = __fadd_rn(__fmul_rn((float)((double)(m > 0 ? m - 1 : 0) / 9.0), span), br_left);
+            const float hi = __fadd_rn(__fmul_rn((float)((double)(m < 9 ? m + 1 : 9) / 9.0), span), br_left);
+            br_best = __fadd_rn(__fmul_rn((float)((double)m / 9.0), span), br_left);
+            const bool below = zm < inv_target;
+            br_left = below ? br_best : lo;
+            br_right = below ? hi : br_best;
+        }
+        }   // rounds
+        if constexpr (INV) {
+            if (ok[0] && lane == 0) a.inv_x[qv[0] * d + a.inv_j] = br_best;
+        }
+        }
+    }
+    if constexpr (!INV) fwd_epilogue<P>(a, lds, Facc, fxv, fx0v, ok, qv, dxv, live, part, ns, wid, g, p);
+}
+

@@ -21,6 +21,12 @@ struct FwdArgs {
     float* ll;                // [B] running log-likelihood; nullable => off
     unsigned* row_cnt;        // [B] arrival counters: zero on entry, zero again on exit
     int ll_first, ll_last;    // first block overwrites ll; last block adds -1/2 sum_i (log 2pi + z^2)
+    // in-kernel inversion (umnn_flow_invert_dim, INV kernel variants): one 16-point tile = ONE sample, its points are
+    // the 10 candidates of a bracket-search round; NI counts samples, d is the flow's full dimension
+    const float* inv_z;       // [B, d] targets; column inv_j is used
+    float* inv_x;             // [B, d] result; column inv_j is written
+    int inv_j, inv_iters;
+    int x_bf16, h_bf16;       // storage of the x-class tensors (x, x0, F, f_x, f_x0, z, log_jac) / of h: 0 fp32, 1 bf16
     long long NI;      // B*d integrals
     int d, E, n, ns, inv_f;
     unsigned ngroups;  // tile groups (of 16*P integrals)
@@ -62,17 +68,17 @@ __device__ __forceinline__ void fwd_epilogue(const FwdArgs& a, float* lds, float
             if (!ok[pt]) continue;
             const long long q = qv[pt];
             const float Fv = Facc[pt] * dxv[pt] * 0.5f;
-            if (a.F) a.F[q] = Fv;
-            if (a.fx) a.fx[q] = fxv[pt];
-            if (a.fx0) a.fx0[q] = fx0v[pt];
+            if (a.F) io_st(a.F, q, Fv, a.x_bf16);
+            if (a.fx) io_st(a.fx, q, fxv[pt], a.x_bf16);
+            if (a.fx0) io_st(a.fx0, q, fx0v[pt], a.x_bf16);
             if (a.scaling) {
                 const long long bi = q / d;
                 const int i = (int)(q - bi * d);
                 const float sc = a.scaling[i];
-                const float z0 = a.h[bi * ((long long)E * d) + i];
-                a.z[a.reverse_z ? bi * d + (d - 1 - i) : q] = __expf(sc) * (Fv + z0);
+                const float z0 = io_ld(a.h, bi * ((long long)E * d) + i, a.h_bf16);
+                io_st(a.z, a.reverse_z ? bi * d + (d - 1 - i) : q, __expf(sc) * (Fv + z0), a.x_bf16);
                 const float lj = __logf(fxv[pt] + 1e-10f) + sc;
-                a.logjac[q] = a.logjac_in ? a.logjac_in[q] + lj : lj;
+                io_st(a.logjac, q, a.logjac_in ? io_ld(a.logjac_in, q, a.x_bf16) + lj : lj, a.x_bf16);
             }
         }
     }

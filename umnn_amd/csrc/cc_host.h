@@ -11,6 +11,7 @@ int umnn_check(hipError_t e, const char* what);           // 0 or records + retu
 // Validates `net`, fills the device-side descriptor (tile / K-step counts, LDS offsets) and reports
 // tmax = max tiles over hidden layers and ksu = the common K-step count if all hidden layers agree (else 0).
 int umnn_prepare_mlp(const umnn_mlp* net, int E, MlpDev* out, int* tmax, int* ksu);
+int umnn_check_io(const umnn_io* io);                     // 0, or UMNN_EINVAL for an unknown dtype code
 int umnn_num_cus();                                      // CU count of the CURRENT device (cached per device)
 
 // Process-wide launch options.  The UMNN_* environment variables are read ONCE (first use, or umnn_reload_env());

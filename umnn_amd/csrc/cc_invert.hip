@@ -1,0 +1,87 @@
+// Sampling direction of a UMNNMAF block on the matrix cores: the reference's dimension-by-dimension bracket search
+// (UMNNMAF.invert, models/UMNN/UMNNMAF.py:182-232, driven by UMNNMAFFlow.invert, UMNNMAFFlow.py:78-90) with the WHOLE search of
+// one dimension -- `iter` rounds x 10 candidate integrals per sample -- inside one launch.  The reference issues, per
+// dimension and round, a ParallelNeuralIntegral over [10*B, 1] rows (plus a MADE pass per dimension); here one dimension is
+// the MADE pass + ONE launch of an INV variant of cc_fwd_bf16_kernel (cc_fwd_bf16_kernel.h): tile = sample, lane p = candidate
+// p, the hoisted first-layer term computed once per sample, the argmin / new bracket a 16-lane butterfly between rounds.
+// Arithmetic: bf16x3 split products (F to ~6e-6 relative), orders of magnitude inside the search's own resolution
+// (100 * (2/9)^iter).
+#include "cc_fwd_bf16_kernel.h"
+
+typedef void (*inv_kernel_t)(const FwdBf16Args);
+struct InvVariant { int tmax, exact, nrl; inv_kernel_t fn; const char* name; };
+#define INV_VARIANT(T, EX, NR) { T, EX, NR, cc_fwd_bf16_kernel<T, 2, 1, (EX) != 0, NR, false, true>, "cc_invert_bf16<T=" #T ",EXACT=" #EX ",LIVE=" #NR ">" }
+static const InvVariant kInvVariants[] = {
+    INV_VARIANT(4, 1, 13), INV_VARIANT(4, 1, 0),       // UCI / VAE nets (31-50^4-1) and every other 3..4-tile net (zero-padded)
+    INV_VARIANT(7, 1, 26), INV_VARIANT(7, 1, 0),       // 100-wide toy nets
+    INV_VARIANT(5, 1, 0), INV_VARIANT(6, 1, 0), INV_VARIANT(8, 1, 0),
+    INV_VARIANT(2, 0, 0), INV_VARIANT(4, 0, 0), INV_VARIANT(8, 0, 0),   // generic (runtime tile counts): mixed widths, e.g. 100-50-50-50-50
+};
+
+extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const float* z, const float* scaling,
+                                    const float* cc_w, const float* cc_s, int nb_steps,
+                                    long long B, int d, int E, int j, int iters, float* x_inv, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FwdBf16Args args;
+    FwdArgs& a = args.f;
+    int tmax = 0, ksu = 0;
+    if (int rc = umnn_prepare_mlp(net, E, &a.m, &tmax, &ksu)) return rc;
+    if (nb_steps < 1 || iters < 1) return umnn_fail(UMNN_EINVAL, "invert: nb_steps and iters must be >= 1");
+    if (B < 0 || d < 1 || j < 0 || j >= d) return umnn_fail(UMNN_EINVAL, "invert: B >= 0, d >= 1, 0 <= j < d");
+    if (B == 0) return 0;
+    if (!h || !z || !scaling || !cc_w || !cc_s || !x_inv) return umnn_fail(UMNN_EINVAL, "invert: null pointer");
+    const int L = a.m.n_linear - 1;
+    if (L < 2) return umnn_fail(UMNN_EUNSUPPORTED, "invert: the matrix-core kernels need at least two hidden layers");
+    a.x0 = nullptr; a.x = nullptr; a.h = h; a.ccw = cc_w; a.ccs = cc_s;
+    a.F = a.fx = a.fx0 = nullptr; a.scaling = scaling; a.z = nullptr; a.logjac = nullptr; a.logjac_in = nullptr;
+    a.reverse_z = 0; a.ll = nullptr; a.row_cnt = nullptr; a.ll_first = a.ll_last = 0;
+    a.inv_z = z; a.inv_x = x_inv; a.inv_j = j; a.inv_iters = iters;
+    a.NI = B; a.d = d; a.E = E; a.n = nb_steps; a.inv_f = 0; a.ns = 1; a.x_bf16 = 0; a.h_bf16 = 0;
+
+    // ---- plan (the P = 1, two-piece subset of umnn_launch_forward_bf16's) ----
+    int T = tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8;
+    int wide = tmax >= 5 ? tmax : 0;
+    for (int l = 1; l <= L && wide; ++l) if (a.m.t_out[l] != wide) wide = 0;
+    if (wide) T = wide;
+    int off16 = 0;
+    for (int l = 1; l <= L; ++l) {
+        args.pl.half_in[l] = wide ? (wide & 1) : 0;
+        args.pl.ks32[l] = wide ? wide / 2 : (a.m.t_out[l] + 1) / 2;
+    }
+    for (int l = 1; l < L; ++l) {
+        args.pl.off16[l] = off16;
+        off16 += a.m.t_out[l + 1] * (args.pl.ks32[l] * 2 * 512 + args.pl.half_in[l] * 2 * 256);
+    }
+    int exact = 1, nrl = a.m.ks_in[1];
+    for (int l = 1; l <= L; ++l) {
+        exact = exact && a.m.t_out[l] == T;
+        if (a.m.ks_in[l] != nrl) nrl = 0;
+    }
+    if (!exact && !wide && tmax <= 4 && tmax >= 3) {       // mixed 3..4-tile nets: zero-pad to the shape-exact kernel
+        T = 4; exact = 1; nrl = 0;
+        for (int l = 1; l <= L; ++l) { a.m.t_out[l] = 4; args.pl.ks32[l] = 2; }
+        off16 = 0;
+        for (int l = 1; l < L; ++l) { args.pl.off16[l] = off16; off16 += 4 * 2 * 2 * 512; }
+    }
+    a.m.lds_off[L] = (((off16 + 1) / 2) + 3) & ~3;
+    const size_t lds_bytes = (size_t)a.m.lds_off[L] * sizeof(float);
+    if (lds_bytes > 160 * 1024) return umnn_fail(UMNN_EUNSUPPORTED, "invert: weight images exceed 160 KiB of LDS");
+    // exact variant for (T, live registers) if instantiated, else the generic one of the tile-count bucket (runtime counts:
+    // only reached by unpadded plans -- every padded or wide plan has its exact variant above)
+    const InvVariant* pick = nullptr;
+    for (int ex = exact; ex >= 0 && !pick; --ex)
+        for (int pass = 0; pass < 2 && !pick; ++pass)
+            for (const InvVariant& v : kInvVariants)
+                if (v.tmax == (ex ? T : (tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8)) && v.exact == ex &&
+                    (pass == 0 ? (ex && nrl && v.nrl == nrl) : v.nrl == 0)) { pick = &v; break; }
+    if (!pick) return umnn_fail(UMNN_EUNSUPPORTED, "invert: no kernel variant for this shape");
+    if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
+    a.ngroups = (unsigned)B;                                  // one tile (= one sample) per wave
+    const unsigned nblk = (a.ngroups + UMNN_WAVES_PER_BLOCK - 1) / UMNN_WAVES_PER_BLOCK;
+    umnn_prof_begin(stream);
+    hipLaunchKernelGGL(pick->fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
+    // algorithmic work: iters rounds x 10 candidate integrals per sample
+    umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * 10.0 * iters * (double)B);
+    umnn_note_launch(pick->name);
+    return umnn_check(hipGetLastError(), "cc_invert launch");
+}

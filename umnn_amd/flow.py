@@ -35,6 +35,7 @@ class EmbeddingNetwork(nn.Module):
                  cond_in=0, act_func='ELU', device="cpu"):
         super().__init__()
         self.m_embeding = None
+        self.embedding_dtype = None     # None: whatever the conditioner computes in; torch.bfloat16: configuration C4
         self.device = device
         self.in_d = in_d
         if cond_in > 0:
@@ -55,9 +56,9 @@ class EmbeddingNetwork(nn.Module):
         # .raw(): the masked MLP itself.  (The reference calls MADE.forward, whose nout==2 "Gaussian" branch
         # breaks the d=2/E=1 and d=1/E=2 flows, made.py:114-118; the embedding never wants that branch.)
         if isinstance(self.made, ConditionnalMADE):
-            self.m_embeding = self.made.raw(x_made, context)
+            self.m_embeding = self.made.raw(x_made, context, out_dtype=self.embedding_dtype)
         else:
-            self.m_embeding = self.made.raw(x_made)
+            self.m_embeding = self.made.raw(x_made, out_dtype=self.embedding_dtype)
         return self.m_embeding
 
     def forward(self, x_t):
@@ -203,6 +204,22 @@ class UMNNMAF(nn.Module):
         K = 10
         B, d = z.shape
         dev = z.device
+        spec = mlp_spec(self.net.parallel_nets)
+        if (_I._use_hip(spec, z) and z.dtype == torch.float32 and self.nb_steps >= 1 and iter >= 1 and B > 0
+                and self.solver in _SOLVERS):
+            # d x (conditioner + ONE launch): the whole 10-way / `iter`-round search of a dimension runs inside the kernel
+            with torch.no_grad():
+                z = z.contiguous()
+                x_inv = torch.zeros(B, d, device=dev)
+                scaling = self.scaling.detach().float().contiguous()
+                done = True
+                for j in range(self.input_size):
+                    h = self.net.make_embeding(x_inv, context).contiguous()
+                    if not _I.hip_invert_dim(spec, h, z, scaling, self.nb_steps, j, iter, x_inv):
+                        done = False
+                        break
+            if done:
+                return x_inv
         frac = torch.linspace(0., 1., K, device=dev).view(K, 1)
         x_inv = torch.zeros(B, d, device=dev)
         scale = torch.exp(self.scaling)
@@ -309,6 +326,8 @@ class UMNNMAFFlow(nn.Module):
         for net in self.nets:
             if net.solver not in _SOLVERS or net.nb_steps < 1 or not _I._use_hip(mlp_spec(net.net.parallel_nets), x):
                 return False
+            if net.net.embedding_dtype not in (None, torch.float32) or torch.is_autocast_enabled():
+                return False                        # (the one-pass entry point is fp32-only; bf16 storage takes the _io route)
         if not torch.is_grad_enabled():
             return True
         return not (x.requires_grad or any(p.requires_grad for p in self.parameters()))
@@ -345,6 +364,13 @@ class UMNNMAFFlow(nn.Module):
     def set_steps_nb(self, nb_steps):
         for net in self.nets:
             net.set_steps_nb(nb_steps)
+
+    def set_embedding_dtype(self, dtype):
+        """Storage type of the [B, E*d] embedding h between the conditioner and the quadrature kernels (an extension of
+        this package, configuration C4): ``torch.bfloat16`` makes the conditioner's last GEMM write bf16 and the kernels
+        read it with bf16 loads (fp32 arithmetic inside); ``None`` restores the conditioner's own dtype."""
+        for net in self.nets:
+            net.net.embedding_dtype = dtype
 
     def compute_lipschitz(self, nb_iter=10):
         L = 1.

@@ -8,26 +8,57 @@ import torch
 
 
 class GraphedLL:
+    """``GraphedLL(model, x_example)(x)`` -> the captured ``(ll, z)`` tensors (overwritten by the next call).
+
+    The conditioner's cached masked / packed weights are baked into the graph as constants, so the capture remembers the
+    version counters of every parameter and buffer and RE-CAPTURES when one moved (an optimizer step, load_state_dict,
+    force_lipschitz between two replays).  Writes that bypass versioning (``p.data``...) need ``refresh()``."""
+
     def __init__(self, model, x_example, context=None, warmup=3):
         assert x_example.is_cuda, "hipGraph capture needs device tensors"
         self.model = model
         self.x = x_example.clone()
         self.context = context.clone() if context is not None else None
+        self.warmup = warmup
+        self.captures = 0
+        self._capture()
+
+    def _versions(self):
+        return tuple(t._version for t in self.model.parameters()) + tuple(t._version for t in self.model.buffers())
+
+    def _run(self):
+        return self.model.compute_ll(self.x, self.context) if self.context is not None else self.model.compute_ll(self.x)
+
+    def _capture(self):
+        from . import made
         with torch.no_grad():
-            side = torch.cuda.Stream(device=x_example.device)
-            side.wait_stream(torch.cuda.current_stream(x_example.device))
+            side = torch.cuda.Stream(device=self.x.device)
+            side.wait_stream(torch.cuda.current_stream(self.x.device))
             with torch.cuda.stream(side):               # warm every cache (LDS caps, tables, packed weights) first
-                for _ in range(warmup):
-                    model.compute_ll(self.x, self.context) if self.context is not None else model.compute_ll(self.x)
-            torch.cuda.current_stream(x_example.device).wait_stream(side)
+                for _ in range(self.warmup):
+                    self._run()
+            torch.cuda.current_stream(self.x.device).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = model.compute_ll(self.x, self.context) if self.context is not None \
-                    else model.compute_ll(self.x)
+            made._CAPTURE["cache_ok"] = True
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.out = self._run()
+            finally:
+                made._CAPTURE["cache_ok"] = False
+        self._seen = self._versions()
+        self.captures += 1
+
+    def refresh(self):
+        """Re-capture unconditionally (after weight writes that do not bump tensor versions)."""
+        from .made import invalidate_caches
+        invalidate_caches(self.model)
+        self._capture()
 
     def __call__(self, x=None, context=None):
         """Replay on new data (copied into the captured buffers); returns the captured output tensors (overwritten by
         the next call)."""
+        if self._versions() != self._seen:
+            self._capture()
         if x is not None:
             self.x.copy_(x)
         if context is not None:

@@ -170,23 +170,44 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+def _io_prep(x_like, h):
+    """Storage plan of one call (configuration C4: bf16 activations): tensors are handed to the kernels in the dtype the
+    caller stores them in when that is fp32 or bf16 (no conversion pass, bf16 loads/stores inside the kernels); fp16 and
+    anything else is converted to fp32 at the boundary.  -> (x dtype, h dtype, umnn_io or None)."""
+    xd = x_like.dtype if x_like.dtype in (torch.float32, torch.bfloat16) else torch.float32
+    hd = h.dtype if h.dtype in (torch.float32, torch.bfloat16) else torch.float32
+    if xd == torch.float32 and hd == torch.float32:
+        return xd, hd, None
+    io = _lib.IoDesc(_lib.DTYPE_BF16 if xd == torch.bfloat16 else _lib.DTYPE_F32,
+                     _lib.DTYPE_BF16 if hd == torch.bfloat16 else _lib.DTYPE_F32)
+    return xd, hd, io
+
+
+def _as(t, dtype):
+    return None if t is None else t.detach().to(dtype).contiguous()
+
+
 def hip_forward(spec, x0, x, h, nb_steps, inv_f=False):
-    """-> (F, f_x, f_x0), each [B,d].  x0 may be None (zeros)."""
+    """-> (F, f_x, f_x0), each [B,d] in x's dtype.  x0 may be None (zeros)."""
     lib = _lib.lib()
     B, d, E = _shape(spec, x, h)
     out_dtype = x.dtype
-    x, h = _f32c(x), _f32c(h)
-    x0 = _f32c(x0) if x0 is not None else None
+    xd, hd, io = _io_prep(x, h)
+    x, h, x0 = _as(x, xd), _as(h, hd), _as(x0, xd)
     w, s = device_tables(nb_steps, x.device)
     F, fx, fx0 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
     desc, keep = _desc(spec)
     with torch.cuda.device(x.device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        rc = lib.umnn_cc_forward(ctypes.byref(desc), _ptr(x0), _ptr(x), _ptr(h), _ptr(w), _ptr(s), int(nb_steps),
-                                 B, d, E, int(bool(inv_f)), _ptr(F), _ptr(fx), _ptr(fx0), stream)
+        if io is None:
+            rc = lib.umnn_cc_forward(ctypes.byref(desc), _ptr(x0), _ptr(x), _ptr(h), _ptr(w), _ptr(s), int(nb_steps),
+                                     B, d, E, int(bool(inv_f)), _ptr(F), _ptr(fx), _ptr(fx0), stream)
+        else:
+            rc = lib.umnn_cc_forward_io(ctypes.byref(desc), ctypes.byref(io), _ptr(x0), _ptr(x), _ptr(h), _ptr(w), _ptr(s),
+                                        int(nb_steps), B, d, E, int(bool(inv_f)), _ptr(F), _ptr(fx), _ptr(fx0), stream)
     _lib.check(rc, "umnn_cc_forward")
     _state.path = "hip"
-    if out_dtype != torch.float32:        # half-precision callers (autocast / bf16 VAE prior): fp32 inside, their dtype outside
+    if out_dtype != xd:                   # fp16 callers: fp32 inside, their dtype outside
         F, fx, fx0 = F.to(out_dtype), fx.to(out_dtype), fx0.to(out_dtype)
     return F, fx, fx0
 
@@ -197,21 +218,48 @@ def hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z=False, log_jac_in=No
     lib = _lib.lib()
     B, d, E = _shape(spec, x, h)
     out_dtype = x.dtype
-    x, h, scaling = _f32c(x), _f32c(h), _f32c(scaling)
+    xd, hd, io = _io_prep(x, h)
+    x, h, scaling = _as(x, xd), _as(h, hd), _f32c(scaling)
     w, s = device_tables(nb_steps, x.device)
     z, lj, fx, fx0 = (torch.empty_like(x) for _ in range(4))
     desc, keep = _desc(spec)
     with torch.cuda.device(x.device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        lj_in = _f32c(log_jac_in) if log_jac_in is not None else None
-        rc = lib.umnn_flow_stack_block_forward(ctypes.byref(desc), _ptr(x), _ptr(h), _ptr(scaling), _ptr(w), _ptr(s),
-                                               int(nb_steps), B, d, E, 1 if reverse_z else 0, _ptr(lj_in),
-                                               _ptr(z), _ptr(lj), _ptr(fx), _ptr(fx0), stream)
+        lj_in = _as(log_jac_in, xd)
+        if io is None:
+            rc = lib.umnn_flow_stack_block_forward(ctypes.byref(desc), _ptr(x), _ptr(h), _ptr(scaling), _ptr(w), _ptr(s),
+                                                   int(nb_steps), B, d, E, 1 if reverse_z else 0, _ptr(lj_in),
+                                                   _ptr(z), _ptr(lj), _ptr(fx), _ptr(fx0), stream)
+        else:
+            rc = lib.umnn_flow_stack_block_forward_io(ctypes.byref(desc), ctypes.byref(io), _ptr(x), _ptr(h), _ptr(scaling),
+                                                      _ptr(w), _ptr(s), int(nb_steps), B, d, E, 1 if reverse_z else 0,
+                                                      _ptr(lj_in), _ptr(z), _ptr(lj), _ptr(fx), _ptr(fx0), stream)
     _lib.check(rc, "umnn_flow_stack_block_forward")
     _state.path = "hip"
-    if out_dtype != torch.float32:
+    if out_dtype != xd:
         z, lj, fx, fx0 = z.to(out_dtype), lj.to(out_dtype), fx.to(out_dtype), fx0.to(out_dtype)
     return z, lj, fx, fx0
+
+
+def hip_invert_dim(spec, h, z, scaling, nb_steps, j, iters, x_inv):
+    """Bracket search of flow dimension j for every sample in ONE launch (umnn_flow_invert_dim): writes x_inv[:, j].
+    Returns False when the library has no kernel for this net (single hidden layer / LDS): the caller keeps its own loop."""
+    lib = _lib.lib()
+    B, d = z.shape
+    E = h.shape[1] // d
+    if E * d != h.shape[1] or spec.linears[0].in_features != 1 + E:
+        raise RuntimeError("umnn_amd: embedding width does not match the integrand")
+    w, s = device_tables(nb_steps, z.device)
+    desc, keep = _desc(spec)
+    with torch.cuda.device(z.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
+        rc = lib.umnn_flow_invert_dim(ctypes.byref(desc), _ptr(h), _ptr(z), _ptr(scaling), _ptr(w), _ptr(s), int(nb_steps),
+                                      B, d, E, int(j), int(iters), _ptr(x_inv), stream)
+    if rc == _lib.EUNSUPPORTED:
+        return False
+    _lib.check(rc, "umnn_flow_invert_dim")
+    _state.path = "hip"
+    return True
 
 
 _row_counters = {}     # (device index, stream handle) -> zeroed uint32 [>= B] arrival counters (kernel leaves them zero)
@@ -246,13 +294,13 @@ def hip_flow_ll_block(spec, x, h, scaling, nb_steps, reverse_z, first, last, ll,
 
 
 def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True)):
-    """-> (dx0, dx, dh, dtheta_flat); entries are None where need[...] is False."""
+    """-> (dx0, dx, dh, dtheta_flat); entries are None where need[...] is False.  dx0/dx come back in x's dtype, dh in
+    h's, dtheta in fp32 (the weights' dtype)."""
     lib = _lib.lib()
     B, d, E = _shape(spec, x, h)
     x_dtype, h_dtype = x.dtype, h.dtype
-    x, h, g = _f32c(x), _f32c(h), _f32c(g)
-    x0 = _f32c(x0) if x0 is not None else None
-    g_fx = _f32c(g_fx) if g_fx is not None else None
+    xd, hd, io = _io_prep(x, h)
+    x, h, g, x0, g_fx = _as(x, xd), _as(h, hd), _as(g, xd), _as(x0, xd), _as(g_fx, xd)
     w, s = device_tables(nb_steps, x.device)
     dx0 = torch.empty_like(x) if need[0] else None
     dx = torch.empty_like(x) if need[1] else None
@@ -264,15 +312,20 @@ def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True
         nbytes = lib.umnn_cc_backward_workspace_bytes(ctypes.byref(desc), B, d, E)
         ws = torch.empty(max(int(nbytes), 4), device=x.device, dtype=torch.uint8)
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        rc = lib.umnn_cc_backward(ctypes.byref(desc), _ptr(x0), _ptr(x), _ptr(h), _ptr(g), _ptr(g_fx),
-                                  _ptr(w), _ptr(s), int(nb_steps), B, d, E,
-                                  _ptr(dx0), _ptr(dx), _ptr(dh), _ptr(dtheta), _ptr(ws), int(nbytes), stream)
+        if io is None:
+            rc = lib.umnn_cc_backward(ctypes.byref(desc), _ptr(x0), _ptr(x), _ptr(h), _ptr(g), _ptr(g_fx),
+                                      _ptr(w), _ptr(s), int(nb_steps), B, d, E,
+                                      _ptr(dx0), _ptr(dx), _ptr(dh), _ptr(dtheta), _ptr(ws), int(nbytes), stream)
+        else:
+            rc = lib.umnn_cc_backward_io(ctypes.byref(desc), ctypes.byref(io), _ptr(x0), _ptr(x), _ptr(h), _ptr(g), _ptr(g_fx),
+                                         _ptr(w), _ptr(s), int(nb_steps), B, d, E,
+                                         _ptr(dx0), _ptr(dx), _ptr(dh), _ptr(dtheta), _ptr(ws), int(nbytes), stream)
     _lib.check(rc, "umnn_cc_backward")
     _state.path = "hip"
-    if x_dtype != torch.float32:
+    if x_dtype != xd:
         dx0 = dx0.to(x_dtype) if dx0 is not None else None
         dx = dx.to(x_dtype) if dx is not None else None
-    if h_dtype != torch.float32 and dh is not None:
+    if h_dtype != hd and dh is not None:
         dh = dh.to(h_dtype)
     return dx0, dx, dh, dtheta
 

@@ -23,6 +23,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+_CAPTURE = {"cache_ok": False}
+
+
 class MaskedLinear(nn.Linear):
     """nn.Linear whose weight is multiplied elementwise by a fixed 0/1 ``mask`` buffer."""
 
@@ -47,7 +50,8 @@ class MaskedLinear(nn.Linear):
 
     @staticmethod
     def _capturing(t):
-        return t.is_cuda and torch.cuda.is_current_stream_capturing()
+        # a capture that tracks the weights' versions itself (graphs.GraphedLL re-captures when they move) may bake the caches in
+        return t.is_cuda and not _CAPTURE["cache_ok"] and torch.cuda.is_current_stream_capturing()
 
     def masked_weight(self):
         if torch.is_grad_enabled() and self.weight.requires_grad:
@@ -124,20 +128,33 @@ def _fast_path_ok(x):
     return _FAST["ok"]
 
 
-def _fast_chain(a, layers, last_rows=None):
-    """a [B, K0] fp32 -> output of the MaskedLinear/ReLU chain, every GEMM as one K-concatenated bf16 GEMM."""
+def _fast_chain(a, layers, last_rows=None, out_dtype=None):
+    """a [B, K0] fp32 -> output of the MaskedLinear/ReLU chain, every GEMM as one K-concatenated bf16 GEMM (fp32
+    accumulation).  ``out_dtype=torch.bfloat16``: the LAST GEMM writes the embedding straight in bf16 (configuration C4:
+    the [B, E*d] tensor the quadrature kernels then read with bf16 loads -- half the bytes of that round trip)."""
     from . import _lib
     lib = _lib.lib()
     raw = a.contiguous()
     stream = ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
     with torch.cuda.device(a.device):
         for i, layer in enumerate(layers):
-            packed = layer.packed_bf16(last_rows if i == len(layers) - 1 else None)
+            last = i == len(layers) - 1
+            packed = layer.packed_bf16(last_rows if last else None)
             op = torch.empty(raw.shape[0], packed.shape[1], dtype=torch.bfloat16, device=a.device)
             _lib.check(lib.umnn_made_split3(raw.data_ptr(), raw.shape[0], raw.shape[1], 1 if i > 0 else 0,
                                             op.data_ptr(), op.shape[1], stream), "made_split3")
-            raw = torch.mm(op, packed.t(), out_dtype=torch.float32)
+            if last and out_dtype == torch.bfloat16:
+                raw = torch.mm(op, packed.t())                       # bf16 out, fp32 accumulate inside the GEMM
+            else:
+                raw = torch.mm(op, packed.t(), out_dtype=torch.float32)
     return raw
+
+
+def _to_weight_dtype(x, layer):
+    """bf16 / fp16 activations handed to fp32 weights outside autocast: widen (exact) instead of failing in F.linear."""
+    if x.dtype != layer.weight.dtype and not torch.is_autocast_enabled():
+        return x.to(layer.weight.dtype)
+    return x
 
 
 class MADE(nn.Module):
@@ -187,11 +204,13 @@ class MADE(nn.Module):
             layer.set_mask(mask)
         self.i_map = np.argsort(self.m[-1])
 
-    def raw(self, x):
+    def raw(self, x, out_dtype=None):
         """The masked MLP itself (what the flow's EmbeddingNetwork needs, whatever nout is)."""
+        x = _to_weight_dtype(x, self.net[0])
         if _fast_path_ok(x):
-            return _fast_chain(x, [l for l in self.net if isinstance(l, MaskedLinear)])
-        return self.net(x)
+            return _fast_chain(x, [l for l in self.net if isinstance(l, MaskedLinear)], out_dtype=out_dtype)
+        out = self.net(x)
+        return out.to(out_dtype) if out_dtype is not None and out.dtype != out_dtype else out
 
     def forward(self, x, context=None):
         if self.nout == 2:       # reference quirk (made.py:114-118): nout == 2 means "Gaussian MADE"
@@ -235,16 +254,19 @@ class ConditionnalMADE(MADE):
             self._keep = idx.reshape(-1).to(device)
         return self._keep
 
-    def raw(self, x, context):
-        a = torch.cat((context, x), 1)
+    def raw(self, x, context, out_dtype=None):
+        if context.dtype != x.dtype:
+            context = context.to(x.dtype)
+        a = _to_weight_dtype(torch.cat((context, x), 1), self.net[0])
         if _fast_path_ok(a):
-            return _fast_chain(a, [l for l in self.net if isinstance(l, MaskedLinear)], self._kept_rows(a.device))
+            return _fast_chain(a, [l for l in self.net if isinstance(l, MaskedLinear)], self._kept_rows(a.device), out_dtype)
         layers = list(self.net)
         for layer in layers[:-1]:
             a = layer(a)
         last = layers[-1]
         keep = self._kept_rows(a.device)
-        return F.linear(a, last.masked_weight().index_select(0, keep), last.bias.index_select(0, keep))
+        out = F.linear(a, last.masked_weight().index_select(0, keep), last.bias.index_select(0, keep))
+        return out.to(out_dtype) if out_dtype is not None and out.dtype != out_dtype else out
 
     def forward(self, x, context):
         if self.nout == 2:
