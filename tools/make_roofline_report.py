@@ -1,60 +1,114 @@
 #!/usr/bin/env python
-"""profiles/r01/roofline_report.{md,json} + profiles/hbm_traffic.json from the CSVs tools/profile_bench.sh collected
-(copied to profiles/r01/bench_<workload>_{kernel_stats,pmc_summary}.csv)."""
+"""profiles/<round>/roofline_report.{md,json} from what tools/profile_bench.sh collected under gpurun_out/prof_<tag>/.
+
+    python tools/make_roofline_report.py r02          # copies the summaries it used into profiles/r02/ next to the report
+
+Per tag (bsds300, power, bsds300_train ...): kernel_stats.csv (rocprofv3 --kernel-trace --stats), pmc_summary.csv (two SQ
+passes, mean per dispatch), bench_stats.json (the bench line of the stats pass) and, for eval tags, hbm_traffic.json
+(FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per MI355X_MICROARCH.md, GRBM_GUI_ACTIVE summed over the 8 XCDs).
+Algorithmic FLOPs: SURVEY 8(d) per forward integral x integrals per launch; backward = 3 x that (include/umnn_cc.h)."""
 import csv
 import json
 import os
+import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = os.path.join(ROOT, "profiles", "r01")
-FL = {"bsds300": 793858867200.0, "power": 92292000000.0}
-ALG = {"bsds300": 8192 * 63 * (4 * (1 + 30 + 2) + 8), "power": 10000 * 6 * (4 * (1 + 30 + 2) + 8)}
-TITLES = (("bsds300", "C3 BSDS300-shaped: 8192 x 63 integrals, n=100, 31-50^4-1"),
-          ("power", "C2 POWER-shaped: 10000 x 6 integrals, n=100, 31-50^4-1"))
-out = {}
-lines = ["# Roofline report (rocprofv3, round 1) — `cc_fwd_bf16_kernel<4,2,2,EXACT,LIVE=13,PIPE>`", "",
-         "Collected with `tools/profile_bench.sh <workload>` on one MI355X (kernel-trace stats, then PMC passes: SQ counters in two",
-         "passes, FETCH_SIZE and WRITE_SIZE each in a pass of its own), rendered by `tools/make_roofline_report.py`.  Raw summaries:",
-         "`bench_<workload>_kernel_stats.csv`, `bench_<workload>_pmc_summary.csv` next to this file.  FETCH_SIZE is doubled (gfx950",
-         "tallies 128-B requests at 64 B, MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs.", ""]
-for w, title in TITLES:
-    st = [r for r in csv.DictReader(open(os.path.join(R, f"bench_{w}_kernel_stats.csv"))) if "cc_fwd_bf16" in r["Name"]][0]
-    pm = {r["counter"]: float(r["mean_per_dispatch"]) for r in csv.DictReader(open(os.path.join(R, f"bench_{w}_pmc_summary.csv")))
-          if "cc_fwd_bf16" in r["kernel"]}
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+OUT = os.path.join(ROOT, "profiles", RND)
+os.makedirs(OUT, exist_ok=True)
+PEAK_BF16 = 2500.0
+
+
+def flops_per_integral(cfg):
+    hd, E, n = cfg["hd"], cfg["E"], cfg["n"]
+    node = hd[0] + hd[-1] + sum(hd[i] * hd[i + 1] for i in range(len(hd) - 1))
+    return 2.0 * ((n + 1) * node + E * hd[0])
+
+
+def load(tag):
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    if not os.path.isdir(src):
+        return None
+    for f in ("kernel_stats.csv", "pmc_summary.csv", "bench_stats.json", "hbm_traffic.json"):
+        if os.path.exists(os.path.join(src, f)):
+            shutil.copy(os.path.join(src, f), os.path.join(OUT, f"bench_{tag}_{f}"))
+    stats = list(csv.DictReader(open(os.path.join(OUT, f"bench_{tag}_kernel_stats.csv"))))
+    pmc = {}
+    for r in csv.DictReader(open(os.path.join(OUT, f"bench_{tag}_pmc_summary.csv"))):
+        pmc.setdefault(r["kernel"], {})[r["counter"]] = float(r["mean_per_dispatch"])
+    line = json.loads(open(os.path.join(OUT, f"bench_{tag}_bench_stats.json")).read().strip().splitlines()[-1])
+    return stats, pmc, line
+
+
+def kernel_entry(stats, pmc, name_part, flops, algo_bytes=None, hbm=None):
+    st = [r for r in stats if name_part in r["Name"]][0]
+    pm = next(v for k, v in pmc.items() if name_part in k)
     avg_ms = float(st["AverageNs"]) / 1e6
     cyc = pm["GRBM_GUI_ACTIVE"] / 8
-    hbm = pm["FETCH_SIZE"] * 1024 * 2 + pm["WRITE_SIZE"] * 1024
-    mfma_busy = pm["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc
-    valu = pm["SQ_INSTS_VALU"] - pm["SQ_INSTS_MFMA"]
-    out[w] = dict(kernel=st["Name"], avg_launch_ms=avg_ms, calls=int(st["Calls"]), algorithmic_tflops=FL[w] / avg_ms / 1e9,
-                  hbm_bytes_per_launch=hbm, algorithmic_bytes_per_launch=ALG[w], hbm_gbps=hbm / avg_ms / 1e6,
-                  mfma_pipe_busy=mfma_busy, clock_ghz=cyc / avg_ms / 1e6, mfma_per_launch=pm["SQ_INSTS_MFMA"],
-                  valu_per_launch=valu, lds_per_launch=pm["SQ_INSTS_LDS"], fetch_size_kb_raw=pm["FETCH_SIZE"],
-                  write_size_kb_raw=pm["WRITE_SIZE"])
-    tf = FL[w] / avg_ms / 1e9
-    ex = pm["SQ_INSTS_MFMA"] * 16384 / avg_ms / 1e9
-    lines += [f"## {title}", "", "| quantity | value |", "|---|---|",
-              f"| average launch (kernel-trace, {st['Calls']} launches) | {avg_ms:.3f} ms |",
-              f"| algorithmic FLOPs per launch (SURVEY 8d) | {FL[w]/1e9:.1f} GFLOP -> **{tf:.0f} TFLOP/s** |",
-              f"| vs dense bf16 MFMA peak (2500 TFLOP/s) / fp32 MFMA peak (157.3) | {tf/2500:.3f} / {tf/157.3:.2f} |",
-              f"| executed MFMA instructions (16x16x32 bf16) | {pm['SQ_INSTS_MFMA']/1e6:.1f} M = {pm['SQ_INSTS_MFMA']*16384/1e12:.2f} TFLOP on the pipe ({ex:.0f} TFLOP/s, {ex/2500:.2f} of peak) |",
-              f"| matrix pipe busy (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles) | {100*mfma_busy:.1f} % |",
-              f"| other VALU instructions / MFMA | {valu/1e6:.0f} M / {pm['SQ_INSTS_MFMA']/1e6:.0f} M = {valu/pm['SQ_INSTS_MFMA']:.2f} |",
-              f"| wave time: issuing / issue-stalled / parked (SQ_ACTIVE_INST_ANY, SQ_WAIT_INST_ANY, SQ_WAIT_ANY over SQ_WAVE_CYCLES) | {100*pm['SQ_ACTIVE_INST_ANY']/pm['SQ_WAVE_CYCLES']:.0f} % / {100*pm['SQ_WAIT_INST_ANY']/pm['SQ_WAVE_CYCLES']:.0f} % / {100*pm['SQ_WAIT_ANY']/pm['SQ_WAVE_CYCLES']:.0f} % |",
-              f"| HBM traffic per launch (2 x FETCH_SIZE + WRITE_SIZE) | {hbm/1e6:.1f} MB vs {ALG[w]/1e6:.1f} MB algorithmic -> {hbm/avg_ms/1e6:.0f} GB/s = {hbm/avg_ms/1e6/8000*100:.2f} % of 8 TB/s |",
-              f"| shader clock during the kernel (GRBM_GUI_ACTIVE / 8 / duration) | {cyc/avg_ms/1e6:.2f} GHz |", ""]
-lines += ["Reading: the path is three orders of magnitude above the HBM ridge, traffic equals the algorithmic bytes (no re-reads), and",
-          "the matrix pipe is the busiest unit but waits on instruction issue: every MFMA comes with ~3 other vector instructions",
-          "(activation, bf16 pieces, packing) of which about two fit in its issue shadow (DESIGN.md 4.0).  The executed-MFMA rate is 3",
-          "bf16 products per algorithmic fp32 product on 64x64-padded 51x51 layers (plus the split-remainder MFMAs), hence the gap",
-          "between the algorithmic and the pipe rates.", ""]
-open(os.path.join(R, "roofline_report.md"), "w").write("\n".join(lines))
-json.dump(out, open(os.path.join(R, "roofline_report.json"), "w"), indent=1)
-method = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --workload {w} --steps 2 --warmup 1`; mean "
-          "per dispatch; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); see "
-          "profiles/r01/bench_{w}_pmc_summary.csv")
-json.dump({w: dict(hbm_bytes_per_launch=o["hbm_bytes_per_launch"], fetch_size_kb_raw=o["fetch_size_kb_raw"],
-                   write_size_kb_raw=o["write_size_kb_raw"], kernel=o["kernel"], method=method.format(w=w),
-                   algorithmic_bytes_per_launch=o["algorithmic_bytes_per_launch"]) for w, o in out.items()},
-          open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+    mfma = pm["SQ_INSTS_MFMA"]
+    valu = pm["SQ_INSTS_VALU"] - mfma
+    e = dict(kernel=st["Name"], calls=int(st["Calls"]), avg_launch_ms=avg_ms, share_of_gpu_time_pct=float(st["Percentage"]),
+             algorithmic_flops_per_launch=flops, algorithmic_tflops=flops / avg_ms / 1e9,
+             frac_of_bf16_peak=flops / avg_ms / 1e9 / PEAK_BF16,
+             mfma_per_launch=mfma, executed_tflops=mfma * 16384 / avg_ms / 1e9, executed_frac_of_bf16_peak=mfma * 16384 / avg_ms / 1e9 / PEAK_BF16,
+             mfma_pipe_busy=pm["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc, other_valu_per_mfma=valu / mfma, lds_per_mfma=pm["SQ_INSTS_LDS"] / mfma,
+             wave_issuing=pm["SQ_ACTIVE_INST_ANY"] / pm["SQ_WAVE_CYCLES"], wave_issue_stalled=pm["SQ_WAIT_INST_ANY"] / pm["SQ_WAVE_CYCLES"],
+             wave_parked=pm["SQ_WAIT_ANY"] / pm["SQ_WAVE_CYCLES"], clock_ghz=cyc / avg_ms / 1e6)
+    if hbm is not None:
+        e.update(hbm_bytes_per_launch=hbm, algorithmic_bytes_per_launch=algo_bytes, hbm_gbps=hbm / avg_ms / 1e6)
+    return e
+
+
+def table(title, e):
+    rows = [f"### {title}", "", "| quantity | value |", "|---|---|",
+            f"| kernel | `{e['kernel'][:90]}` |",
+            f"| average launch (kernel-trace, {e['calls']} launches) | **{e['avg_launch_ms']:.3f} ms** ({e['share_of_gpu_time_pct']:.1f} % of the GPU time of the run) |",
+            f"| algorithmic FLOPs per launch | {e['algorithmic_flops_per_launch']/1e9:.1f} GFLOP -> **{e['algorithmic_tflops']:.0f} TFLOP/s** = {e['frac_of_bf16_peak']:.3f} of the dense bf16 MFMA peak (2500) |",
+            f"| executed MFMA (16x16x32-class, 16384 FLOP each) | {e['mfma_per_launch']/1e6:.1f} M -> {e['executed_tflops']:.0f} TFLOP/s on the pipe = {e['executed_frac_of_bf16_peak']:.2f} of peak |",
+            f"| matrix pipe busy (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles) | **{100*e['mfma_pipe_busy']:.1f} %** |",
+            f"| other VALU / MFMA, LDS instructions / MFMA | {e['other_valu_per_mfma']:.2f}, {e['lds_per_mfma']:.2f} |",
+            f"| wave time issuing / issue-stalled / parked | {100*e['wave_issuing']:.0f} % / {100*e['wave_issue_stalled']:.0f} % / {100*e['wave_parked']:.0f} % |",
+            f"| shader clock during the kernel | {e['clock_ghz']:.2f} GHz |"]
+    if "hbm_bytes_per_launch" in e:
+        rows.append(f"| HBM traffic per launch (2 x FETCH_SIZE + WRITE_SIZE) | {e['hbm_bytes_per_launch']/1e6:.1f} MB vs {e['algorithmic_bytes_per_launch']/1e6:.1f} MB "
+                    f"algorithmic -> {e['hbm_gbps']:.0f} GB/s = {e['hbm_gbps']/80:.2f} % of 8 TB/s |")
+    return rows + [""]
+
+
+report, lines = {}, [f"# Roofline report (rocprofv3, round {RND[1:]}) -- kernels at HEAD", "",
+                     "Collected with `tools/profile_bench.sh <workload> [--mode train]` on one MI355X, rendered by `tools/make_roofline_report.py`;",
+                     "the CSV / JSON summaries it read are the `bench_<tag>_*` files next to this report.", ""]
+for tag, title in (("bsds300", "C3 BSDS300-shaped eval (8192 x 63 integrals per launch, n=100, 31-50^4-1)"),
+                   ("power", "C2 POWER-shaped eval (10000 x 6 integrals per launch)"),
+                   ("bsds300_train", "C3 training step (forward + HIP backward + Adam)")):
+    got = load(tag)
+    if got is None:
+        continue
+    stats, pmc, line = got
+    cfg = bench.WORKLOADS[tag.replace("_train", "")]
+    fl = flops_per_integral(cfg) * cfg["rows"] * cfg["d"]
+    lines += [f"## {title}", "", f"bench line of the stats pass: {line['value']:.4g} {line['unit']}, {line['ms_per_step']:.3f} ms/step.", ""]
+    report[tag] = {"bench": {k: line[k] for k in ("value", "unit", "ms_per_step")}}
+    hbm = algo = None
+    tr = os.path.join(OUT, f"bench_{tag}_hbm_traffic.json")
+    if os.path.exists(tr):
+        rec = json.load(open(tr)).get(tag, {})
+        hbm, algo = rec.get("hbm_bytes_per_launch"), rec.get("algorithmic_bytes_per_launch")
+    e = kernel_entry(stats, pmc, "cc_fwd_bf16_kernel", fl, algo, hbm)
+    report[tag]["forward"] = e
+    lines += table("forward quadrature kernel", e)
+    if tag.endswith("_train"):
+        e = kernel_entry(stats, pmc, "cc_bwd_bf16_kernel", 3 * fl)
+        report[tag]["backward"] = e
+        lines += table("backward quadrature kernel (algorithmic FLOPs = 3 x forward: two gradient GEMMs per forward GEMM + the recompute)", e)
+        lines += ["Top kernels of the training step (kernel-trace):", "", "| kernel | calls | avg | % |", "|---|---|---|---|"]
+        for r in stats[:8]:
+            lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} ms | {float(r['Percentage']):.1f} |")
+        lines.append("")
+open(os.path.join(OUT, "roofline_report.md"), "w").write("\n".join(lines))
+json.dump(report, open(os.path.join(OUT, "roofline_report.json"), "w"), indent=1)
 print("\n".join(lines))
