@@ -603,3 +603,47 @@ def test_mnist_width_d784_against_oracle(dev):
     assert U.scaled_err(hr.grad.cpu().numpy(), ref[2]) < TOL
     dth = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
     assert U.scaled_err(dth, ref[5]) < TOL
+
+
+def test_c_abi_from_four_threads_at_once(dev):
+    """The library is called from whatever thread PyTorch runs the op on (backward: autograd worker threads).  Four host
+    threads launch forward + backward through the C ABI concurrently, each on its own stream (ctypes drops the GIL inside
+    the call): every thread must get the bits the serial run produced -- no shared mutable state on the launch path
+    (options are atomics read per launch, the LDS-cap / CU-count caches are locked or atomic, errors thread-local)."""
+    import threading
+    from umnn_amd import integral as I, IntegrandNetwork
+    from umnn_amd.nets import mlp_spec
+    torch.manual_seed(11)
+    nets = [IntegrandNetwork(d, 1 + E, hid, 1).to(dev) for d, E, hid in
+            [(6, 30, [50] * 4), (2, 10, [100] * 4), (5, 4, [40, 33]), (3, 8, [64, 64, 64])]]
+    data = []
+    for net in nets:
+        d, E = net.nnets, net.nin - 1
+        data.append((torch.randn(200, d, device=dev), torch.randn(200, E * d, device=dev), torch.randn(200, d, device=dev)))
+    serial = []
+    for net, (x, h, g) in zip(nets, data):
+        spec = mlp_spec(net)
+        serial.append((I.hip_forward(spec, None, x, h, 30), I.hip_backward(spec, None, x, h, g, None, 30)))
+    torch.cuda.synchronize()
+    results, errors = [None] * 4, []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                spec = mlp_spec(nets[i])
+                x, h, g = data[i]
+                out = None
+                for _ in range(25):
+                    out = (I.hip_forward(spec, None, x, h, 30), I.hip_backward(spec, None, x, h, g, None, 30))
+                st.synchronize()
+            results[i] = out
+        except Exception as e:           # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for got, ref in zip(results, serial):
+        for a, b in zip(got[0] + tuple(got[1]), ref[0] + tuple(ref[1])):
+            assert torch.equal(a, b)
