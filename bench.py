@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: UMNN-MAF log-density evals/s (BASELINE.json metric) on MI355X.
 
-  python bench.py [--gpus N --steps K --warmup W --workload bsds300|power|toy|vae --mode eval|train]
+  python bench.py [--gpus N --steps K --warmup W --workload bsds300|power|toy|vae|mnist --mode eval|train]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -32,6 +32,9 @@ WORKLOADS = {
                   desc="C2 POWER-shaped UMNN-MAF compute_ll: d=6, batch 10000, n_steps=100"),
     "toy": dict(nb_flow=1, d=2, he=[100] * 4, hd=[100] * 4, E=10, n=50, rows=4096, cond=0,
                 desc="C1 2-moons UMNN-MAF compute_ll: d=2, batch 4096, n_steps=50"),
+    "mnist": dict(nb_flow=5, d=784, he=[1024] * 3, hd=[100, 50, 50, 50, 50], E=30, n=50, rows=100, cond=0,
+                  desc="MNISTExperiment-shaped UMNN-MAF (the d=784 shape BASELINE config 5 quotes): 5 blocks, MADE [1024]*3, "
+                       "integrand 31-100-50-50-50-50-1, n_steps=50, the script's batch of 100 rows/GPU"),
     "vae": dict(nb_flow=4, d=64, he=[512, 512], hd=[50] * 4, E=30, n=50, rows=1024, cond=320,
                 desc="C4 TrainVaeFlow prior flow: d=64 latent, cond_in=320, 4 blocks, n_steps=50, 1024 rows/GPU"),
 }

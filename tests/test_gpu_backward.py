@@ -205,11 +205,14 @@ def test_graphed_train_step_matches_eager_training(dev):
         assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6), n
 
 
-@pytest.mark.parametrize("hid", [[100, 50, 50], [72, 72], [120, 40, 40, 40]])   # (no shape-exact backward family)
-def test_mixed_wide_nets_take_the_aten_backward_and_match_the_oracle(hid, dev, monkeypatch):
-    """Nets whose HIP backward only has the generic more-than-four-tile variants (they spill) are differentiated with
-    the materialised ATen chain on the GPU by default; UMNN_BWD_WIDE=hip still reaches the HIP kernels.  Both must match
-    the oracle's restatement of the reference backward."""
+@pytest.mark.parametrize("hid", [[100, 50, 50], [72, 72], [120, 40, 40, 40], [100, 50, 50, 50, 50]])
+def test_mixed_wide_nets_backward_routes_match_the_oracle(hid, dev, monkeypatch, bwd_precision):
+    """Nets with hidden layers wider than four tiles and no one-pass shape-exact backward.  With the default (bf16x3)
+    arithmetic, nets whose FIRST hidden layer is wide and the rest narrow (MNISTExperiment's 100-50-50-50-50) run the
+    three-stage HIP backward of cc_backward_front.hip; everything else (and the fp32 mode) is differentiated with the
+    materialised ATen chain on the GPU unless UMNN_BWD_WIDE=hip forces the generic HIP kernels.  Every route must match the
+    oracle's restatement of the reference backward."""
+    import ctypes
     from umnn_amd import integral as I, IntegrandNetwork, _lib
     from umnn_amd.nets import mlp_spec
     torch.manual_seed(len(hid))
@@ -224,6 +227,9 @@ def test_mixed_wide_nets_take_the_aten_backward_and_match_the_oracle(hid, dev, m
     g = torch.randn(B, d, device=dev)
     ref = O.integrate_backward(onet, x0.cpu().numpy(), x.cpu().numpy(), h.cpu().numpy(), n, g.cpu().numpy())
     ref_dh, ref_dtheta = ref[2], ref[5]
+    staged = bwd_precision == "bf16x3" and hid[0] > 63 and max(hid[1:]) <= 63
+    desc, keep = I._desc(spec)
+    assert (_lib.lib().umnn_cc_backward_kind(ctypes.byref(desc), E) >= 0) == staged
     for mode in ("", "hip"):
         monkeypatch.setenv("UMNN_BWD_WIDE", mode)
         xr, hr = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
@@ -234,23 +240,68 @@ def test_mixed_wide_nets_take_the_aten_backward_and_match_the_oracle(hid, dev, m
         F.backward(g)
         torch.cuda.synchronize()
         # (autograd runs backward on its own thread: count library launches instead of asking path_taken())
-        assert (_lib.lib().umnn_launch_count() > launches) == (mode == "hip")
+        assert (_lib.lib().umnn_launch_count() > launches) == (mode == "hip" or staged)
+        if staged:
+            assert "FRONT" in _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
         dtheta = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
         assert np.abs(dtheta - ref_dtheta).max() <= 1e-4 * np.abs(ref_dtheta).max()
         assert np.abs(hr.grad.cpu().numpy() - ref_dh).max() <= 1e-4 * np.abs(ref_dh).max()
         assert U.rel_err(xr.grad.cpu().numpy(), O.integrand(onet, x.cpu().numpy(), h.cpu().numpy()) * g.cpu().numpy()) < 1e-4
-    # the (F, f_x) operator of the flow blocks: both routes agree with each other
+    # the (F, f_x) operator of the flow blocks (cotangents for both outputs: exercises the tangent pass through the wide
+    # first layer): the HIP route against the materialised ATen chain
     outs = []
-    for mode in ("", "hip"):
-        monkeypatch.setenv("UMNN_BWD_WIDE", mode)
+    for route in ("hip", "aten"):
+        monkeypatch.setenv("UMNN_BWD_WIDE", "hip" if route == "hip" else "")
         xr, hr = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
         for p in net.parameters():
             p.grad = None
+        if route == "aten":
+            monkeypatch.setattr(I, "_hip_backward_ok", lambda *a, **k: False)
         F, fx = I.IntegralWithJacobian.apply(x0, xr, net, I._flatten(net.parameters()), hr, n)
         (F * g).sum().add((torch.log(fx) * g.flip(0)).sum()).backward()
         outs.append((xr.grad.clone(), hr.grad.clone(), torch.cat([p.grad.reshape(-1) for p in net.parameters()])))
     for a, b in zip(*outs):
         assert (a - b).abs().max() <= 1e-4 * b.abs().max()
+
+
+def test_staged_backward_chunks_and_large_batch(dev, bwd_precision):
+    """The three-stage backward at the MNIST shape (d=784, 31-100-50-50-50-50-1, n=50): rows sampled against the oracle
+    (d_h, d_x depend on their own row), d_theta against the sum of two half batches (linearity), chunked scratch (the
+    batch of 256 rows needs several 1-GiB chunks) and bit-repeatability."""
+    from umnn_amd import integral as I, IntegrandNetwork, _lib
+    from umnn_amd.nets import mlp_spec
+    if bwd_precision != "bf16x3":
+        pytest.skip("the staged kernels are the bf16x3 route")
+    torch.manual_seed(0)
+    B, d, E, n = 256, 784, 30, 50
+    net = IntegrandNetwork(d, 1 + E, [100, 50, 50, 50, 50], 1).to(dev)
+    with torch.no_grad():
+        for mod in net.net:
+            if isinstance(mod, torch.nn.Linear):
+                mod.weight.mul_(1.5)
+    spec = mlp_spec(net)
+    lin = spec.linears
+    onet = O.Net([m.weight.detach().cpu().numpy() for m in lin], [m.bias.detach().cpu().numpy() for m in lin], O.LEAKY, O.ELU1)
+    x = torch.randn(B, d, device=dev)
+    h = torch.randn(B, E * d, device=dev)
+    g, gf = torch.randn(B, d, device=dev), torch.randn(B, d, device=dev) * 0.1
+    before = _lib.lib().umnn_launch_count()
+    dx0, dx, dh, dth = I.hip_backward(spec, None, x, h, g, gf, n)
+    torch.cuda.synchronize()
+    assert "FRONT" in _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+    assert _lib.lib().umnn_launch_count() > before
+    rows = np.array([0, 101, 255])
+    xs, hs, gs = x[rows].cpu().numpy(), h[rows].cpu().numpy(), g[rows].cpu().numpy()
+    r = O.integrate_backward(onet, np.zeros_like(xs), xs, hs, n, gs)
+    dh_nogfx = I.hip_backward(spec, None, x, h, g, None, n)
+    assert U.scaled_err(dh_nogfx[2][rows].cpu().numpy(), r[2]) < TOL
+    assert U.rel_err(dh_nogfx[1][rows].cpu().numpy(), r[1]) < TOL
+    a = I.hip_backward(spec, None, x[:128].contiguous(), h[:128].contiguous(), g[:128].contiguous(), gf[:128].contiguous(), n)
+    b = I.hip_backward(spec, None, x[128:].contiguous(), h[128:].contiguous(), g[128:].contiguous(), gf[128:].contiguous(), n)
+    assert float((a[3] + b[3] - dth).abs().max()) <= 3e-5 * float(dth.abs().max())
+    assert torch.equal(torch.cat([a[2], b[2]]), dh) and torch.equal(torch.cat([a[1], b[1]]), dx)
+    again = I.hip_backward(spec, None, x, h, g, gf, n)
+    assert all(torch.equal(p, q) for p, q in zip(again[1:], (dx, dh, dth)))
 
 
 def test_full_size_backward_properties_bsds300_shard(dev):

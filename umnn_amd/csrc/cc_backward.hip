@@ -534,6 +534,7 @@ struct BwdPlan {
     int ns;            // node-range split of the fp32 kernels (small batches: fewer tiles than waves)
     size_t lds_bytes_for(int nacc, int waves) const { return (size_t)(a.scratch_off + waves * (nacc + 1) * tmax * 256) * sizeof(float); }
     long long ws_partials, ws_dc, ws_p0;   // byte offsets in the workspace
+    long long ws_front, ws_front_bytes;    // HBM scratch of the staged backward (wide first hidden layer), 0 if not that family
     long long ws_total;
     int nparts0, chunk0;
 };
@@ -591,6 +592,9 @@ static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan
     pl->ws_partials = o; o += (long long)pl->nwaves * a.n_params * 4; o = (o + 255) & ~255LL;
     pl->ws_dc = o; o += a.NI * H1 * 4 * pl->ns; o = (o + 255) & ~255LL;
     pl->ws_p0 = o; o += (long long)pl->nparts0 * H1 * (E + 1) * 4; o = (o + 255) & ~255LL;
+    pl->ws_front = o;
+    pl->ws_front_bytes = (umnn_backward_front_shape(a.m) && pl->wpb == 4) ? umnn_backward_front_scratch_bytes(a.m, a.NI) : 0;
+    o += pl->ws_front_bytes; o = (o + 255) & ~255LL;
     pl->ws_total = o;
     return 0;
 }
@@ -617,6 +621,9 @@ extern "C" int umnn_cc_backward_kind(const umnn_mlp* net, int E) {
     const int ks = (ksu && tmax == T) ? ksu : 0;
     const int nm = best_nacc(T, 1, ks);
     if (ks && nm >= 0 && find_bwd(T, nm, 1, ks)->ksc) return 1;
+    // wide first hidden layer + narrow rest (MNISTExperiment's 100-50-50-50-50): the three-stage kernels of
+    // cc_backward_front.hip (bf16 arithmetic only)
+    if (umnn_backward_front_shape(m) && umnn_options().bwd_precision == UMNN_PRECISION_BF16X3) return 1;
     return T <= 4 ? 0 : -1;
 }
 
@@ -663,9 +670,16 @@ extern "C" int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const
 
     // ---- bf16-split kernels (default) where the shape allows; otherwise / on request the fp32-MFMA kernels below
     bool done = false;
-    const int ns_used = pl.ns > nb_steps + 1 ? nb_steps + 1 : pl.ns;
+    int ns_used = pl.ns > nb_steps + 1 ? nb_steps + 1 : pl.ns;
     a.ns = ns_used;
-    if (umnn_options().bwd_precision == UMNN_PRECISION_BF16X3) {
+    if (umnn_options().bwd_precision == UMNN_PRECISION_BF16X3 && pl.ws_front_bytes > 0) {
+        a.ns = 1;
+        const int rc = umnn_launch_backward_front(a, net, pl.nblocks, ws + pl.ws_front, pl.ws_front_bytes, stream);
+        if (rc == 0) { done = true; ns_used = 1; }
+        else if (rc != UMNN_EUNSUPPORTED) return rc;
+        else a.ns = ns_used;
+    }
+    if (!done && umnn_options().bwd_precision == UMNN_PRECISION_BF16X3) {
         int nw = 0;
         const int rc = umnn_launch_backward_bf16(a, net, pl.nblocks, &nw, stream);
         if (rc == 0) done = true;

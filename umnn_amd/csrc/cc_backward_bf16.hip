@@ -1,428 +1,7 @@
-// Backward of the quadrature on the bf16 matrix cores -- the same gradient convention and the same reference lines
-// as cc_backward.hip, for the shapes the headline configurations use: every hidden layer 48..62 wide (4 tiles of 16)
-// and at most 3 hidden->hidden layers.  One pass, persistent waves (one per SIMD, the whole register file), one tile
-// of 16 integrals per wave.  Per quadrature node:
-//   forward recompute  W_l fragments x split(a_l), THREE bf16 pieces / 6 cross terms: fp32-level accuracy (the sign of
-//                      each activation is later read off its leading bf16 piece, which is kept for dW anyway).  This one
-//                      must be that accurate: the backward needs the SIGN of every pre-activation (LeakyReLU/ReLU
-//                      kink), and a recompute that is only 1e-5 accurate flips enough signs to move small-batch
-//                      gradients by 5e-4 relative to the reference (measured with a 3-term recompute).
-//   delta chain        W_l^T fragments x split(delta), two pieces / 3 terms (smooth: errors stay ~1e-5)
-//   dW_l += delta_{l+1} (x) a_l   contracts over the 16 POINTS, which sit on the wrong lane axis.  The transposition
-//                      is done by the matrix core itself: the packed bf16 fragments of a_l / delta (already there as
-//                      B operands) are reused as A operands against a 0/1 selection fragment, which returns
-//                      "feature on lane&15, points on (lane>>4, r)" -- exact, since it multiplies by one.  No LDS round
-//                      trip (the fp32 kernel's transposes cost ~770 LDS cycles per layer and tile, CU-wide).
-//                      The product then runs as 16 output tiles x 3 terms on the K = 16 instruction (16x16x16).
-// What depends on an integral only once leaves as dc = sum_k delta_1 (finishing kernels of cc_backward.hip);
-// every wave writes its partial d_theta slice (deterministic reduction, no atomics).
-#include "cc_bf16.h"
-#include "cc_bwd_shared.h"
-
-constexpr int BT = 4;            // tiles of 16 features per hidden layer
-constexpr int BKS = 2;           // K-steps of 32 features
-constexpr int FRAG = 512;        // ushorts per fragment (64 lanes x 8)
-constexpr int NPF = 3;           // bf16 pieces in the forward recompute (6 cross terms)
-constexpr int NPB = 2;           // bf16 pieces in the delta chain and the dW product (3 cross terms)
-
-struct BwdBf16Args {
-    BwdArgs b;
-    int off_fwd[UMNN_MAX_LINEAR];    // ushort offset of the forward fragment image of hidden layer l -> l+1 (NPF pieces)
-    int off_tr[UMNN_MAX_LINEAR];     // ushort offset of the transposed image (delta_{l+1} -> delta_l, NPB pieces)
-};
-
-// fragment (tile t, K-step s, piece) of W (TRANSPOSED = false: rows = out features, K = in features incl. the
-// constant-one feature / bias column) or of W^T (rows = in features, K = out features; no bias/constant entries:
-// gradients must not flow through the constant feature).
-template <bool TRANSPOSED, int NP>
-__device__ __forceinline__ void stage_frag_image(const MlpDev& m, int l, unsigned short* img, int tid, int nthreads) {
-    const int Hin = m.width[l], Hout = m.width[l + 1];
-    const float* __restrict__ W = m.W[l];
-    const float* __restrict__ b = m.b[l];
-    for (int idx = tid; idx < BT * BKS * FRAG; idx += nthreads) {
-        const int j = idx & 7, ln = (idx >> 3) & 63, ts = idx >> 9;
-        const int s = ts % BKS, t = ts / BKS;
-        const int frow = fout_of(t, ln & 15);
-        const int fk = feat_of(2 * s + (j >> 2), j & 3, ln >> 4);
-        float v = 0.f;
-        if (!TRANSPOSED) {
-            const int fo = frow, fi = fk;
-            if (fo < Hout) {
-                if (fi < Hin) v = W[fo * Hin + fi];
-                else if (fi == Hin) v = b[fo];
-            } else if (fo == Hout && fi == Hin) {
-                v = 1.f;
-            }
-        } else {
-            const int fi = frow, fo = fk;
-            if (fo < Hout && fi < Hin) v = W[fo * Hin + fi];
-        }
-#pragma unroll
-        for (int part = 0; part < NP; ++part) {
-            const unsigned short hb = bf16_rn_bits(v);
-            img[(ts * NP + part) * FRAG + ln * 8 + j] = hb;
-            v -= bf16_bits_to_f32(hb);
-        }
-    }
-}
-
-template <int NP>
-struct BFrag { u32x4 v[BKS][NP]; };
-
-template <int NRL, int NP>
-__device__ __forceinline__ void split_regs(const f32x4 (&act)[BT], BFrag<NP>& bf) {
-    constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
-#pragma unroll
-    for (int s = 0; s < BKS; ++s) {
-        unsigned q0[NP], q1[NP], q2[NP], q3[NP];
-#pragma unroll
-        for (int k2 = 0; k2 < NP; ++k2) q0[k2] = q1[k2] = q2[k2] = q3[k2] = 0u;
-        if (8 * s + 0 < NLIVE) split_pair<NP>(act[2 * s][0], act[2 * s][1], q0);
-        if (8 * s + 2 < NLIVE) split_pair<NP>(act[2 * s][2], act[2 * s][3], q1);
-        if (8 * s + 4 < NLIVE) split_pair<NP>(act[2 * s + 1][0], act[2 * s + 1][1], q2);
-        if (8 * s + 6 < NLIVE) split_pair<NP>(act[2 * s + 1][2], act[2 * s + 1][3], q3);
-#pragma unroll
-        for (int k2 = 0; k2 < NP; ++k2) bf.v[s][k2] = u32x4{q0[k2], q1[k2], q2[k2], q3[k2]};
-    }
-}
-
-// acc[t] = sum over K-steps and the cross terms (wa + ba < NP) of frag(t, s, wa) * bf[s][ba]
-template <int NP>
-__device__ __forceinline__ void gemm_frags(const unsigned short* img, const BFrag<NP>& bf, f32x4 (&acc)[BT]) {
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};        // the first MFMA of every accumulator takes the literal 0 as C
-#pragma unroll
-    for (int s = 0; s < BKS; ++s) {
-        u32x4 wf[BT][NP];
-#pragma unroll
-        for (int t = 0; t < BT; ++t)
-#pragma unroll
-            for (int k2 = 0; k2 < NP; ++k2)
-                wf[t][k2] = *reinterpret_cast<const u32x4*>(img + ((t * BKS + s) * NP + k2) * FRAG);
-#pragma unroll
-        for (int wa = 0; wa < NP; ++wa)
-#pragma unroll
-            for (int ba = 0; ba < NP; ++ba) {
-                if (wa + ba >= NP) continue;
-                const bool first = s == 0 && wa == 0 && ba == 0;
-#pragma unroll
-                for (int t = 0; t < BT; ++t) acc[t] = mfma_bf16(wf[t][wa], bf.v[s][ba], first ? zero : acc[t]);
-            }
-    }
-}
-
-// d act / d pre-activation of the feature held in register (t, r), read off the SIGN of its leading bf16 piece
-// (a_l > 0  <=>  its round-to-nearest bf16 is > 0): 1 for a positive activation, `slope` otherwise -- the same
-// convention as torch's LeakyReLU / ReLU backward (x > 0 ? 1 : slope).
-template <int NP>
-__device__ __forceinline__ float act_grad(const BFrag<NP>& a, int t, int r, float slope) {
-    const unsigned u = a.v[t >> 1][0][(t & 1) * 2 + (r >> 1)];
-    const int hi16 = (r & 1) ? (int)(u & 0xffff0000u) : (int)(u << 16);
-    return hi16 > 0 ? 1.f : slope;
-}
-
-// Transposition on the matrix core.  `x` holds, as packed bf16 k-slots, the features of two tiles (2s, 2s+1) for the
-// point lane&15 -- i.e. it is a valid A operand with rows = points.  Multiplying by the 0/1 fragment sel[h] (k-slot of
-// feature 16(2s+h)+n  ->  column n) returns D[point][n]: lane (g, n) gets feature 16(2s+h)+n at points 4g..4g+3.
-// Both pieces are transposed and re-packed as the 4 k-slots of a 16x16x16 operand (K = the 16 points of the tile).
-__device__ __forceinline__ void transpose_pieces(const BFrag<NPB>& x, const u32x4 (&sel)[2], u32x2 (&out)[BT][NPB]) {
-#pragma unroll
-    for (int s = 0; s < BKS; ++s)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int part = 0; part < NPB; ++part) {
-                const f32x4 tr = mfma_bf16(x.v[s][part], sel[h], f32x4{0.f, 0.f, 0.f, 0.f});
-                const bf16x2 lo = __builtin_convertvector(f32x2{tr[0], tr[1]}, bf16x2);     // exact: values are bf16 already
-                const bf16x2 hi = __builtin_convertvector(f32x2{tr[2], tr[3]}, bf16x2);
-                out[2 * s + h][part] = u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
-            }
-}
-
-// LH = number of hidden layers (compile-time: the layer loops are unrolled so that every register array is
-// statically indexed); NACC = LH - 1 hidden->hidden layers, all accumulated in this one pass (l_lo = 1).
-template <int LH, bool EDGE, int NRL>
-__global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf16Args args) {
-    constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
-    constexpr int NACC = LH - 1;
-    constexpr int NA = NACC > 0 ? NACC : 1;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const BwdArgs& a = args.b;
-    const MlpDev& m = a.m;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, p = lane & 15;
-    constexpr int L = LH;
-    const int H1 = m.width[1], HL = m.width[L];
-    const int E = a.E, d = a.d, n = a.n;
-    const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
-    unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
-
-    for (int l = 1; l < L; ++l) {
-        stage_frag_image<false, NPF>(m, l, lds16 + args.off_fwd[l], tid, blockDim.x);
-        stage_frag_image<true, NPB>(m, l, lds16 + args.off_tr[l], tid, blockDim.x);
-    }
-    __syncthreads();
-    const unsigned short* frag_base = lds16 + lane * 8;
-
-    // selection fragments of the matrix-core transpose: lane (g, n) sets k-slot 4h + (n>>2) to 1.0 iff (n&3) == g
-    u32x4 sel[2];
-    {
-        const unsigned one_lo = 0x3f80u, one_hi = 0x3f800000u;      // bf16 1.0 in the low / high half of a dword
-        const int slot = p >> 2;                                    // k-slot inside the 4 slots of tile h
-        const unsigned w0 = (p & 3) == g ? (slot == 0 ? one_lo : slot == 1 ? one_hi : 0u) : 0u;
-        const unsigned w1 = (p & 3) == g ? (slot == 2 ? one_lo : slot == 3 ? one_hi : 0u) : 0u;
-        sel[0] = u32x4{w0, w1, 0u, 0u};
-        sel[1] = u32x4{0u, 0u, w0, w1};
-    }
-
-    float w1x[BT][4], wout[BT][4];
-    {
-        const float* __restrict__ W0 = m.W[0];
-        const float* __restrict__ WL = m.W[L];
-        const float bL = m.b[L][0];
-#pragma unroll
-        for (int t = 0; t < BT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = feat_of(t, r, g);
-                w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
-                wout[t][r] = f < HL ? WL[f] : (f == HL ? bL : 0.f);
-            }
-    }
-
-    f32x4 dW[NA][BT][BT];
-#pragma unroll
-    for (int j = 0; j < NA; ++j)
-#pragma unroll
-        for (int to = 0; to < BT; ++to)
-#pragma unroll
-            for (int ti = 0; ti < BT; ++ti) dW[j][to][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 dW1x[BT], dwo[BT];
-#pragma unroll
-    for (int t = 0; t < BT; ++t) { dW1x[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dwo[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-    const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + wid;
-    const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
-
-    const unsigned nsp = a.ns > 1 ? (unsigned)a.ns : 1u;       // node-range split (small batches), see BwdArgs::ns
-    for (unsigned item = wave_global; item < a.ngroups * nsp; item += nwaves) {
-        const unsigned grp = item / nsp, part = item - grp * nsp;
-        const int k_lo = (int)(((long long)part * (n + 1)) / nsp), k_hi = (int)(((long long)(part + 1) * (n + 1)) / nsp);
-        const long long q = (long long)grp * 16 + p;
-        const bool ok = q < a.NI;
-        const long long qq = ok ? q : a.NI - 1;
-        const float xv = io_ld(a.x, qq, a.x_bf16);
-        const float x0v = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
-        const float dxv = xv - x0v;
-        const float gv = ok ? io_ld(a.g, qq, a.x_bf16) : 0.f;
-        const float gfxv = (ok && a.gfx) ? io_ld(a.gfx, qq, a.x_bf16) : 0.f;
-        const float cotbase = gv * dxv * 0.5f;
-        const long long bi = qq / d;
-        const IoView hb = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
-
-        f32x4 c[BT];
-        {
-            const float* __restrict__ W0 = m.W[0];
-            const float* __restrict__ b0 = m.b[0];
-#pragma unroll
-            for (int t = 0; t < BT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int f = feat_of(t, r, g);
-                    c[t][r] = f < H1 ? b0[f] : (f == H1 ? 1.f : 0.f);
-                }
-            for (int se = 0; se < (E + 3) / 4; ++se) {
-                const int e = 4 * se + g;
-                const float hv = e < E ? hb[(long long)e * d] : 0.f;
-#pragma unroll
-                for (int t = 0; t < BT; ++t) {
-                    const int fo = fout_of(t, p);
-                    const float A = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
-                    c[t] = mfma16(A, hv, c[t]);
-                }
-            }
-        }
-
-        f32x4 dcs[BT];
-#pragma unroll
-        for (int t = 0; t < BT; ++t) dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float fxv = 0.f, fx0v = 0.f, dfdt = 0.f;
-
-        for (int k = k_lo; k < k_hi; ++k) {
-            const float u = a.ccs[k] + 1.f;
-            const float wk = a.ccw[k];
-            const float tk = k == 0 ? xv : __fadd_rn(x0v, __fmul_rn(dxv, u) * 0.5f);
-            f32x4 act[BT];
-            BFrag<NPB> asave[NA];            // packed (hi, next) pieces of a_l for the layers whose dW this pass owns
-            // ---------------- forward recompute (6 cross terms) ----------------
-#pragma unroll
-            for (int t = 0; t < BT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    act[t][r] = 4 * t + r < NLIVE ? hidden_act_f(fmaf(w1x[t][r], tk, c[t][r]), slope) : 0.f;
-#pragma unroll
-            for (int l = 1; l < L; ++l) {
-                BFrag<NPF> bf;
-                split_regs<NRL, NPF>(act, bf);
-#pragma unroll
-                for (int s = 0; s < BKS; ++s)
-#pragma unroll
-                    for (int k2 = 0; k2 < NPB; ++k2) asave[l - 1].v[s][k2] = bf.v[s][k2];
-                f32x4 acc[BT];
-                gemm_frags<NPF>(frag_base + args.off_fwd[l], bf, acc);
-#pragma unroll
-                for (int t = 0; t < BT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) act[t][r] = 4 * t + r < NLIVE ? hidden_act_f(acc[t][r], slope) : 0.f;
-            }
-            float sdot = 0.f;
-#pragma unroll
-            for (int t = 0; t < BT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * t + r < NLIVE) sdot = fmaf(wout[t][r], act[t][r], sdot);
-            sdot = group_allreduce(sdot);
-            const float f = out_act_f(sdot, m.out_act);
-            const float fp = out_grad_f(sdot, m.out_act);
-            if (k == 0) fxv = f;
-            if (k == n) fx0v = f;
-
-            // ---------------- tangent pass at node 0: d f / d x for the g_fx term ----------------
-            if (EDGE && k == 0 && a.gfx) {
-                f32x4 ta[BT];
-#pragma unroll
-                for (int t = 0; t < BT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ta[t][r] = 4 * t + r < NLIVE ? w1x[t][r] * act_grad(asave[0], t, r, slope) : 0.f;
-#pragma unroll
-                for (int l = 1; l < L; ++l) {
-                    BFrag<NPF> bf;
-                    split_regs<NRL, NPF>(ta, bf);
-                    f32x4 tz[BT];
-                    gemm_frags<NPF>(frag_base + args.off_fwd[l], bf, tz);
-#pragma unroll
-                    for (int t = 0; t < BT; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            // layer l+1: its activation is a saved fragment, except the last layer whose act is still live
-                            const float fac = l + 1 < L ? act_grad(asave[l + 1 < L ? l : 0], t, r, slope)
-                                                        : (act[t][r] > 0.f ? 1.f : slope);
-                            ta[t][r] = 4 * t + r < NLIVE ? tz[t][r] * fac : 0.f;
-                        }
-                }
-                float ds = 0.f;
-#pragma unroll
-                for (int t = 0; t < BT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ds = fmaf(wout[t][r], ta[t][r], ds);
-                dfdt = fp * group_allreduce(ds);
-            }
-
-            // ---------------- backward sweep ----------------
-            const float cot = fmaf(cotbase, wk, k == 0 ? gfxv : 0.f);
-            const float dout = cot * fp;
-            f32x4 delta[BT];
-#pragma unroll
-            for (int t = 0; t < BT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (EDGE) dwo[t][r] = fmaf(dout, act[t][r], dwo[t][r]);
-                    delta[t][r] = dout * wout[t][r] * (act[t][r] > 0.f ? 1.f : slope);
-                }
-#pragma unroll
-            for (int l = L - 1; l >= 1; --l) {
-                BFrag<NPB> bd;
-                split_regs<NRL, NPB>(delta, bd);
-                {
-                    u32x2 dT[BT][NPB], aT[BT][NPB];
-                    transpose_pieces(bd, sel, dT);
-                    transpose_pieces(asave[l - 1], sel, aT);
-#pragma unroll
-                    for (int wa = 0; wa < NPB; ++wa)
-#pragma unroll
-                        for (int ba = 0; ba < NPB; ++ba) {
-                            if (wa + ba >= NPB) continue;
-#pragma unroll
-                            for (int to = 0; to < BT; ++to)
-#pragma unroll
-                                for (int ti = 0; ti < BT; ++ti)
-                                    dW[l - 1][to][ti] = mfma_bf16_k16(dT[to][wa], aT[ti][ba], dW[l - 1][to][ti]);
-                        }
-                }
-                f32x4 nd[BT];
-                gemm_frags<NPB>(frag_base + args.off_tr[l], bd, nd);
-#pragma unroll
-                for (int t = 0; t < BT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        delta[t][r] = 4 * t + r < NLIVE ? nd[t][r] * act_grad(asave[l - 1], t, r, slope) : 0.f;
-            }
-            if (EDGE) {
-#pragma unroll
-                for (int t = 0; t < BT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dcs[t][r] += delta[t][r];
-                        dW1x[t][r] = fmaf(delta[t][r], tk, dW1x[t][r]);
-                    }
-            }
-        }
-
-        if (EDGE && ok) {
-#pragma unroll
-            for (int t = 0; t < BT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int f = feat_of(t, r, g);
-                    if (f < H1) a.dc[(size_t)part * a.NI * H1 + q * H1 + f] = dcs[t][r];
-                }
-            if (g == 0) {
-                if (a.dx && k_lo == 0) io_st(a.dx, q, fmaf(gfxv, dfdt, fxv * gv), a.x_bf16);
-                if (a.dx0 && k_hi == n + 1) io_st(a.dx0, q, -fx0v * gv, a.x_bf16);
-            }
-        }
-    }
-
-    // ---------------- write this wave's partial d_theta ----------------
-    // dW tile (to, ti): row 4g+r is the row (lane&15 = 4g+r) of the delta^T operand = feature 16 to + 4g+r (natural, the
-    // transpose delivers features in natural order inside a tile); column lane&15 likewise feature 16 ti + (lane&15).
-    float* part = a.partials + (size_t)wave_global * a.n_params;
-#pragma unroll
-    for (int j = 0; j < NACC; ++j) {
-        const int l = 1 + j;
-        {
-            const int Hin = m.width[l], Hout = m.width[l + 1];
-#pragma unroll
-            for (int to = 0; to < BT; ++to)
-#pragma unroll
-                for (int ti = 0; ti < BT; ++ti)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int fo = 16 * to + 4 * g + r, fi = 16 * ti + (lane & 15);
-                        if (fo < Hout) {
-                            if (fi < Hin) part[a.poffW[l] + fo * Hin + fi] = dW[j][to][ti][r];
-                            else if (fi == Hin) part[a.poffb[l] + fo] = dW[j][to][ti][r];
-                        }
-                    }
-        }
-    }
-    if (EDGE) {
-#pragma unroll
-        for (int t = 0; t < BT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v1 = dW1x[t][r], v2 = dwo[t][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { v1 += __shfl_xor(v1, o); v2 += __shfl_xor(v2, o); }
-                const int f = feat_of(t, r, g);
-                if (p == 0) {
-                    if (f < H1) part[a.poffW[0] + f * (1 + E)] = v1;
-                    if (f < HL) part[a.poffW[L] + f] = v2;
-                    else if (f == HL) part[a.poffb[L]] = v2;
-                }
-            }
-    }
-}
+// Backward of the quadrature on the bf16 matrix cores: variant table and launcher of the one-pass kernels (the kernel
+// template, with its layout notes, lives in cc_bwd_bf16_kernel.h and is shared with the staged backward of
+// cc_backward_front.hip).
+#include "cc_bwd_bf16_kernel.h"
 
 // ------------------------------------------------------------------------------------------
 typedef void (*bwd_bf16_kernel_t)(const BwdBf16Args);
@@ -442,6 +21,7 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
                               hipStream_t stream) {
     BwdBf16Args args;
     args.b = base;
+    args.z2 = nullptr; args.d2 = nullptr; args.tz2 = nullptr; args.grp0 = 0; args.nl2 = 0; args.accumulate = 0;
     BwdArgs& a = args.b;
     const int L = a.m.n_linear - 1;
     if (L < 2 || L - 1 > 3) return UMNN_EUNSUPPORTED;

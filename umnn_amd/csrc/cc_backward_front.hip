@@ -1,0 +1,555 @@
+// Backward of the quadrature for nets whose FIRST hidden layer is wider than four 16-feature tiles and whose other hidden
+// layers fit four (MNISTExperiment's integrand 31-100-50-50-50-50-1, /root/reference MNISTExperiment.py:18,238; same
+// reference lines as cc_backward.hip for the arithmetic: ParallelNeuralIntegral.py:66-94,110-123).
+//
+// One pass cannot hold this shape: the dW accumulators alone would be 28 + 3 x 16 tiles = 304 registers next to a live
+// set of ~310, and the fragment images 190 KB of 160.  The register-spilling generic kernels were ~100x slower than
+// they should be, so round 1 sent this family to a materialised ATen chain.  Here the pass is cut in three at the
+// 50-wide pre-activation of hidden layer 2 -- and the cut goes through HBM, which this GPU has 288 GB of:
+//
+//   A  cc_front_fwd_kernel   per tile and node: a1 = act(W1[:,0] t + c) (T1 tiles, VALU), z2 = G1 a1 + b2 with six bf16 cross
+//                            terms (fp32-level: the signs of z2 decide LeakyReLU kinks downstream); z2 is written to HBM in
+//                            the register layout of the middle kernel, [tile][node][register][lane]: every store is a
+//                            coalesced 256-B row.  Also d z2 / d t at node 0 (tangent of the g_fx term).
+//   B  cc_bwd_bf16_kernel<LH, EDGE, NRL, FRONT=true>   the flagship one-pass kernel on the net from hidden layer 2 on: reads z2
+//                            (one node ahead of its use), does everything it does for a 4-tile net (recompute, delta chain, dW
+//                            of the 50x50 layers, output layer, Leibniz terms) and writes delta_2 = dL/dz2 back to HBM.
+//   C  cc_front_bwd_kernel   per tile and node: recomputes a1, reads delta_2, accumulates dG1 += delta_2 (x) a1 (28 tiles on the
+//                            K=16 MFMA, operands transposed by the matrix core as in the flagship kernel), back-propagates
+//                            delta_1 = (G1^T delta_2) act'(z1), and leaves dc = sum_k delta_1 and dW1[:,0] like the one-pass
+//                            kernels do; the usual finishing kernels (d_h, dW1[:,1:], d_theta reduction) follow.
+//
+// Scratch: 2 x (n+1) x ceil((H2+1)/4) x 256 B per tile (339 KB at n = 50); tiles are processed in chunks that fit the
+// scratch the workspace provides (1 GiB), every wave's d_theta slice accumulating across chunks.  HBM traffic per
+// tile-node 4 x 3.3 KB against ~5 us of matrix work: three orders of magnitude below the bandwidth roof.
+#include "cc_bwd_bf16_kernel.h"
+
+struct FrontArgs {
+    BwdArgs b;              // the FULL net
+    float* z2;
+    float* d2;
+    float* tz2;             // nullable (no g_fx)
+    unsigned grp0;          // first tile of the chunk; b.ngroups = tiles in the chunk
+    int nl2;                // live registers of hidden layer 2
+    int accumulate;
+};
+
+// fragment image of G1 = W[1] (hidden 1 -> hidden 2).  TRANSPOSED = false: rows = hidden-2 features (BT tiles, incl. the
+// constant-one row), K = hidden-1 features: KSF = T1/2 full K-steps + a half K-step (K = 16) when T1 is odd, laid out
+// behind the full ones.  TRANSPOSED = true: rows = hidden-1 features (T1 tiles), K = hidden-2 features (two K-steps), no
+// bias / constant entries (gradients do not flow through the constant feature).
+template <int T1, bool TRANSPOSED, int NP>
+__device__ __forceinline__ void stage_g1_image(const MlpDev& m, unsigned short* img, int tid, int nthreads) {
+    constexpr int KSF = T1 / 2;
+    const int Hin = m.width[1], Hout = m.width[2];
+    const float* __restrict__ W = m.W[1];
+    const float* __restrict__ b = m.b[1];
+    constexpr int ROWT = TRANSPOSED ? T1 : BT;
+    constexpr int KS = TRANSPOSED ? BKS : KSF;
+    for (int idx = tid; idx < ROWT * KS * FRAG; idx += nthreads) {
+        const int j = idx & 7, ln = (idx >> 3) & 63, ts = idx >> 9;
+        const int s = ts % KS, t = ts / KS;
+        const int frow = fout_of(t, ln & 15);
+        const int fk = feat_of(2 * s + (j >> 2), j & 3, ln >> 4);
+        float v = 0.f;
+        if (!TRANSPOSED) {
+            if (frow < Hout) v = fk < Hin ? W[frow * Hin + fk] : (fk == Hin ? b[frow] : 0.f);
+            else if (frow == Hout && fk == Hin) v = 1.f;
+        } else {
+            if (fk < Hout && frow < Hin) v = W[fk * Hin + frow];
+        }
+#pragma unroll
+        for (int part = 0; part < NP; ++part) {
+            const unsigned short hb = bf16_rn_bits(v);
+            img[(ts * NP + part) * FRAG + ln * 8 + j] = hb;
+            v -= bf16_bits_to_f32(hb);
+        }
+    }
+    if (!TRANSPOSED && (T1 & 1)) {
+        unsigned short* himg = img + BT * KSF * NP * FRAG;
+        for (int idx = tid; idx < BT * 256; idx += nthreads) {
+            const int j = idx & 3, ln = (idx >> 2) & 63, t = idx >> 8;
+            const int frow = fout_of(t, ln & 15);
+            const int fk = feat_of(T1 - 1, j, ln >> 4);
+            float v = 0.f;
+            if (frow < Hout) v = fk < Hin ? W[frow * Hin + fk] : (fk == Hin ? b[frow] : 0.f);
+            else if (frow == Hout && fk == Hin) v = 1.f;
+#pragma unroll
+            for (int part = 0; part < NP; ++part) {
+                const unsigned short hb = bf16_rn_bits(v);
+                himg[(t * NP + part) * 256 + ln * 4 + j] = hb;
+                v -= bf16_bits_to_f32(hb);
+            }
+        }
+    }
+}
+
+// hoisted first-layer term of one tile: c = W1[:,1:] h + b1 (and the constant-one feature), fp32 MFMA, T1 tiles
+template <int T1>
+__device__ __forceinline__ void front_prologue(const MlpDev& m, const IoView& hb, int E, int d, int g, int p, f32x4 (&c)[T1]) {
+    const int H1 = m.width[1];
+    const float* __restrict__ W0 = m.W[0];
+    const float* __restrict__ b0 = m.b[0];
+#pragma unroll
+    for (int t = 0; t < T1; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = feat_of(t, r, g);
+            c[t][r] = f < H1 ? b0[f] : (f == H1 ? 1.f : 0.f);
+        }
+    for (int se = 0; se < (E + 3) / 4; ++se) {
+        const int e = 4 * se + g;
+        const float hv = e < E ? hb[(long long)e * d] : 0.f;
+#pragma unroll
+        for (int t = 0; t < T1; ++t) {
+            const int fo = fout_of(t, p);
+            const float A = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
+            c[t] = mfma16(A, hv, c[t]);
+        }
+    }
+}
+
+// out[BT] = G1-fragments x split(act[T1]) with NP pieces / the cross terms wa + ba < NP
+template <int T1, int NP>
+__device__ __forceinline__ void front_gemm(const unsigned short* base, int lane, const f32x4 (&act)[T1], f32x4 (&out)[BT]) {
+    const unsigned short* img = base + lane * 8;            // full fragments: 8 bf16 per lane; half fragments below: 4
+    constexpr int KSF = T1 / 2;
+    u32x4 bf[KSF][NP];
+#pragma unroll
+    for (int s = 0; s < KSF; ++s) {
+        unsigned q0[NP], q1[NP], q2[NP], q3[NP];
+        split_pair<NP>(act[2 * s][0], act[2 * s][1], q0);
+        split_pair<NP>(act[2 * s][2], act[2 * s][3], q1);
+        split_pair<NP>(act[2 * s + 1][0], act[2 * s + 1][1], q2);
+        split_pair<NP>(act[2 * s + 1][2], act[2 * s + 1][3], q3);
+#pragma unroll
+        for (int k2 = 0; k2 < NP; ++k2) bf[s][k2] = u32x4{q0[k2], q1[k2], q2[k2], q3[k2]};
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KSF; ++s) {
+        u32x4 wf[BT][NP];
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int k2 = 0; k2 < NP; ++k2)
+                wf[t][k2] = *reinterpret_cast<const u32x4*>(img + ((t * KSF + s) * NP + k2) * FRAG);
+#pragma unroll
+        for (int wa = 0; wa < NP; ++wa)
+#pragma unroll
+            for (int ba = 0; ba < NP; ++ba) {
+                if (wa + ba >= NP) continue;
+                const bool first = s == 0 && wa == 0 && ba == 0;
+#pragma unroll
+                for (int t = 0; t < BT; ++t) out[t] = mfma_bf16(wf[t][wa], bf[s][ba], first ? zero : out[t]);
+            }
+    }
+    if constexpr (T1 & 1) {
+        u32x2 hb[NP];
+        {
+            unsigned q0[NP], q1[NP];
+            split_pair<NP>(act[T1 - 1][0], act[T1 - 1][1], q0);
+            split_pair<NP>(act[T1 - 1][2], act[T1 - 1][3], q1);
+#pragma unroll
+            for (int k2 = 0; k2 < NP; ++k2) hb[k2] = u32x2{q0[k2], q1[k2]};
+        }
+        const unsigned short* himg = base + BT * KSF * NP * FRAG + lane * 4;
+        u32x2 wh[BT][NP];
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int k2 = 0; k2 < NP; ++k2) wh[t][k2] = *reinterpret_cast<const u32x2*>(himg + (t * NP + k2) * 256);
+#pragma unroll
+        for (int wa = 0; wa < NP; ++wa)
+#pragma unroll
+            for (int ba = 0; ba < NP; ++ba) {
+                if (wa + ba >= NP) continue;
+#pragma unroll
+                for (int t = 0; t < BT; ++t) out[t] = mfma_bf16_k16(wh[t][wa], hb[ba], out[t]);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- stage A
+template <int T1>
+__global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_fwd_kernel(const FrontArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const BwdArgs& a = fa.b;
+    const MlpDev& m = a.m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, p = lane & 15;
+    const int H1 = m.width[1];
+    const int E = a.E, d = a.d, n = a.n, nl2 = fa.nl2;
+    const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
+    unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
+    stage_g1_image<T1, false, NPF>(m, lds16, tid, blockDim.x);
+    __syncthreads();
+
+    float w1x[T1][4];
+    {
+        const float* __restrict__ W0 = m.W[0];
+#pragma unroll
+        for (int t = 0; t < T1; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = feat_of(t, r, g);
+                w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
+            }
+    }
+    const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + wid;
+    const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
+    for (unsigned item = wave_global; item < a.ngroups; item += nwaves) {
+        const unsigned grp = fa.grp0 + item;
+        const long long q = (long long)grp * 16 + p;
+        const long long qq = q < a.NI ? q : a.NI - 1;
+        const float xv = io_ld(a.x, qq, a.x_bf16);
+        const float x0v = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
+        const float dxv = xv - x0v;
+        const long long bi = qq / d;
+        const IoView hb = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
+        f32x4 c[T1];
+        front_prologue<T1>(m, hb, E, d, g, p, c);
+        const size_t frag0 = (size_t)item * (size_t)(n + 1) * nl2 * 64 + lane;
+        for (int k = 0; k <= n; ++k) {
+            const float u = a.ccs[k] + 1.f;
+            const float tk = k == 0 ? xv : __fadd_rn(x0v, __fmul_rn(dxv, u) * 0.5f);
+            f32x4 z1[T1], act[T1];
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    z1[t][r] = fmaf(w1x[t][r], tk, c[t][r]);
+                    act[t][r] = hidden_act_f(z1[t][r], slope);
+                }
+            f32x4 z2[BT];
+            front_gemm<T1, NPF>(lds16, lane, act, z2);
+#pragma unroll
+            for (int t = 0; t < BT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * t + r < nl2) fa.z2[frag0 + ((size_t)k * nl2 + 4 * t + r) * 64] = z2[t][r];
+            if (k == 0 && fa.tz2) {       // d z2 / d t = G1 (W1[:,0] . act'(z1)): linear in the tangent, no bias
+                f32x4 ta[T1];
+#pragma unroll
+                for (int t = 0; t < T1; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ta[t][r] = w1x[t][r] * (z1[t][r] > 0.f ? 1.f : slope);
+                f32x4 tz[BT];
+                front_gemm<T1, NPF>(lds16, lane, ta, tz);
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * t + r < nl2) fa.tz2[((size_t)item * nl2 + 4 * t + r) * 64 + lane] = tz[t][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- stage C
+template <int T1>
+__global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const FrontArgs fa) {
+    constexpr int KS1 = (T1 + 1) / 2;          // K-steps of 32 hidden-1 features (the last one half empty when T1 is odd)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const BwdArgs& a = fa.b;
+    const MlpDev& m = a.m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, p = lane & 15;
+    const int H1 = m.width[1], H2 = m.width[2];
+    const int E = a.E, d = a.d, n = a.n, nl2 = fa.nl2;
+    const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
+    unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
+    stage_g1_image<T1, true, NPB>(m, lds16, tid, blockDim.x);
+    __syncthreads();
+    const unsigned short* frag_base = lds16 + lane * 8;
+
+    u32x4 sel[2];        // selection fragments of the matrix-core transpose (see cc_bwd_bf16_kernel)
+    {
+        const unsigned one_lo = 0x3f80u, one_hi = 0x3f800000u;
+        const int slot = p >> 2;
+        const unsigned w0 = (p & 3) == g ? (slot == 0 ? one_lo : slot == 1 ? one_hi : 0u) : 0u;
+        const unsigned w1 = (p & 3) == g ? (slot == 2 ? one_lo : slot == 3 ? one_hi : 0u) : 0u;
+        sel[0] = u32x4{w0, w1, 0u, 0u};
+        sel[1] = u32x4{0u, 0u, w0, w1};
+    }
+    float w1x[T1][4];
+    {
+        const float* __restrict__ W0 = m.W[0];
+#pragma unroll
+        for (int t = 0; t < T1; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = feat_of(t, r, g);
+                w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
+            }
+    }
+    f32x4 dG1[BT][T1], dW1x[T1];
+#pragma unroll
+    for (int to = 0; to < BT; ++to)
+#pragma unroll
+        for (int ti = 0; ti < T1; ++ti) dG1[to][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T1; ++t) dW1x[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + wid;
+    const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
+    for (unsigned item = wave_global; item < a.ngroups; item += nwaves) {
+        const unsigned grp = fa.grp0 + item;
+        const long long q = (long long)grp * 16 + p;
+        const bool ok = q < a.NI;
+        const long long qq = ok ? q : a.NI - 1;
+        const float xv = io_ld(a.x, qq, a.x_bf16);
+        const float x0v = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
+        const float dxv = xv - x0v;
+        const long long bi = qq / d;
+        const IoView hb = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
+        f32x4 c[T1], dcs[T1];
+        front_prologue<T1>(m, hb, E, d, g, p, c);
+#pragma unroll
+        for (int t = 0; t < T1; ++t) dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const size_t frag0 = (size_t)item * (size_t)(n + 1) * nl2 * 64 + lane;
+        f32x4 dnext[BT];
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dnext[t][r] = 4 * t + r < nl2 ? fa.d2[frag0 + (size_t)(4 * t + r) * 64] : 0.f;
+
+        for (int k = 0; k <= n; ++k) {
+            const float u = a.ccs[k] + 1.f;
+            const float tk = k == 0 ? xv : __fadd_rn(x0v, __fmul_rn(dxv, u) * 0.5f);
+            f32x4 a1[T1], delta2[BT];
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a1[t][r] = hidden_act_f(fmaf(w1x[t][r], tk, c[t][r]), slope);
+#pragma unroll
+            for (int t = 0; t < BT; ++t) delta2[t] = dnext[t];
+            if (k < n) {
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * t + r < nl2) dnext[t][r] = fa.d2[frag0 + ((size_t)(k + 1) * nl2 + 4 * t + r) * 64];
+            }
+            // ---- packed two-piece fragments: delta_2 as a BFrag (two K-steps), a_1 as KS1 K-steps
+            BFrag<NPB> bd;
+            split_regs<0, NPB>(delta2, bd);
+            u32x4 ba[KS1][NPB];
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                unsigned q0[NPB], q1[NPB], q2[NPB], q3[NPB];
+#pragma unroll
+                for (int k2 = 0; k2 < NPB; ++k2) q2[k2] = q3[k2] = 0u;
+                split_pair<NPB>(a1[2 * s][0], a1[2 * s][1], q0);
+                split_pair<NPB>(a1[2 * s][2], a1[2 * s][3], q1);
+                if (2 * s + 1 < T1) {
+                    split_pair<NPB>(a1[2 * s + 1][0], a1[2 * s + 1][1], q2);
+                    split_pair<NPB>(a1[2 * s + 1][2], a1[2 * s + 1][3], q3);
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < NPB; ++k2) ba[s][k2] = u32x4{q0[k2], q1[k2], q2[k2], q3[k2]};
+            }
+            // ---- dG1 += delta_2 (x) a_1 over the 16 points (operands transposed on the matrix core)
+            {
+                u32x2 dT[BT][NPB], aT[T1][NPB];
+                transpose_pieces(bd, sel, dT);
+#pragma unroll
+                for (int s = 0; s < KS1; ++s)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        if (2 * s + hh >= T1) continue;
+#pragma unroll
+                        for (int part = 0; part < NPB; ++part) {
+                            const f32x4 tr = mfma_bf16(ba[s][part], sel[hh], f32x4{0.f, 0.f, 0.f, 0.f});
+                            const bf16x2 lo = __builtin_convertvector(f32x2{tr[0], tr[1]}, bf16x2);
+                            const bf16x2 hi = __builtin_convertvector(f32x2{tr[2], tr[3]}, bf16x2);
+                            aT[2 * s + hh][part] = u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+                        }
+                    }
+#pragma unroll
+                for (int wa = 0; wa < NPB; ++wa)
+#pragma unroll
+                    for (int bb = 0; bb < NPB; ++bb) {
+                        if (wa + bb >= NPB) continue;
+#pragma unroll
+                        for (int to = 0; to < BT; ++to)
+#pragma unroll
+                            for (int ti = 0; ti < T1; ++ti) dG1[to][ti] = mfma_bf16_k16(dT[to][wa], aT[ti][bb], dG1[to][ti]);
+                    }
+            }
+            // ---- delta_1 = (G1^T delta_2) . act'(z_1)
+            f32x4 nd[T1];
+            {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < BKS; ++s) {
+#pragma unroll
+                    for (int t = 0; t < T1; ++t) {
+                        u32x4 wf[NPB];
+#pragma unroll
+                        for (int k2 = 0; k2 < NPB; ++k2)
+                            wf[k2] = *reinterpret_cast<const u32x4*>(frag_base + ((t * BKS + s) * NPB + k2) * FRAG);
+#pragma unroll
+                        for (int wa = 0; wa < NPB; ++wa)
+#pragma unroll
+                            for (int bb = 0; bb < NPB; ++bb) {
+                                if (wa + bb >= NPB) continue;
+                                const bool first = s == 0 && wa == 0 && bb == 0;
+                                nd[t] = mfma_bf16(wf[wa], bd.v[s][bb], first ? zero : nd[t]);
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dl = nd[t][r] * (a1[t][r] > 0.f ? 1.f : slope);
+                    dcs[t][r] += dl;
+                    dW1x[t][r] = fmaf(dl, tk, dW1x[t][r]);
+                }
+        }
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = feat_of(t, r, g);
+                    if (f < H1) a.dc[q * H1 + f] = dcs[t][r];
+                }
+        }
+    }
+    // ---- this wave's partial d_theta: G1 (weights + bias column) and the x-column of W1
+    float* part = a.partials + (size_t)wave_global * a.n_params;
+#pragma unroll
+    for (int to = 0; to < BT; ++to)
+#pragma unroll
+        for (int ti = 0; ti < T1; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int fo = 16 * to + 4 * g + r, fi = 16 * ti + (lane & 15);
+                if (fo < H2) {
+                    const int idx = fi < H1 ? a.poffW[1] + fo * H1 + fi : (fi == H1 ? a.poffb[1] + fo : -1);
+                    if (idx >= 0) part[idx] = (fa.accumulate ? part[idx] : 0.f) + dG1[to][ti][r];
+                }
+            }
+#pragma unroll
+    for (int t = 0; t < T1; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v1 = dW1x[t][r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) v1 += __shfl_xor(v1, o);
+            const int f = feat_of(t, r, g);
+            if (p == 0 && f < H1) {
+                const int idx = a.poffW[0] + f * (1 + E);
+                part[idx] = (fa.accumulate ? part[idx] : 0.f) + v1;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+typedef void (*front_kernel_t)(const FrontArgs);
+typedef void (*mid_kernel_t)(const BwdBf16Args);
+struct FrontVariant { int t1; front_kernel_t fwd, bwd; };
+static const FrontVariant kFrontVariants[] = {
+    {5, cc_front_fwd_kernel<5>, cc_front_bwd_kernel<5>}, {6, cc_front_fwd_kernel<6>, cc_front_bwd_kernel<6>},
+    {7, cc_front_fwd_kernel<7>, cc_front_bwd_kernel<7>}, {8, cc_front_fwd_kernel<8>, cc_front_bwd_kernel<8>},
+};
+struct MidVariant { int lh, nrl; mid_kernel_t fn; const char* name; };
+#define MID_VARIANT(LHH, NR) { LHH, NR, cc_bwd_bf16_kernel<LHH, true, NR, true>, "cc_bwd_bf16<L=" #LHH ",EDGE=1,LIVE=" #NR ",FRONT>" }
+static const MidVariant kMidVariants[] = { MID_VARIANT(4, 13), MID_VARIANT(3, 13), MID_VARIANT(2, 13),
+                                           MID_VARIANT(4, 0), MID_VARIANT(3, 0), MID_VARIANT(2, 0) };
+
+// Does this net belong to the family?  hidden layer 1: 5..8 tiles; hidden layers 2..L: three or four tiles at most (zero-padded
+// to four), 2..4 of them.
+int umnn_backward_front_shape(const MlpDev& m) {
+    const int L = m.n_linear - 1;
+    if (L < 3 || L > 5) return 0;
+    if (m.t_out[1] < 5 || m.t_out[1] > 8) return 0;
+    for (int l = 2; l <= L; ++l) if (m.t_out[l] > BT) return 0;
+    return 1;
+}
+
+// bytes of HBM scratch the staged backward wants for B*d integrals (nb_steps is not known when the workspace is sized: the
+// chunking adapts to whatever n the call brings)
+long long umnn_backward_front_scratch_bytes(const MlpDev& m, long long NI) {
+    const long long tiles = (NI + 15) / 16;
+    const long long nl2 = (m.width[2] + 1 + 3) / 4;
+    const long long per_tile = (2LL * 257 + 1) * nl2 * 64 * 4;          // sized for n = 256
+    const long long want = tiles * per_tile, cap = 1LL << 30;
+    return want < cap ? want : cap;
+}
+
+// Runs the three stages chunk by chunk.  `base` is the fully populated BwdArgs of umnn_cc_backward (partials zeroed).
+int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nblocks_max, void* scratch, long long scratch_bytes,
+                               hipStream_t stream) {
+    const MlpDev& m = base.m;
+    const int L = m.n_linear - 1, n = base.n;
+    if (!umnn_backward_front_shape(m)) return UMNN_EUNSUPPORTED;
+    const int T1 = m.t_out[1], LH = L - 1;
+    const int nl2 = (m.width[2] + 1 + 3) / 4;
+    const FrontVariant* fv = nullptr;
+    for (const FrontVariant& v : kFrontVariants) if (v.t1 == T1) fv = &v;
+    int nrl = m.ks_in[2];
+    for (int l = 2; l <= L; ++l) if (m.ks_in[l] != nrl) nrl = 0;
+    if (nrl != 13) nrl = 0;
+    const MidVariant* mv = nullptr;
+    for (const MidVariant& v : kMidVariants) if (v.lh == LH && v.nrl == nrl) { mv = &v; break; }
+    if (!fv || !mv) return UMNN_EUNSUPPORTED;
+
+    const long long tiles = (base.NI + 15) / 16;
+    const long long per_tile = (2LL * (n + 1) + (base.gfx ? 1 : 0)) * nl2 * 64 * 4;
+    long long chunk = scratch_bytes / per_tile;
+    if (chunk < 1 || !scratch) return UMNN_EUNSUPPORTED;
+    if (chunk > tiles) chunk = tiles;
+
+    // ---- the middle stage sees the net from hidden layer 2 on
+    BwdBf16Args mid;
+    mid.b = base;
+    {
+        MlpDev& s = mid.b.m;
+        s.n_linear = m.n_linear - 1;
+        for (int l = 0; l <= s.n_linear; ++l) s.width[l] = m.width[l + 1];
+        for (int l = 0; l < s.n_linear; ++l) { s.W[l] = m.W[l + 1]; s.b[l] = m.b[l + 1]; }
+        for (int l = 1; l <= s.n_linear - 1; ++l) { s.t_out[l] = m.t_out[l + 1]; s.ks_in[l] = m.ks_in[l + 1]; s.t_mfma[l] = m.t_mfma[l + 1]; }
+        for (int l = 0; l < s.n_linear; ++l) { mid.b.poffW[l] = base.poffW[l + 1]; mid.b.poffb[l] = base.poffb[l + 1]; }
+    }
+    int off16 = 0;
+    for (int l = 1; l < LH; ++l) { mid.off_fwd[l] = off16; off16 += BT * BKS * NPF * FRAG; }
+    for (int l = 1; l < LH; ++l) { mid.off_tr[l] = off16; off16 += BT * BKS * NPB * FRAG; }
+    const size_t lds_mid = (size_t)off16 * sizeof(unsigned short);
+    const size_t lds_a = ((size_t)BT * (T1 / 2) * NPF * FRAG + (T1 & 1 ? BT * NPF * 256 : 0)) * sizeof(unsigned short);
+    const size_t lds_c = (size_t)T1 * BKS * NPB * FRAG * sizeof(unsigned short);
+    if (lds_mid > 160 * 1024 || lds_a > 160 * 1024 || lds_c > 160 * 1024) return UMNN_EUNSUPPORTED;
+    if (int rc = umnn_allow_lds((const void*)fv->fwd, lds_a)) return rc;
+    if (int rc = umnn_allow_lds((const void*)mv->fn, lds_mid)) return rc;
+    if (int rc = umnn_allow_lds((const void*)fv->bwd, lds_c)) return rc;
+
+    FrontArgs fa;
+    fa.b = base;
+    fa.b.ns = 1;
+    mid.b.ns = 1;
+    mid.b.l_lo = 1;
+    fa.nl2 = mid.nl2 = nl2;
+    umnn_prof_begin(stream);
+    for (long long t0 = 0; t0 < tiles; t0 += chunk) {
+        const long long nt = tiles - t0 < chunk ? tiles - t0 : chunk;
+        float* z2 = (float*)scratch;
+        float* d2 = z2 + (size_t)nt * (n + 1) * nl2 * 64;
+        float* tz2 = base.gfx ? d2 + (size_t)nt * (n + 1) * nl2 * 64 : nullptr;
+        int nblocks = nblocks_max;
+        if ((long long)nblocks * UMNN_WAVES_PER_BLOCK > nt) nblocks = (int)((nt + UMNN_WAVES_PER_BLOCK - 1) / UMNN_WAVES_PER_BLOCK);
+        if (nblocks < 1) nblocks = 1;
+        fa.z2 = z2; fa.d2 = d2; fa.tz2 = tz2; fa.grp0 = (unsigned)t0; fa.b.ngroups = (unsigned)nt; fa.accumulate = t0 > 0;
+        mid.z2 = z2; mid.d2 = d2; mid.tz2 = tz2; mid.grp0 = (unsigned)t0; mid.b.ngroups = (unsigned)nt; mid.accumulate = t0 > 0;
+        hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
+        hipLaunchKernelGGL(mv->fn, dim3(nblocks), dim3(UMNN_BLOCK), lds_mid, stream, mid);
+        hipLaunchKernelGGL(fv->bwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_c, stream, fa);
+    }
+    umnn_prof_end(stream, 3.0 * umnn_cc_forward_flops_per_integral(net, n) * (double)base.NI, UMNN_PROF_BACKWARD);
+    umnn_note_launch(mv->name);
+    return umnn_check(hipGetLastError(), "cc_bwd front launch");
+}

@@ -34,3 +34,9 @@ struct BwdArgs {
 // permutation that turns an accumulator row (lane&15 in an A operand) into a feature offset inside a tile
 __device__ __forceinline__ int perm16(int rho) { return 4 * (rho & 3) + (rho >> 2); }
 
+
+// staged backward for nets with a wide first hidden layer (cc_backward_front.hip)
+int umnn_backward_front_shape(const MlpDev& m);
+long long umnn_backward_front_scratch_bytes(const MlpDev& m, long long NI);
+int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nblocks_max, void* scratch, long long scratch_bytes,
+                               hipStream_t stream);

@@ -121,13 +121,14 @@ _bwd_kind = {}
 
 
 def _hip_backward_ok(spec, x, h):
-    """False for nets the HIP backward only covers with its register-spilling generic wide variants (mixed hidden
-    widths above 63, e.g. MNISTExperiment's 100-50-50-50-50: 687 ms per call at 256x784 against ~40 ms for the
-    materialised ATen chain on the same GPU).  ``UMNN_BWD_WIDE=hip`` forces the HIP kernels anyway."""
+    """False for nets the HIP backward only covers with its register-spilling generic wide variants (several hidden
+    layers above 63 units of unequal width: 687 ms per call at 256x784 against ~190 ms for the materialised ATen chain on
+    the same GPU).  Nets with a wide FIRST hidden layer and a narrow rest (MNISTExperiment's 100-50-50-50-50) have the
+    three-stage kernels of cc_backward_front.hip.  ``UMNN_BWD_WIDE=hip`` forces the HIP kernels anyway."""
     if os.environ.get("UMNN_BWD_WIDE", "") == "hip":
         return True
     E = h.shape[1] // x.shape[1]
-    key = (tuple((m.in_features, m.out_features) for m in spec.linears), E)
+    key = (tuple((m.in_features, m.out_features) for m in spec.linears), E, _lib.get_option("bwd_precision"))
     kind = _bwd_kind.get(key)
     if kind is None:
         desc, keep = _desc(spec)
