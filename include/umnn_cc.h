@@ -195,9 +195,12 @@ int umnn_get_forward_precision(void);
 /* Same for the backward kernels: UMNN_PRECISION_FP32 or UMNN_PRECISION_BF16X3 (default; env UMNN_BWD_PRECISION =
  * fp32 | bf16x3).  The bf16 kernels cover nets with 2..4 hidden layers, each 32..63 wide (narrower layers of
  * such a net are zero-padded to four 16-feature tiles); other shapes always run the fp32 kernels. */
-/* Which kernel family umnn_cc_backward would run for this net: 1 shape-exact kernels, 0 generic kernels with at most four
- * 16-feature tiles per layer, -1 generic kernels with more tiles (mixed widths above 63: they spill registers and are
- * ~100x slower -- the shipped host code sends such nets to the materialised ATen chain on the GPU), < -1 error. */
+/* Which kernel family umnn_cc_backward would run for this net: 1 shape-exact kernels (one pass; or, for a first hidden layer
+ * of 5..8 sixteen-feature tiles over 2..4 narrower ones such as MNISTExperiment's 100-50-50-50-50, the three-stage kernels
+ * of cc_backward_front.hip, bf16x3 arithmetic only), 0 generic kernels with at most four tiles per layer, -1 generic kernels
+ * with more tiles (several unequal layers above 63 units: they spill registers and are ~100x slower -- the shipped host code
+ * sends such nets to the materialised ATen chain on the GPU), < -1 error.  The staged family takes its HBM scratch from the
+ * workspace (umnn_cc_backward_workspace_bytes includes up to 1 GiB for it). */
 int umnn_cc_backward_kind(const umnn_mlp* net, int E);
 int umnn_set_backward_precision(int mode);
 int umnn_get_backward_precision(void);

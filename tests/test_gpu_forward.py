@@ -600,7 +600,11 @@ def test_mnist_width_d784_against_oracle(dev):
     Fa = I.ParallelNeuralIntegral.apply(torch.zeros_like(xr), xr, net, I._flatten(net.parameters()), hr, n)
     Fa.backward(g.to(dev))
     ref = O.integrate_backward(onet, x0, x.numpy(), h.numpy(), n, g.numpy())
-    assert U.scaled_err(hr.grad.cpu().numpy(), ref[2]) < TOL
+    # 120 000 quadrature points x 300 hidden units: some pre-activation always sits inside the rounding noise of its own dot
+    # product (kink margin 8e-10 here; the fp32 and fp64 ORACLES differ by 8.4e-5 on d_h for this very case), and d_h of one
+    # (row, dimension) hangs on that unit's sign -- the kink-ambiguity rule of the random-shape sweep applies
+    tol_g = TOL if U.kink_margin(onet, x0, x.numpy(), h.numpy(), n) > 5e-7 else 5e-4
+    assert U.scaled_err(hr.grad.cpu().numpy(), ref[2]) < tol_g
     dth = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
     assert U.scaled_err(dth, ref[5]) < TOL
 
