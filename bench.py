@@ -281,7 +281,7 @@ def main():
               "pci_bus_id": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None),
               "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}]
     if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         gathered = [None] * world

@@ -39,13 +39,13 @@ def _oracle_blocks(model, cfg):
 
 
 def _sample_rows(B, k=32, seed=5):
-    rows = np.sort(np.random.RandomState(seed).choice(B, k, replace=False))
+    rows = np.sort(np.random.RandomState(seed).choice(B, min(k, B), replace=False))
     rows[0], rows[-1] = 0, B - 1                       # first and last row: tile / shard edges
     return rows
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
-@pytest.mark.parametrize("workload", ["bsds300", "power", "toy", "vae"])
+@pytest.mark.parametrize("workload", ["bsds300", "power", "toy", "vae", "mnist"])
 def test_benchmarked_model_matches_oracle_at_full_batch(workload, precision, dev):
     import umnn_amd
     from umnn_amd import _lib
@@ -67,7 +67,7 @@ def test_benchmarked_model_matches_oracle_at_full_batch(workload, precision, dev
         assert ("bf16" in kname) == (precision != "fp32"), kname
     finally:
         umnn_amd.set_precision(old)
-    rows = _sample_rows(cfg["rows"])
+    rows = _sample_rows(cfg["rows"], 8 if cfg["d"] > 128 else 32)       # (d = 784: 8 rows keep the oracle to seconds)
     xs = x[rows].cpu().numpy()
     cs = ctx[rows].cpu().numpy() if ctx is not None else None
     blocks = _oracle_blocks(model, cfg)
@@ -204,3 +204,29 @@ def test_block_level_compute_ll_and_bis_on_the_hip_path(dev):
         llb, zf = m.compute_ll_bis(torch.from_numpy(G["x"]).to(dev))
     assert U.rel_err(zf.cpu().numpy(), z_full_ref) < TOL
     assert U.rel_err(llb.sum(1).cpu().numpy(), ll_full_ref) < TOL
+
+
+def test_bench_two_ranks_on_one_gpu_smoke(dev, tmp_path):
+    """bench.py's N>1 launch path (torch.distributed.run, barrier + max-over-ranks timing, rank gathering, one JSON line on
+    rank 0) on the single GPU of this box: two ranks share cuda:0 over gloo (RCCL refuses two ranks on one device; the
+    8-GPU run uses the same code with backend nccl).  value must be about twice the per-rank rate of the same run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UMNN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "power", "--rows", "2000"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["dist"]["backend"] == "gloo"
+    assert {rk["rank"] for rk in line["ranks"]} == {0, 1}
+    assert line["value"] > 0 and line["scaling"] == "weak" and "cpu_baseline" not in line
+    for mode in ("train",):
+        r = subprocess.run(cmd + ["--mode", mode], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["metric"] == "umnn_maf_training_samples_per_s"

@@ -15,13 +15,16 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available()
-    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    # one rank per GPU; more ranks than GPUs (a 2-rank smoke test of the launch path on a 1-GPU box) wrap around, which
+    # only the gloo backend accepts -- RCCL refuses two ranks on one device
+    device = torch.device("cuda", local % torch.cuda.device_count()) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world,
-                                **({"device_id": device} if use_gpu else {}))
+        backend = backend or os.environ.get("UMNN_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                **({"device_id": device} if use_gpu and backend == "nccl" else {}))
     return rank, world, device
 
 
@@ -35,6 +38,17 @@ def shard_bounds(n_rows, rank, world):
 def shard_rows(t, rank, world):
     lo, hi = shard_bounds(t.shape[0], rank, world)
     return t[lo:hi]
+
+
+def _all_reduce_sum(flat):
+    """all_reduce(SUM) in place; device tensors under the gloo backend (the 2-ranks-on-one-GPU smoke test) are staged through
+    the host, RCCL reduces them where they are."""
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        c = flat.cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        flat.copy_(c)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
 
 def allreduce_gradients(module, world=None, average=True):
@@ -51,7 +65,7 @@ def allreduce_gradients(module, world=None, average=True):
             p.grad = torch.zeros_like(p)
     grads = [p.grad for p in params]
     flat = torch._utils._flatten_dense_tensors(grads)           # one message (a few MB: latency-bound on xGMI)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    _all_reduce_sum(flat)
     if average:
         flat /= world
     # the gradients become views into the reduced flat buffer: no second pass of per-parameter copies
@@ -66,5 +80,11 @@ def broadcast_parameters(module, src=0):
     from .made import invalidate_caches
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.detach(), src)      # detach() shares the version counter: the in-place receive bumps it
+            v = t.detach()                       # detach() shares the version counter: the in-place receive bumps it
+            if v.is_cuda and dist.get_backend() == "gloo":       # (gloo builds without device support: stage through the host)
+                c = v.cpu()
+                dist.broadcast(c, src)
+                v.copy_(c)
+            else:
+                dist.broadcast(v, src)
     invalidate_caches(module)                    # belt and braces for the conditioner's masked / packed weight caches
