@@ -593,6 +593,10 @@ def test_mnist_width_d784_against_oracle(dev):
     spec = mlp_spec(net)
     x, h, g = torch.randn(B, d), torch.randn(B, E * d), torch.randn(B, d)
     F, fx, _ = I.hip_forward(spec, None, x.to(dev), h.to(dev), n)
+    import umnn_amd
+    from umnn_amd import _lib
+    if umnn_amd.get_forward_precision() == "bf16x3":      # the shape-exact wide-first-layer family, not the guarded T=8 one
+        assert "T1=7,TREST=4" in _lib.lib().umnn_last_kernel_name().decode()
     x0 = np.zeros((B, d), np.float32)
     assert U.rel_err(F.cpu().numpy(), O.integrate_parallel(onet, x0, x.numpy(), h.numpy(), n)) < TOL
     assert U.rel_err(fx.cpu().numpy(), O.integrand(onet, x.numpy(), h.numpy())) < TOL

@@ -5,6 +5,11 @@
 // ------------------------------------------------------------------------------------------
 typedef void (*fwd_bf16_kernel_t)(const FwdBf16Args);
 struct Bf16Variant { int tmax, nparts, p, exact, nrl, pipe; fwd_bf16_kernel_t fn; const char* name; };
+// first hidden layer T1 = 5..8 tiles, every other hidden layer at most four (zero-padded to four): MNISTExperiment's
+// 31-100-50-50-50-50-1.  Shape-exact: layer 1's GEMM contracts over T1 tiles, the others over four.
+struct Bf16WideFirst { int t1; fwd_bf16_kernel_t fn; const char* name; };
+#define BF16_WIDE_FIRST(T) { T, cc_fwd_bf16_kernel<T, 2, 1, true, 0, false, false, 4>, "cc_fwd_bf16<T1=" #T ",TREST=4,PARTS=2,P=1,EXACT=1>" }
+static const Bf16WideFirst kBf16WideFirst[] = { BF16_WIDE_FIRST(5), BF16_WIDE_FIRST(6), BF16_WIDE_FIRST(7), BF16_WIDE_FIRST(8) };
 #define BF16_VARIANT(T, NP, PP, EX, NR) { T, NP, PP, EX, NR, 0, cc_fwd_bf16_kernel<T, NP, PP, (EX) != 0, NR>, "cc_fwd_bf16<T=" #T ",PARTS=" #NP ",P=" #PP ",EXACT=" #EX ",LIVE=" #NR ">" }
 #define BF16_PIPE_VARIANT(NP, PP, NR) { 4, NP, PP, 1, NR, 1, cc_fwd_bf16_kernel<4, NP, PP, true, NR, true>, "cc_fwd_bf16<T=4,PARTS=" #NP ",P=" #PP ",EXACT=1,LIVE=" #NR ",PIPE>" }
 static const Bf16Variant kBf16Variants[] = {
@@ -40,6 +45,46 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
     }
     FwdBf16Args args;
     args.f = a;
+    // ---- wide first hidden layer over a narrow rest: its own shape-exact family
+    {
+        bool wf = nparts == 2 && L >= 2 && a.m.t_out[1] >= 5 && a.m.t_out[1] <= 8 && (P == 1 || !p_forced);
+        for (int l = 2; l <= L && wf; ++l) if (a.m.t_out[l] > 4) wf = false;
+        if (wf) {
+            const int T1 = a.m.t_out[1];
+            int o16 = 0;
+            for (int l = 1; l <= L; ++l) {
+                args.pl.ks32[l] = l == 1 ? T1 / 2 : 2;
+                args.pl.half_in[l] = l == 1 ? (T1 & 1) : 0;
+                if (l >= 2) args.f.m.t_out[l] = 4;
+            }
+            for (int l = 1; l < L; ++l) {
+                args.pl.off16[l] = o16;
+                o16 += 4 * (args.pl.ks32[l] * 2 * 512 + args.pl.half_in[l] * 2 * 256);
+            }
+            args.f.m.lds_off[L] = (((o16 + 1) / 2) + 3) & ~3;
+            if (!ns_forced) {
+                const long long tiles16 = (a.NI + 15) / 16, slots = (long long)umnn_num_cus() * 4 * 2;
+                ns = tiles16 * 4 <= slots ? 4 : tiles16 * 2 <= slots ? 2 : 1;
+                if (ns > nb_steps + 1) ns = 1;
+            }
+            const size_t lds_bytes = ((size_t)args.f.m.lds_off[L] + (ns > 1 ? UMNN_WAVES_PER_BLOCK * 3 * 16 : 0)) * sizeof(float);
+            const Bf16WideFirst* pick = nullptr;
+            for (const Bf16WideFirst& v : kBf16WideFirst) if (v.t1 == T1) pick = &v;
+            if (pick && lds_bytes <= 160 * 1024) {
+                if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
+                args.f.ns = ns;
+                args.f.ngroups = (unsigned)((a.NI + 15) / 16);
+                const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
+                const unsigned nblk = (args.f.ngroups + gpb - 1) / gpb;
+                umnn_prof_begin(stream);
+                hipLaunchKernelGGL(pick->fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
+                umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * (double)a.NI);
+                umnn_note_launch(pick->name);
+                return umnn_check(hipGetLastError(), "cc_fwd_bf16 launch");
+            }
+            args.f = a;         // (not launched: fall through to the generic plan)
+        }
+    }
     int off16 = 0;
     for (int l = 1; l <= L; ++l) {
         args.pl.half_in[l] = wide ? (wide & 1) : 0;

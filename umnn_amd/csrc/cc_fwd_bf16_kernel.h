@@ -122,8 +122,9 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
 // to start with, `iter` rounds, the new bracket is the pair of candidates around the one whose image is closest to the
 // target); every round integrates all ten candidates with the node loop below, the search itself is a 16-lane butterfly.
 // The hoisted first-layer term depends on the sample only and is computed once for all rounds.
-template <int TMAX, int NPARTS, int P, bool EXACT, int NRL, bool PIPE = false, bool INV = false>
+template <int TMAX, int NPARTS, int P, bool EXACT, int NRL, bool PIPE = false, bool INV = false, int TREST = 0>
 __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Args args) {
+    static_assert(TREST == 0 || (EXACT && !PIPE && TREST < TMAX && (TREST & 1) == 0), "wide-first-layer variants: exact, plain loop");
     static_assert(!INV || (P == 1 && !PIPE), "inversion variants: plain loop, one tile per wave");
     constexpr int KSM = TMAX / 2;
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * TMAX;
@@ -415,15 +416,22 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                         act[pt][t][r] = 4 * t + r < NLIVE ? hidden_act_f(fmaf(w1x[t][r], tk, c[pt][t][r]), slope) : 0.f;
             }
 
-            for (int l = 1; l < L; ++l) {
-                const int ks = EXACT ? KSM : args.pl.ks32[l], to = EXACT ? TMAX : m.t_out[l + 1];
+            auto layer = [&](auto wide_c, int l) {
+                // TREST > 0 (first hidden layer wider than the others, e.g. 100-50-50-50-50): layer 1 contracts over TMAX tiles, every
+                // later layer over TREST; every layer produces TREST output tiles.  Compile-time per instantiation of this lambda.
+                constexpr bool WIDE = decltype(wide_c)::value;
+                constexpr int KT = (TREST > 0 && !WIDE) ? TREST : TMAX;
+                constexpr int OT = TREST > 0 ? TREST : TMAX;
+                constexpr int KSL = KT / 2;
+                constexpr bool HALFL = EXACT && (KT & 1);
+                const int ks = EXACT ? KSL : args.pl.ks32[l], to = EXACT ? OT : m.t_out[l + 1];
                 const unsigned short* img = lds16 + args.pl.off16[l] + lane * 8;
                 // split + pack the activations into B fragments: K-step s <- tiles 2s, 2s+1
-                u32x4 bf[P][KSM][NPARTS];
+                u32x4 bf[P][KSL > 0 ? KSL : 1][NPARTS];
 #pragma unroll
                 for (int pt = 0; pt < P; ++pt)
 #pragma unroll
-                    for (int s = 0; s < KSM; ++s) {
+                    for (int s = 0; s < KSL; ++s) {
                         unsigned q0[NPARTS], q1[NPARTS], q2[NPARTS], q3[NPARTS];
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) q0[k2] = q1[k2] = q2[k2] = q3[k2] = 0u;
@@ -436,14 +444,14 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     }
                 // odd tile count (EXACT only): the last tile is a K = 16 step of its own
                 u32x2 hb[P][NPARTS];
-                if constexpr (EXACT && (TMAX & 1)) {
+                if constexpr (HALFL) {
 #pragma unroll
                     for (int pt = 0; pt < P; ++pt) {
                         unsigned q0[NPARTS], q1[NPARTS];
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) q0[k2] = q1[k2] = 0u;
-                        if (4 * (TMAX - 1) + 0 < NLIVE) split_pair<NPARTS>(act[pt][TMAX - 1][0], act[pt][TMAX - 1][1], q0);
-                        if (4 * (TMAX - 1) + 2 < NLIVE) split_pair<NPARTS>(act[pt][TMAX - 1][2], act[pt][TMAX - 1][3], q1);
+                        if (4 * (KT - 1) + 0 < NLIVE) split_pair<NPARTS>(act[pt][KT - 1][0], act[pt][KT - 1][1], q0);
+                        if (4 * (KT - 1) + 2 < NLIVE) split_pair<NPARTS>(act[pt][KT - 1][2], act[pt][KT - 1][3], q1);
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) hb[pt][k2] = u32x2{q0[k2], q1[k2]};
                     }
@@ -454,11 +462,11 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
 #pragma unroll
                     for (int t = 0; t < TMAX; ++t) acc[pt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < KSM; ++s) {
+                for (int s = 0; s < KSL; ++s) {
                     if (EXACT || s < ks) {
                         u32x4 wf[TMAX][NPARTS];
 #pragma unroll
-                        for (int t = 0; t < TMAX; ++t)
+                        for (int t = 0; t < OT; ++t)
                             if (EXACT || t < to) {
 #pragma unroll
                                 for (int k2 = 0; k2 < NPARTS; ++k2)
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                             for (int ba = 0; ba < NPARTS; ++ba) {
                                 if (wa + ba >= NPARTS) continue;      // 2 parts: hh,hl,lh ; 3 parts: + h l2, l2 h, l l
 #pragma unroll
-                                for (int t = 0; t < TMAX; ++t)
+                                for (int t = 0; t < OT; ++t)
                                     if (EXACT || t < to) {
 #pragma unroll
                                         for (int pt = 0; pt < P; ++pt)
@@ -480,11 +488,11 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                             }
                     }
                 }
-                if constexpr (EXACT && (TMAX & 1)) {
-                    const unsigned short* himg = lds16 + args.pl.off16[l] + TMAX * KSM * NPARTS * 512 + lane * 4;
+                if constexpr (HALFL) {
+                    const unsigned short* himg = lds16 + args.pl.off16[l] + OT * KSL * NPARTS * 512 + lane * 4;
                     u32x2 wh[TMAX][NPARTS];
 #pragma unroll
-                    for (int t = 0; t < TMAX; ++t)
+                    for (int t = 0; t < OT; ++t)
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2)
                             wh[t][k2] = *reinterpret_cast<const u32x2*>(himg + (t * NPARTS + k2) * 256);
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                         for (int ba = 0; ba < NPARTS; ++ba) {
                             if (wa + ba >= NPARTS) continue;
 #pragma unroll
-                            for (int t = 0; t < TMAX; ++t)
+                            for (int t = 0; t < OT; ++t)
 #pragma unroll
                                 for (int pt = 0; pt < P; ++pt)
                                     acc[pt][t] = mfma_bf16_k16(wh[t][wa], hb[pt][ba], acc[pt][t]);
@@ -506,7 +514,13 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     for (int t = 0; t < TMAX; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            act[pt][t][r] = ((EXACT || t < to) && 4 * t + r < NLIVE) ? hidden_act_f(acc[pt][t][r], slope) : 0.f;
+                            act[pt][t][r] = (t < OT && (EXACT || t < to) && 4 * t + r < NLIVE) ? hidden_act_f(acc[pt][t][r], slope) : 0.f;
+            };
+            if constexpr (TREST > 0) {
+                layer(std::true_type{}, 1);
+                for (int l = 2; l < L; ++l) layer(std::false_type{}, l);
+            } else {
+                for (int l = 1; l < L; ++l) layer(std::true_type{}, l);
             }
 
 #pragma unroll
