@@ -200,7 +200,7 @@ int umnn_get_forward_precision(void);
  * of cc_backward_front.hip, bf16x3 arithmetic only), 0 generic kernels with at most four tiles per layer, -1 generic kernels
  * with more tiles (several unequal layers above 63 units: they spill registers and are ~100x slower -- the shipped host code
  * sends such nets to the materialised ATen chain on the GPU), < -1 error.  The staged family takes its HBM scratch from the
- * workspace (umnn_cc_backward_workspace_bytes includes up to 1 GiB for it). */
+ * workspace (umnn_cc_backward_workspace_bytes includes up to 2 GiB for it). */
 int umnn_cc_backward_kind(const umnn_mlp* net, int E);
 int umnn_set_backward_precision(int mode);
 int umnn_get_backward_precision(void);

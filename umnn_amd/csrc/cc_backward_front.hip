@@ -20,7 +20,7 @@
 //                            kernels do; the usual finishing kernels (d_h, dW1[:,1:], d_theta reduction) follow.
 //
 // Scratch: 2 x (n+1) x ceil((H2+1)/4) x 256 B per tile (339 KB at n = 50); tiles are processed in chunks that fit the
-// scratch the workspace provides (1 GiB), every wave's d_theta slice accumulating across chunks.  HBM traffic per
+// scratch the workspace provides (2 GiB), every wave's d_theta slice accumulating across chunks.  HBM traffic per
 // tile-node 4 x 3.3 KB against ~5 us of matrix work: three orders of magnitude below the bandwidth roof.
 #include "cc_bwd_bf16_kernel.h"
 
@@ -479,7 +479,7 @@ long long umnn_backward_front_scratch_bytes(const MlpDev& m, long long NI) {
     const long long tiles = (NI + 15) / 16;
     const long long nl2 = (m.width[2] + 1 + 3) / 4;
     const long long per_tile = (2LL * 257 + 1) * nl2 * 64 * 4;          // sized for n = 256
-    const long long want = tiles * per_tile, cap = 1LL << 30;
+    const long long want = tiles * per_tile, cap = 2LL << 30;
     return want < cap ? want : cap;
 }
 
@@ -505,6 +505,14 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
     long long chunk = scratch_bytes / per_tile;
     if (chunk < 1 || !scratch) return UMNN_EUNSUPPORTED;
     if (chunk > tiles) chunk = tiles;
+    else {
+        // several chunks: equal shares, rounded up to whole rounds of the persistent grid where the scratch allows (a chunk
+        // of 3.06 rounds costs 4)
+        const long long nchunks = (tiles + chunk - 1) / chunk, waves = (long long)nblocks_max * UMNN_WAVES_PER_BLOCK;
+        long long even = (tiles + nchunks - 1) / nchunks;
+        const long long rounded = (even + waves - 1) / waves * waves;
+        chunk = rounded <= chunk ? rounded : even;
+    }
 
     // ---- the middle stage sees the net from hidden layer 2 on
     BwdBf16Args mid;
