@@ -36,6 +36,8 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
     int off16 = 0;
     for (int l = 1; l < L; ++l) { args.off_fwd[l] = off16; off16 += BT * BKS * NPF * FRAG; }
     for (int l = 1; l < L; ++l) { args.off_tr[l] = off16; off16 += BT * BKS * NPB * FRAG; }
+    args.off_trtile = off16;
+    off16 += UMNN_WAVES_PER_BLOCK * NPB * 16 * TRS;
     const size_t lds_bytes = (size_t)off16 * sizeof(unsigned short);
     if (lds_bytes > 160 * 1024) return UMNN_EUNSUPPORTED;
     a.ngroups = (unsigned)((a.NI + 15) / 16);

@@ -40,6 +40,7 @@ struct BwdBf16Args {
     unsigned grp0;                   // first tile of the chunk (HBM fragments are indexed by grp - grp0)
     int nl2;                         // live registers of that layer: ceil((H2 + 1) / 4)
     int accumulate;                  // d_theta slices: 0 overwrite (first chunk), 1 add
+    int off_trtile;                  // ushort offset in LDS of the per-wave transpose tiles (one-pass kernels)
 };
 
 // fragment (tile t, K-step s, piece) of W (TRANSPOSED = false: rows = out features, K = in features incl. the
@@ -149,6 +150,36 @@ __device__ __forceinline__ void transpose_pieces(const BFrag<NPB>& x, const u32x
             }
 }
 
+// The same transposition through a wave-private LDS tile and the transposing LDS read of gfx950 (ds_read_b64_tr_b16):
+// every lane stores its packed k-slots as they are -- Mem[piece][point p][slot g*16 + s*8 + j], two 16-byte stores per piece --
+// and reads back, for "slot tile" tau, the 4 bf16 at Mem[piece][point 4g + (p>>2)][16 tau + 4 (p&3) ..]; the instruction
+// hands lane (g, n) element j = Mem[point 4g + j][16 tau + n]: slot 16 tau + n on lane n, points 4g..4g+3 in the k-slots
+// of a 16x16x16 operand.  (Semantics probed in tools/ubench/trread.hip.)  Rows / columns of the dW tiles then run over
+// SLOTS, slot sigma <-> feature 16 (2 s + (j>>2)) + 4 (j&3) + G with G = sigma>>4, s = (sigma>>3)&1, j = sigma&7: a
+// permutation that only the final write-out of the accumulators has to know (slot_feature).  No MFMA, no v_cvt_pk.
+constexpr int TRS = 72;          // ushorts per point row of the tile: 64 slots + 8 padding (144 B: 16-byte aligned rows)
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int slot_feature(int sigma) {
+    const int G = sigma >> 4, ss = (sigma >> 3) & 1, j = sigma & 7;
+    return 16 * (2 * ss + (j >> 2)) + 4 * (j & 3) + G;
+}
+__device__ __forceinline__ void transpose_pieces_lds(const BFrag<NPB>& x, unsigned short* tile, int g, int p,
+                                                     u32x2 (&out)[BT][NPB]) {
+#pragma unroll
+    for (int part = 0; part < NPB; ++part)
+#pragma unroll
+        for (int s = 0; s < BKS; ++s)
+            *reinterpret_cast<u32x4*>(tile + (part * 16 + p) * TRS + g * 16 + s * 8) = x.v[s][part];
+#pragma unroll
+    for (int tau = 0; tau < BT; ++tau)
+#pragma unroll
+        for (int part = 0; part < NPB; ++part) {
+            const unsigned short* src = tile + (part * 16 + 4 * g + (p >> 2)) * TRS + 16 * tau + 4 * (p & 3);
+            const s16x4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4v __attribute__((address_space(3)))*)(src));
+            out[tau][part] = __builtin_bit_cast(u32x2, v);
+        }
+}
+
 // LH = number of hidden layers (compile-time: the layer loops are unrolled so that every register array is
 // statically indexed); NACC = LH - 1 hidden->hidden layers, all accumulated in this one pass (l_lo = 1).
 template <int LH, bool EDGE, int NRL, bool FRONT = false>
@@ -174,6 +205,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
     }
     __syncthreads();
     const unsigned short* frag_base = lds16 + lane * 8;
+    constexpr bool TRL = !FRONT;                       // dW operands transposed through LDS (one-pass kernels)
+    unsigned short* tr_tile = lds16 + args.off_trtile + wid * (NPB * 16 * TRS);
 
     // selection fragments of the matrix-core transpose: lane (g, n) sets k-slot 4h + (n>>2) to 1.0 iff (n&3) == g
     u32x4 sel[2];
@@ -385,8 +418,13 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
                 split_regs<NRL, NPB>(delta, bd);
                 {
                     u32x2 dT[BT][NPB], aT[BT][NPB];
-                    transpose_pieces(bd, sel, dT);
-                    transpose_pieces(asave[l - 1], sel, aT);
+                    if constexpr (TRL) {
+                        transpose_pieces_lds(bd, tr_tile, g, p, dT);
+                        transpose_pieces_lds(asave[l - 1], tr_tile, g, p, aT);
+                    } else {
+                        transpose_pieces(bd, sel, dT);
+                        transpose_pieces(asave[l - 1], sel, aT);
+                    }
 #pragma unroll
                     for (int wa = 0; wa < NPB; ++wa)
 #pragma unroll
@@ -455,7 +493,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
                 for (int ti = 0; ti < BT; ++ti)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int fo = 16 * to + 4 * g + r, fi = 16 * ti + (lane & 15);
+                        const int fo = TRL ? slot_feature(16 * to + 4 * g + r) : 16 * to + 4 * g + r;
+                        const int fi = TRL ? slot_feature(16 * ti + (lane & 15)) : 16 * ti + (lane & 15);
                         if (fo < Hout) {
                             const int idx = fi < Hin ? a.poffW[l] + fo * Hin + fi : (fi == Hin ? a.poffb[l] + fo : -1);
                             if (idx >= 0) part[idx] = (FRONT && args.accumulate ? part[idx] : 0.f) + dW[j][to][ti][r];
