@@ -414,13 +414,15 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
                 }
 #pragma unroll
             for (int l = L - 1; l >= 1; --l) {
+                u32x2 dT[BT][NPB], aT[BT][NPB];
+                // (LDS route: a_l has been ready since the forward pass -- its round trip is issued first, so that it runs
+                // under the VALU work that packs delta)
+                if constexpr (TRL) transpose_pieces_lds(asave[l - 1], tr_tile, g, p, aT);
                 BFrag<NPB> bd;
                 split_regs<NRL, NPB>(delta, bd);
                 {
-                    u32x2 dT[BT][NPB], aT[BT][NPB];
                     if constexpr (TRL) {
                         transpose_pieces_lds(bd, tr_tile, g, p, dT);
-                        transpose_pieces_lds(asave[l - 1], tr_tile, g, p, aT);
                     } else {
                         transpose_pieces(bd, sel, dT);
                         transpose_pieces(asave[l - 1], sel, aT);
