@@ -84,7 +84,8 @@ report, lines = {}, [f"# Roofline report (rocprofv3, round {RND[1:]}) -- kernels
                      "the CSV / JSON summaries it read are the `bench_<tag>_*` files next to this report.", ""]
 for tag, title in (("bsds300", "C3 BSDS300-shaped eval (8192 x 63 integrals per launch, n=100, 31-50^4-1)"),
                    ("power", "C2 POWER-shaped eval (10000 x 6 integrals per launch)"),
-                   ("bsds300_train", "C3 training step (forward + HIP backward + Adam)")):
+                   ("bsds300_train", "C3 training step (forward + HIP backward + Adam)"),
+                   ("mnist_train", "MNISTExperiment-shaped training step (d=784, 31-100-50-50-50-50-1, batch 100; three-stage backward)")):
     got = load(tag)
     if got is None:
         continue
@@ -102,9 +103,19 @@ for tag, title in (("bsds300", "C3 BSDS300-shaped eval (8192 x 63 integrals per 
     report[tag]["forward"] = e
     lines += table("forward quadrature kernel", e)
     if tag.endswith("_train"):
-        e = kernel_entry(stats, pmc, "cc_bwd_bf16_kernel", 3 * fl)
-        report[tag]["backward"] = e
-        lines += table("backward quadrature kernel (algorithmic FLOPs = 3 x forward: two gradient GEMMs per forward GEMM + the recompute)", e)
+        if tag.startswith("mnist"):     # three kernels per chunk share the backward's work: report each with its own counters
+            for part, ttl in (("cc_front_fwd_kernel", "stage A: front forward (a1, z2 -> HBM)"),
+                              ("cc_bwd_bf16_kernel", "stage B: flagship kernel on the net from hidden layer 2 on (FRONT)"),
+                              ("cc_front_bwd_kernel", "stage C: front backward (dG1, delta_1)")):
+                e = kernel_entry(stats, pmc, part, fl)
+                e["algorithmic_flops_per_launch"] = None
+                report[tag][part] = e
+                rows = table(ttl, dict(e, algorithmic_flops_per_launch=0.0, algorithmic_tflops=0.0, frac_of_bf16_peak=0.0))
+                lines += [r for r in rows if "algorithmic FLOPs" not in r]
+        else:
+            e = kernel_entry(stats, pmc, "cc_bwd_bf16_kernel", 3 * fl)
+            report[tag]["backward"] = e
+            lines += table("backward quadrature kernel (algorithmic FLOPs = 3 x forward: two gradient GEMMs per forward GEMM + the recompute)", e)
         lines += ["Top kernels of the training step (kernel-trace):", "", "| kernel | calls | avg | % |", "|---|---|---|---|"]
         for r in stats[:8]:
             lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} ms | {float(r['Percentage']):.1f} |")
