@@ -399,3 +399,43 @@ def test_results_do_not_depend_on_what_ran_before(hid, B, d, E, n, dev):
         out_f = I.hip_forward(spec, None, x, h, n)
         assert all(torch.equal(a, b) for a, b in zip(out_b, ref_b))
         assert all(torch.equal(a, b) for a, b in zip(out_f, ref_f))
+
+
+def test_integration_md_ctypes_stub_runs_as_written(dev):
+    """INTEGRATION.md section B shows the ctypes binding a maintainer of the reference would paste into
+    models/UMNN/ParallelNeuralIntegral.py.  Execute that very code block (only the library path substituted) and compare
+    its forward and backward with this package's operator: the documented boundary is the real one."""
+    import os
+    import re
+    import umnn_amd
+    from umnn_amd import _lib, IntegrandNetwork
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes, torch.*?)```", text, re.S).group(1)
+    code = code.replace('"/path/to/umnn_amd/libumnn_cc.so"', repr(_lib.LIB_PATH))
+    ns = {"compute_cc_weights": umnn_amd.compute_cc_weights}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    ns["_lib"].umnn_last_error.restype = __import__("ctypes").c_char_p
+    ns["_lib"].umnn_cc_backward_workspace_bytes.restype = __import__("ctypes").c_longlong
+    Stub = ns["ParallelNeuralIntegral"]
+    torch.manual_seed(2)
+    B, d, E, n = 40, 6, 30, 50
+    net = IntegrandNetwork(d, 1 + E, [50] * 4, 1).to(dev)
+    x0 = torch.zeros(B, d, device=dev)
+    x = torch.randn(B, d, device=dev)
+    h = torch.randn(B, E * d, device=dev)
+    g = torch.randn(B, d, device=dev)
+    outs = []
+    for Op in (Stub, umnn_amd.ParallelNeuralIntegral):
+        xr, hr = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
+        flat = torch.cat([p.reshape(-1) for p in net.parameters()]).detach().requires_grad_(True)
+        for p in net.parameters():
+            p.grad = None
+        F = Op.apply(x0, xr, net, flat, hr, n, False)
+        F.backward(g)
+        torch.cuda.synchronize()
+        # the stub returns d_theta for the flat_params argument (the reference's convention); the package fills both
+        dth = flat.grad if flat.grad is not None else torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        outs.append((F.detach(), xr.grad, hr.grad, dth))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -279,6 +279,8 @@ def test_in_kernel_inversion_round_trip(d, hid, E, n, nb_flow, B, dev):
         x_inv = m.invert(z, iter=iters)
         assert _lib.lib().umnn_launch_count() - before == nb_flow * d
         assert "cc_invert_bf16" in _lib.lib().umnn_last_kernel_name().decode()
+        if hid[0] == 100 and len(hid) == 5:
+            assert "T1=7,TREST=4" in _lib.lib().umnn_last_kernel_name().decode()
         assert float((x_inv - x).abs().max()) < tol * nb_flow
         with I.force_generic():                       # host-driven search, ATen integrals
             x_ref = m.invert(z, iter=iters)

@@ -11,6 +11,10 @@
 typedef void (*inv_kernel_t)(const FwdBf16Args);
 struct InvVariant { int tmax, exact, nrl; inv_kernel_t fn; const char* name; };
 #define INV_VARIANT(T, EX, NR) { T, EX, NR, cc_fwd_bf16_kernel<T, 2, 1, (EX) != 0, NR, false, true>, "cc_invert_bf16<T=" #T ",EXACT=" #EX ",LIVE=" #NR ">" }
+// wide first hidden layer over a narrow rest (MNISTExperiment's integrand: sampling d = 784 images is 3 920 of these launches)
+struct InvWideFirst { int t1; inv_kernel_t fn; const char* name; };
+#define INV_WIDE_FIRST(T) { T, cc_fwd_bf16_kernel<T, 2, 1, true, 0, false, true, 4>, "cc_invert_bf16<T1=" #T ",TREST=4>" }
+static const InvWideFirst kInvWideFirst[] = { INV_WIDE_FIRST(5), INV_WIDE_FIRST(6), INV_WIDE_FIRST(7), INV_WIDE_FIRST(8) };
 static const InvVariant kInvVariants[] = {
     INV_VARIANT(4, 1, 13), INV_VARIANT(4, 1, 0),       // UCI / VAE nets (31-50^4-1) and every other 3..4-tile net (zero-padded)
     INV_VARIANT(7, 1, 26), INV_VARIANT(7, 1, 0),       // 100-wide toy nets
@@ -38,6 +42,39 @@ extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const f
     a.inv_z = z; a.inv_x = x_inv; a.inv_j = j; a.inv_iters = iters;
     a.NI = B; a.d = d; a.E = E; a.n = nb_steps; a.inv_f = 0; a.ns = 1; a.x_bf16 = 0; a.h_bf16 = 0;
 
+    // ---- wide first hidden layer, every other layer at most four tiles: shape-exact family (as in cc_forward_bf16.hip)
+    {
+        bool wf = a.m.t_out[1] >= 5 && a.m.t_out[1] <= 8;
+        for (int l = 2; l <= L && wf; ++l) if (a.m.t_out[l] > 4) wf = false;
+        if (wf) {
+            const int T1 = a.m.t_out[1];
+            int o16 = 0;
+            for (int l = 1; l <= L; ++l) {
+                args.pl.ks32[l] = l == 1 ? T1 / 2 : 2;
+                args.pl.half_in[l] = l == 1 ? (T1 & 1) : 0;
+                if (l >= 2) a.m.t_out[l] = 4;
+            }
+            for (int l = 1; l < L; ++l) {
+                args.pl.off16[l] = o16;
+                o16 += 4 * (args.pl.ks32[l] * 2 * 512 + args.pl.half_in[l] * 2 * 256);
+            }
+            a.m.lds_off[L] = (((o16 + 1) / 2) + 3) & ~3;
+            const size_t lds_bytes = (size_t)a.m.lds_off[L] * sizeof(float);
+            const InvWideFirst* pick = nullptr;
+            for (const InvWideFirst& v : kInvWideFirst) if (v.t1 == T1) pick = &v;
+            if (pick && lds_bytes <= 160 * 1024) {
+                if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
+                a.ngroups = (unsigned)B;
+                const unsigned nblk = (a.ngroups + UMNN_WAVES_PER_BLOCK - 1) / UMNN_WAVES_PER_BLOCK;
+                umnn_prof_begin(stream);
+                hipLaunchKernelGGL(pick->fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
+                umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * 10.0 * iters * (double)B);
+                umnn_note_launch(pick->name);
+                return umnn_check(hipGetLastError(), "cc_invert launch");
+            }
+            return umnn_fail(UMNN_EUNSUPPORTED, "invert: weight images exceed 160 KiB of LDS");
+        }
+    }
     // ---- plan (the P = 1, two-piece subset of umnn_launch_forward_bf16's) ----
     int T = tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8;
     int wide = tmax >= 5 ? tmax : 0;
