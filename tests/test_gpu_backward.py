@@ -231,7 +231,7 @@ def test_mixed_wide_nets_backward_routes_match_the_oracle(hid, dev, monkeypatch,
     desc, keep = I._desc(spec)
     assert (_lib.lib().umnn_cc_backward_kind(ctypes.byref(desc), E) >= 0) == staged
     for mode in ("", "hip"):
-        monkeypatch.setenv("UMNN_BWD_WIDE", mode)
+        monkeypatch.setitem(I._BWD_WIDE, "hip", mode == "hip")
         xr, hr = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
         for p in net.parameters():
             p.grad = None
@@ -251,7 +251,7 @@ def test_mixed_wide_nets_backward_routes_match_the_oracle(hid, dev, monkeypatch,
     # first layer): the HIP route against the materialised ATen chain
     outs = []
     for route in ("hip", "aten"):
-        monkeypatch.setenv("UMNN_BWD_WIDE", "hip" if route == "hip" else "")
+        monkeypatch.setitem(I._BWD_WIDE, "hip", route == "hip")
         xr, hr = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
         for p in net.parameters():
             p.grad = None

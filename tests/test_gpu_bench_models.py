@@ -172,6 +172,11 @@ def test_vae_prior_flow_bf16_embedding_training_gradients(dev):
         assert U.scaled_err(grads["bf16"][k].cpu().numpy(), grads["fp32"][k].cpu().numpy()) < 5e-2, k
 
 
+def I_force_generic():
+    from umnn_amd import integral as I
+    return I.force_generic()
+
+
 def test_block_level_compute_ll_and_bis_on_the_hip_path(dev):
     """UMNNMAF.compute_ll / compute_ll_bis (block level, with the in-place clamp of z, UMNNMAF.py:141-162) on the HIP path."""
     import umnn_amd
@@ -198,6 +203,20 @@ def test_block_level_compute_ll_and_bis_on_the_hip_path(dev):
     assert U.rel_err(z.cpu().numpy(), zc) < TOL and U.rel_err(zb.cpu().numpy(), zc) < TOL
     assert U.rel_err(ll.cpu().numpy(), ll_ref) < TOL
     assert np.all(np.abs(ljb.cpu().numpy() - lj_ref) <= TOL * np.maximum(1.0, np.abs(lj_ref)))
+    # block-level compute_log_jac (UMNNMAF.py:136-139): f(x;h) from a one-step launch, with and without a graph
+    with torch.no_grad():
+        lj_only = m.nets[0].compute_log_jac(x)
+    assert umnn_amd.path_taken() == "hip"
+    assert np.all(np.abs(lj_only.cpu().numpy() - lj_ref) <= TOL * np.maximum(1.0, np.abs(lj_ref)))
+    xr = x.clone().requires_grad_(True)
+    lj_g = m.nets[0].compute_log_jac(xr)
+    lj_g.sum().backward()
+    # (autograd on: the conditioner runs its fp32 chain, autograd off its bf16x3 GEMMs -- same path tolerance)
+    assert torch.allclose(lj_g.detach(), lj_only, rtol=TOL, atol=TOL) and torch.isfinite(xr.grad).all()
+    with I_force_generic():
+        xa = x.clone().requires_grad_(True)
+        m.nets[0].compute_log_jac(xa).sum().backward()
+    assert U.scaled_err(xr.grad.cpu().numpy(), xa.grad.cpu().numpy()) < TOL
     # flow-level compute_ll_bis (per-dimension log-likelihood terms, UMNNMAFFlow.py:121-130)
     ll_full_ref, z_full_ref = O.flow_compute_ll(blocks, G["x"], int(G["n"]))
     with torch.no_grad():

@@ -144,7 +144,19 @@ class UMNNMAF(nn.Module):
 
     def compute_log_jac(self, x, context=None):
         h = self.net.make_embeding(x, context)
-        jac = self.net.parallel_nets(x, h)
+        integrand = self.net.parallel_nets
+        spec = mlp_spec(integrand)
+        if _I._use_hip(spec, x):
+            # f(x;h) is quadrature node 0: a one-step launch of the forward kernel evaluates it (two nodes) without the
+            # [B*d, 1+E] row matrix the reference materialises (UMNNMAF.py:136-139, 263-284)
+            wants_graph = torch.is_grad_enabled() and (x.requires_grad or h.requires_grad
+                                                       or any(p.requires_grad for p in integrand.parameters()))
+            if wants_graph:
+                jac = IntegralWithJacobianParams.apply(None, x, integrand, h, 1, *integrand.parameters())[1]
+            else:
+                jac = _I.hip_forward(spec, None, x, h, 1)[1]
+        else:
+            jac = integrand(x, h)
         return torch.log(jac + 1e-10) + self.scaling.unsqueeze(0).expand(x.shape[0], -1)
 
     def compute_log_jac_bis(self, x, context=None):

@@ -118,6 +118,13 @@ def _use_hip(spec, x):
 
 
 _bwd_kind = {}
+_BWD_WIDE = {"hip": os.environ.get("UMNN_BWD_WIDE", "") == "hip"}     # read once; set_backward_wide() at run time
+
+
+def set_backward_wide(force_hip):
+    """True: nets whose HIP backward only has the register-spilling generic wide kernels use them anyway (default: the
+    materialised ATen chain on the GPU; environment UMNN_BWD_WIDE=hip at import)."""
+    _BWD_WIDE["hip"] = bool(force_hip)
 
 
 def _hip_backward_ok(spec, x, h):
@@ -125,7 +132,7 @@ def _hip_backward_ok(spec, x, h):
     layers above 63 units of unequal width: 687 ms per call at 256x784 against ~190 ms for the materialised ATen chain on
     the same GPU).  Nets with a wide FIRST hidden layer and a narrow rest (MNISTExperiment's 100-50-50-50-50) have the
     three-stage kernels of cc_backward_front.hip.  ``UMNN_BWD_WIDE=hip`` forces the HIP kernels anyway."""
-    if os.environ.get("UMNN_BWD_WIDE", "") == "hip":
+    if _BWD_WIDE["hip"]:
         return True
     E = h.shape[1] // x.shape[1]
     key = (tuple((m.in_features, m.out_features) for m in spec.linears), E, _lib.get_option("bwd_precision"))
