@@ -8,7 +8,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libumnn_cc.so")
+LIB_PATH = os.environ.get("UMNN_CC_LIB") or os.path.join(_HERE, "libumnn_cc.so")     # (override: A/B runs of two builds)
 
 MAX_LINEAR = 8
 EINVAL, EUNSUPPORTED, ENODEVICE = -1, -2, -3

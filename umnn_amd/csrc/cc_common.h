@@ -96,6 +96,12 @@ __device__ __forceinline__ float out_grad_f(float v, int kind) {
     return s * (1.f - s);
 }
 
+// f or 1/f (inv_f, ParallelNeuralIntegral.py:58-59).  inv_f is a launch argument and almost never set, but as a select both
+// sides are evaluated for every node: the hardware reciprocal (v_rcp_f32, 1 ulp) costs one instruction there, the IEEE
+// division sequence eleven -- 22 of the ~450 vector instructions of a two-tile node of the forward kernel.  (A real branch
+// would split the hand-scheduled node body into several scheduling regions.)
+__device__ __forceinline__ float maybe_inverse(float f, int inv_f) { return inv_f ? __builtin_amdgcn_rcpf(f) : f; }
+
 // sum over the four lane groups (lanes p, p+16, p+32, p+48); every lane gets the total.
 // gfx950 row/half swaps keep this on the VALU (no LDS-crossbar bpermute): permlane16_swap(v,v) returns
 // {rows (0,0,2,2), rows (1,1,3,3)} of v, permlane32_swap(v,v) returns {(lo,lo), (hi,hi)}.

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_kernel(const FwdArgs a) {
                         if (t < TT || r == 0) s = fmaf(wout[t][r], act[pt][t][r], s);
                 s = group_allreduce(s);
                 const float f = out_act_f(s, m.out_act);
-                Facc[pt] = fmaf(wk, a.inv_f ? 1.f / f : f, Facc[pt]);
+                Facc[pt] = fmaf(wk, maybe_inverse(f, a.inv_f), Facc[pt]);
                 if (k == 0) fxv[pt] = f;
                 if (k == n) fx0v[pt] = f;
             }

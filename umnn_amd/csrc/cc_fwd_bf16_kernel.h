@@ -380,7 +380,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 for (int pt = 0; pt < 2; ++pt) {
                     const float sr = group_allreduce(pt == 0 ? sd0 : sd1);
                     const float f = out_act_f(sr, m.out_act);
-                    Facc[pt] = fmaf(wk, a.inv_f ? 1.f / f : f, Facc[pt]);
+                    Facc[pt] = fmaf(wk, maybe_inverse(f, a.inv_f), Facc[pt]);
                     if (k == 0) fxv[pt] = f;
                     if (k == n) fx0v[pt] = f;
                 }
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                         if (4 * t + r < NLIVE) s = fmaf(wout[t][r], act[pt][t][r], s);
                 s = group_allreduce(s);
                 const float f = out_act_f(s, m.out_act);
-                Facc[pt] = fmaf(wk, a.inv_f ? 1.f / f : f, Facc[pt]);
+                Facc[pt] = fmaf(wk, maybe_inverse(f, a.inv_f), Facc[pt]);
                 if (k == 0) fxv[pt] = f;
                 if (k == n) fx0v[pt] = f;
             }
