@@ -293,12 +293,13 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
             //         tile 3: act 17-20, hi 21, lo 23  -- or, with one live register, split on the VALU in slots 17, 18
             auto pack_slot = [&](auto ic, auto first, f32x4 (&z)[4], u32x4 (&bfout)[2][2], float tkv, const f32x4 (&cv)[TMAX]) {
                 constexpr int i = decltype(ic)::value;
-                constexpr bool FIRST = decltype(first)::value;
+                constexpr int MODE = decltype(first)::value;      // 0: raw MFMA output, 1: layer 1 (fma first), 2: already activated
+                constexpr bool FIRST = MODE == 1, PRE = MODE == 2;
                 constexpr int t_act = i <= 3 ? 0 : (i >= 5 && i <= 8) ? 1 : (i >= 11 && i <= 14) ? 2 : (NFULL == 4 && i >= 17 && i <= 20) ? 3 : -1;
                 constexpr int r_act = t_act == 0 ? i : t_act == 1 ? i - 5 : t_act == 2 ? i - 11 : i - 17;
                 constexpr int t_hi = i == 4 ? 0 : i == 9 ? 1 : i == 15 ? 2 : (NFULL == 4 && i == 21) ? 3 : -1;
                 constexpr int t_lo = i == 10 ? 0 : i == 16 ? 1 : i == 20 ? 2 : (NFULL == 4 && i == 23) ? 3 : -1;
-                if constexpr (t_act >= 0) {
+                if constexpr (t_act >= 0 && !PRE) {
                     if constexpr (FIRST) z[t_act][r_act] = fmaf(w1x[t_act][r_act], tkv, cv[t_act][r_act]);
                     z[t_act][r_act] = hidden_act_f(z[t_act][r_act], slope);
                 }
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 }
                 if constexpr (NFULL == 3 && i == 17) {           // tile 3 has one live register: split it on the VALU
                     if constexpr (FIRST) z[3][0] = fmaf(w1x[3][0], tkv, cv[3][0]);
-                    rem_a = hidden_act_f(z[3][0], slope);
+                    rem_a = PRE ? z[3][0] : hidden_act_f(z[3][0], slope);
                     const bf16x2 h = __builtin_convertvector(f32x2{rem_a, 0.f}, bf16x2);
                     rem_hi = __builtin_bit_cast(unsigned, h);
                     bfout[1][0][2] = rem_hi;
@@ -328,17 +329,36 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 }
             };
 
+            // Layer 1 of the FIRST tile (fma + LeakyReLU per live register) is computed one node ahead, in the shadow of the
+            // previous node's last matrix section (whose slots 11..23 carry no other vector work): at the head of a node, where
+            // nothing runs on the matrix pipe yet, only the bf16 packing of those values is left.
+            constexpr int PRE0 = 24 - NLIVE;                          // first slot of the last section that prepares the next node
+            f32x4 znext[4];
+            {
+                const float u0 = a.ccs[k_lo] + 1.f;
+                const float t0 = k_lo == 0 ? xv[0] : __fadd_rn(x0v[0], __fmul_rn(dxv[0], u0) * 0.5f);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        znext[t][r] = 4 * t + r < NLIVE ? hidden_act_f(fmaf(w1x[t][r], t0, c[0][t][r]), slope) : 0.f;
+            }
             for (int k = k_lo; k < k_hi; ++k) {
                 const float u = a.ccs[k] + 1.f;
                 const float wk = a.ccw[k];
                 float tk[2];
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) tk[pt] = k == 0 ? xv[pt] : __fadd_rn(x0v[pt], __fmul_rn(dxv[pt], u) * 0.5f);
+                const int kn = k + 1 <= n ? k + 1 : n;
+                const float tkn0 = __fadd_rn(x0v[0], __fmul_rn(dxv[0], a.ccs[kn] + 1.f) * 0.5f);     // (k + 1 >= 1: never node 0)
                 f32x4 acc0[4], acc1[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc0[t] = znext[t];
                 constexpr std::true_type kFirst{};
                 constexpr std::false_type kLater{};
-                // first tile: layer 1 on the VALU, nothing to hide behind yet
-                static_for(Slots{}, [&](auto ic) { pack_slot(ic, kFirst, acc0, bf[0], tk[0], c[0]); });
+                constexpr std::integral_constant<int, 2> kPre{};
+                // first tile: its layer 1 is already there, only the packing is left -- nothing to hide behind yet
+                static_for(Slots{}, [&](auto ic) { pack_slot(ic, kPre, acc0, bf[0], tk[0], c[0]); });
                 __builtin_amdgcn_sched_barrier(0);
                 // section A of layer 1: first tile on the matrix pipe, second tile's layer 1 + packing on the VALU
                 static_for(Slots{}, [&](auto ic) {
@@ -368,6 +388,10 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     constexpr int i = decltype(ic)::value;
                     mfma_slot(ic, bf[1], acc1);
                     if constexpr (i < NLIVE) sd0 = fmaf(wout[i / 4][i % 4], hidden_act_f(acc0[i / 4][i % 4], slope), sd0);
+                    if constexpr (i >= PRE0) {
+                        constexpr int e = i - PRE0, t = e / 4, r = e % 4;
+                        znext[t][r] = hidden_act_f(fmaf(w1x[t][r], tkn0, c[0][t][r]), slope);
+                    }
                     reload_slot(ic, 1);
                     __builtin_amdgcn_sched_barrier(0);
                 });
