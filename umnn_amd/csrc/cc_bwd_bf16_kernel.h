@@ -163,13 +163,14 @@ __device__ __forceinline__ int slot_feature(int sigma) {
     const int G = sigma >> 4, ss = (sigma >> 3) & 1, j = sigma & 7;
     return 16 * (2 * ss + (j >> 2)) + 4 * (j & 3) + G;
 }
-__device__ __forceinline__ void transpose_pieces_lds(const BFrag<NPB>& x, unsigned short* tile, int g, int p,
-                                                     u32x2 (&out)[BT][NPB]) {
+__device__ __forceinline__ void tr_tile_store(const BFrag<NPB>& x, unsigned short* tile, int g, int p) {
 #pragma unroll
     for (int part = 0; part < NPB; ++part)
 #pragma unroll
         for (int s = 0; s < BKS; ++s)
             *reinterpret_cast<u32x4*>(tile + (part * 16 + p) * TRS + g * 16 + s * 8) = x.v[s][part];
+}
+__device__ __forceinline__ void tr_tile_read(const unsigned short* tile, int g, int p, u32x2 (&out)[BT][NPB]) {
 #pragma unroll
     for (int tau = 0; tau < BT; ++tau)
 #pragma unroll
@@ -178,6 +179,11 @@ __device__ __forceinline__ void transpose_pieces_lds(const BFrag<NPB>& x, unsign
             const s16x4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4v __attribute__((address_space(3)))*)(src));
             out[tau][part] = __builtin_bit_cast(u32x2, v);
         }
+}
+__device__ __forceinline__ void transpose_pieces_lds(const BFrag<NPB>& x, unsigned short* tile, int g, int p,
+                                                     u32x2 (&out)[BT][NPB]) {
+    tr_tile_store(x, tile, g, p);
+    tr_tile_read(tile, g, p, out);
 }
 
 // LH = number of hidden layers (compile-time: the layer loops are unrolled so that every register array is
@@ -420,9 +426,14 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
                 if constexpr (TRL) transpose_pieces_lds(asave[l - 1], tr_tile, g, p, aT);
                 BFrag<NPB> bd;
                 split_regs<NRL, NPB>(delta, bd);
+                // the GEMM through W_l^T first: it is the critical path to the next layer; the dW product below only feeds
+                // accumulators and can run under the vector work that follows
+                f32x4 nd[BT];
+                if constexpr (TRL) tr_tile_store(bd, tr_tile, g, p);
+                gemm_frags<NPB>(frag_base + args.off_tr[l], bd, nd);
                 {
                     if constexpr (TRL) {
-                        transpose_pieces_lds(bd, tr_tile, g, p, dT);
+                        tr_tile_read(tr_tile, g, p, dT);
                     } else {
                         transpose_pieces(bd, sel, dT);
                         transpose_pieces(asave[l - 1], sel, aT);
@@ -439,8 +450,6 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
                                     dW[l - 1][to][ti] = mfma_bf16_k16(dT[to][wa], aT[ti][ba], dW[l - 1][to][ti]);
                         }
                 }
-                f32x4 nd[BT];
-                gemm_frags<NPB>(frag_base + args.off_tr[l], bd, nd);
 #pragma unroll
                 for (int t = 0; t < BT; ++t)
 #pragma unroll
