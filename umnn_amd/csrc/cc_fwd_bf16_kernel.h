@@ -30,7 +30,13 @@
 // half_in[l] != 0: the input layer has an odd tile count; ks counts its FULL K-steps (tile pairs) only and the last
 // tile follows as half fragments (64 lanes x 4 bf16, for the K = 16 MFMA) at ((t'*NPARTS + part)*256 + lane*4 + j)
 // behind the full ones -- the padding tile of a full K-step would cost 7 KB of LDS per layer and part at width 100.
-template <int NPARTS>
+// MERGE (four tiles, two pieces, hidden widths 48..51 -- 13 live registers per lane, tile 3 holds ONE feature per lane
+// group): the three cross terms need 3 x (H+1) <= 156 k-slots, so FIVE K-steps per layer carry them instead of six.  K-step 0
+// (tiles 0,1) keeps its two fragments [Whi] (used with ahi, then alo) and [Wlo] (with ahi); the two fragments of "K-step 1" become
+//   part 0:  k-slots 0-3 Whi of tile 2 (x ahi)  |  4: Whi, 5: Whi, 6: Wlo, 7: 0 of the lane group's tile-3 feature (x ahi, alo, ahi)
+//   part 1:  k-slots 0-3 Whi of tile 2 (x alo)  |  4-7 Wlo of tile 2 (x ahi)
+// and the kernels pack the B operands to match -- each lane group still supplies its own features only.
+template <int NPARTS, bool MERGE = false>
 __device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks32, const int* off16, const int* half_in,
                                                   unsigned short* lds16, int tid, int nthreads) {
     const int L = m.n_linear - 1;
@@ -46,14 +52,25 @@ __device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks
             const int j = idx & 7, ln = (idx >> 3) & 63, ts = idx >> 9;
             const int s = ts % ks, t = ts / ks;
             const int fo = fout_of(t, ln & 15);
-            const int fi = feat_of(2 * s + (j >> 2), j & 3, ln >> 4);
-            float v = 0.f;
-            if (fo < Hout) {
-                if (fi < Hin) v = W[fo * Hin + fi];
-                else if (fi == Hin) v = b[fo];
-            } else if (fo == Hout && fi == Hin) {
-                v = 1.f;
+            auto wv = [&](int fi) {
+                float v = 0.f;
+                if (fo < Hout) {
+                    if (fi < Hin) v = W[fo * Hin + fi];
+                    else if (fi == Hin) v = b[fo];
+                } else if (fo == Hout && fi == Hin) {
+                    v = 1.f;
+                }
+                return v;
+            };
+            if (MERGE && s == 1) {
+                const float v2 = wv(feat_of(2, j & 3, ln >> 4)), v3 = wv(feat_of(3, 0, ln >> 4));
+                const unsigned short h2 = bf16_rn_bits(v2), l2 = bf16_rn_bits(v2 - bf16_bits_to_f32(h2));
+                const unsigned short h3 = bf16_rn_bits(v3), l3 = bf16_rn_bits(v3 - bf16_bits_to_f32(h3));
+                img[(ts * NPARTS + 0) * 512 + ln * 8 + j] = j < 4 ? h2 : j < 6 ? h3 : j == 6 ? l3 : (unsigned short)0;
+                img[(ts * NPARTS + 1) * 512 + ln * 8 + j] = j < 4 ? h2 : l2;
+                continue;
             }
+            float v = wv(feat_of(2 * s + (j >> 2), j & 3, ln >> 4));
 #pragma unroll
             for (int part = 0; part < NPARTS; ++part) {
                 const unsigned short hb = bf16_rn_bits(v);
@@ -128,6 +145,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
     static_assert(!INV || (P == 1 && !PIPE), "inversion variants: plain loop, one tile per wave");
     constexpr int KSM = TMAX / 2;
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * TMAX;
+    constexpr bool MERGE = EXACT && TMAX == 4 && NRL == 13 && NPARTS == 2 && TREST == 0;      // five K-steps per layer (see staging)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FwdArgs& a = args.f;
     const MlpDev& m = a.m;
@@ -140,7 +158,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
     const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
     unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
 
-    stage_bf16_images<NPARTS>(m, args.pl.ks32, args.pl.off16, args.pl.half_in, lds16, tid, UMNN_BLOCK);
+    stage_bf16_images<NPARTS, MERGE>(m, args.pl.ks32, args.pl.off16, args.pl.half_in, lds16, tid, UMNN_BLOCK);
     __syncthreads();
 
     const int ns = a.ns;
@@ -235,8 +253,9 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
 
         if constexpr (PIPE) {
             static_assert(TMAX == 4 && EXACT && NPARTS == 2 && P == 2, "pipelined loop: 4 tiles, 2 pieces, 2 point tiles");
-            constexpr int NSLOT = 24;                               // MFMAs of one point tile in one layer
+            constexpr int NSLOT = MERGE ? 20 : 24;                  // MFMAs of one point tile in one layer
             constexpr int NFULL = NLIVE / 4;                        // tiles with all four registers live
+            static_assert(MERGE == (NFULL == 3), "13 live registers <-> merged K-steps");
             static_assert(NLIVE % 4 == 0 || (NLIVE % 4 == 1 && NFULL == 3), "pipelined loop: 13 or 16 live registers");
             using Slots = std::make_integer_sequence<int, NSLOT>;
             u32x4 wf[4][2][2];                                      // [tile][K-step][piece] of the layer in flight
@@ -268,10 +287,14 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2) wf[t][ks][k2] = frag(1, t, ks, k2);
             // slot i of a section: K-step i/12, cross term (i/4)%3 = (W piece, activation piece) (0,0),(0,1),(1,0), tile i%4
+            // MERGE: step i/4 of five -- (tiles 0,1) x the same three terms, then the two merged K-steps [ks=1][0], [ks=1][1]
             auto mfma_slot = [&](auto ic, const u32x4 (&bfin)[2][2], f32x4 (&acc)[4]) {
                 constexpr int i = decltype(ic)::value;
-                constexpr int ks = i / 12, term = (i / 4) % 3, t = i % 4;
-                constexpr int wa = term == 2 ? 1 : 0, ba = term == 1 ? 1 : 0;
+                constexpr int t = i % 4;
+                constexpr int ks = MERGE ? (i / 4 >= 3) : i / 12;
+                constexpr int term = MERGE ? (i / 4) % 3 : (i / 4) % 3;
+                constexpr int wa = (MERGE && ks == 1) ? i / 4 - 3 : (term == 2 ? 1 : 0);
+                constexpr int ba = (MERGE && ks == 1) ? i / 4 - 3 : (term == 1 ? 1 : 0);
                 if constexpr (i < 4) acc[t] = mfma_bf16(wf[t][ks][wa], bfin[ks][ba], f32x4{0.f, 0.f, 0.f, 0.f});
                 else acc[t] = mfma_bf16(wf[t][ks][wa], bfin[ks][ba], acc[t]);
             };
@@ -279,9 +302,14 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
             // fragment of the layer that runs next into its registers
             auto reload_slot = [&](auto ic, int lnext) {
                 constexpr int i = decltype(ic)::value;
-                constexpr int ks = i / 12, term = (i / 4) % 3, t = i % 4;
-                if constexpr (term == 1) wf[t][ks][0] = frag(lnext, t, ks, 0);
-                if constexpr (term == 2) wf[t][ks][1] = frag(lnext, t, ks, 1);
+                if constexpr (MERGE) {
+                    constexpr int step = i / 4, t = i % 4;            // last uses: step 1, 2, 3, 4
+                    if constexpr (step >= 1) wf[t][step >= 3][(step - 1) & 1] = frag(lnext, t, step >= 3, (step - 1) & 1);
+                } else {
+                    constexpr int ks = i / 12, term = (i / 4) % 3, t = i % 4;
+                    if constexpr (term == 1) wf[t][ks][0] = frag(lnext, t, ks, 0);
+                    if constexpr (term == 2) wf[t][ks][1] = frag(lnext, t, ks, 1);
+                }
             };
             // The packing work of one point tile, in place on its raw pre-activations z[4], one slice per MFMA slot so that
             // (almost) every slice fits the two-instruction issue shadow of the slot's MFMA:
@@ -290,7 +318,8 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
             //             pipe                                                                       2 VALU + 1 MFMA
             //   lo(t)     second pieces packed into bf[t/2][1] (two slots after hi(t): the MFMA has landed)    2 VALU
             // slots   tile 0: act 0-3, hi 4, lo 10     tile 1: act 5-8, hi 9, lo 16     tile 2: act 11-14, hi 15, lo 20
-            //         tile 3: act 17-20, hi 21, lo 23  -- or, with one live register, split on the VALU in slots 17, 18
+            //         tile 3: act 17-20, hi 21, lo 23  -- or (MERGE: 20 slots), with one live register, split on the VALU in
+            //         slots 17, 18 and tile 2's lo in 19
             auto pack_slot = [&](auto ic, auto first, f32x4 (&z)[4], u32x4 (&bfout)[2][2], float tkv, const f32x4 (&cv)[TMAX]) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int MODE = decltype(first)::value;      // 0: raw MFMA output, 1: layer 1 (fma first), 2: already activated
@@ -298,7 +327,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 constexpr int t_act = i <= 3 ? 0 : (i >= 5 && i <= 8) ? 1 : (i >= 11 && i <= 14) ? 2 : (NFULL == 4 && i >= 17 && i <= 20) ? 3 : -1;
                 constexpr int r_act = t_act == 0 ? i : t_act == 1 ? i - 5 : t_act == 2 ? i - 11 : i - 17;
                 constexpr int t_hi = i == 4 ? 0 : i == 9 ? 1 : i == 15 ? 2 : (NFULL == 4 && i == 21) ? 3 : -1;
-                constexpr int t_lo = i == 10 ? 0 : i == 16 ? 1 : i == 20 ? 2 : (NFULL == 4 && i == 23) ? 3 : -1;
+                constexpr int t_lo = i == 10 ? 0 : i == 16 ? 1 : i == (MERGE ? 19 : 20) ? 2 : (NFULL == 4 && i == 23) ? 3 : -1;
                 if constexpr (t_act >= 0 && !PRE) {
                     if constexpr (FIRST) z[t_act][r_act] = fmaf(w1x[t_act][r_act], tkv, cv[t_act][r_act]);
                     z[t_act][r_act] = hidden_act_f(z[t_act][r_act], slope);
@@ -308,6 +337,10 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     const bf16x2 h1 = __builtin_convertvector(f32x2{z[t_hi][2], z[t_hi][3]}, bf16x2);
                     bfout[t_hi / 2][0][2 * (t_hi % 2)] = __builtin_bit_cast(unsigned, h0);
                     bfout[t_hi / 2][0][2 * (t_hi % 2) + 1] = __builtin_bit_cast(unsigned, h1);
+                    if constexpr (MERGE && t_hi == 2) {           // tile 2's leading pieces also close the last K-step
+                        bfout[1][1][2] = __builtin_bit_cast(unsigned, h0);
+                        bfout[1][1][3] = __builtin_bit_cast(unsigned, h1);
+                    }
                     z[t_hi] = mfma_bf16(sel[t_hi % 2], bfout[t_hi / 2][0], z[t_hi]);          // exact remainders
                 }
                 if constexpr (t_lo >= 0) {
@@ -321,18 +354,18 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     rem_a = PRE ? z[3][0] : hidden_act_f(z[3][0], slope);
                     const bf16x2 h = __builtin_convertvector(f32x2{rem_a, 0.f}, bf16x2);
                     rem_hi = __builtin_bit_cast(unsigned, h);
-                    bfout[1][0][2] = rem_hi;
+                    bfout[1][0][3] = rem_hi;                     // k-slots 6,7: (hi, 0)
                 }
                 if constexpr (NFULL == 3 && i == 18) {
                     const bf16x2 l = __builtin_convertvector(f32x2{rem_a - __uint_as_float(rem_hi << 16), 0.f}, bf16x2);
-                    bfout[1][1][2] = __builtin_bit_cast(unsigned, l);
+                    bfout[1][0][2] = rem_hi | (__builtin_bit_cast(unsigned, l) << 16);      // k-slots 4,5: (hi, lo)
                 }
             };
 
             // Layer 1 of the FIRST tile (fma + LeakyReLU per live register) is computed one node ahead, in the shadow of the
             // previous node's last matrix section (whose slots 11..23 carry no other vector work): at the head of a node, where
             // nothing runs on the matrix pipe yet, only the bf16 packing of those values is left.
-            constexpr int PRE0 = 24 - NLIVE;                          // first slot of the last section that prepares the next node
+            constexpr int PRE0 = NSLOT - NLIVE;                          // first slot of the last section that prepares the next node
             f32x4 znext[4];
             {
                 const float u0 = a.ccs[k_lo] + 1.f;
@@ -465,6 +498,12 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                         if (8 * s + 6 < NLIVE) split_pair<NPARTS>(act[pt][2 * s + 1][2], act[pt][2 * s + 1][3], q3);
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) bf[pt][s][k2] = u32x4{q0[k2], q1[k2], q2[k2], q3[k2]};
+                        if constexpr (MERGE) {
+                            if (s == 1) {        // (tile 2 hi | tile-3 feature: hi, lo, hi, 0) and (tile 2 lo | tile 2 hi)
+                                bf[pt][1][0] = u32x4{q0[0], q1[0], q2[0] | (q2[NPARTS - 1] << 16), q2[0]};
+                                bf[pt][1][NPARTS - 1] = u32x4{q0[NPARTS - 1], q1[NPARTS - 1], q0[0], q1[0]};
+                            }
+                        }
                     }
                 // odd tile count (EXACT only): the last tile is a K = 16 step of its own
                 u32x2 hb[P][NPARTS];
@@ -501,7 +540,8 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                         for (int wa = 0; wa < NPARTS; ++wa)
 #pragma unroll
                             for (int ba = 0; ba < NPARTS; ++ba) {
-                                if (wa + ba >= NPARTS) continue;      // 2 parts: hh,hl,lh ; 3 parts: + h l2, l2 h, l l
+                                if (MERGE && s == 1) { if (wa != ba) continue; }      // merged K-steps: fragment k x operand k
+                                else if (wa + ba >= NPARTS) continue;      // 2 parts: hh,hl,lh ; 3 parts: + h l2, l2 h, l l
 #pragma unroll
                                 for (int t = 0; t < OT; ++t)
                                     if (EXACT || t < to) {
