@@ -277,8 +277,10 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
             }
             float rem_a = 0.f;                                      // the single live register of tile 3 (13-register shape)
             unsigned rem_hi = 0u;
+            // (every image of this shape is 16 fragments: off16[l] = (l - 1) * 8192 -- computed, not fetched from the kernel
+            // arguments: a scalar load per layer and the wait behind it)
             auto frag = [&](int l, int t, int ks, int k2) {
-                return *reinterpret_cast<const u32x4*>(lds16 + args.pl.off16[l] + lane * 8 + ((t * 2 + ks) * 2 + k2) * 512);
+                return *reinterpret_cast<const u32x4*>(lds16 + (l - 1) * (16 * 512) + lane * 8 + ((t * 2 + ks) * 2 + k2) * 512);
             };
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -376,14 +378,16 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     for (int r = 0; r < 4; ++r)
                         znext[t][r] = 4 * t + r < NLIVE ? hidden_act_f(fmaf(w1x[t][r], t0, c[0][t][r]), slope) : 0.f;
             }
+            float cs_cur = a.ccs[k_lo], cw_cur = a.ccw[k_lo];       // node abscissa / weight: fetched one node ahead
             for (int k = k_lo; k < k_hi; ++k) {
-                const float u = a.ccs[k] + 1.f;
-                const float wk = a.ccw[k];
+                const int kn = k + 1 <= n ? k + 1 : n;
+                const float cs_next = a.ccs[kn], cw_next = a.ccw[kn];
+                const float u = cs_cur + 1.f;
+                const float wk = cw_cur;
+                cs_cur = cs_next; cw_cur = cw_next;
                 float tk[2];
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) tk[pt] = k == 0 ? xv[pt] : __fadd_rn(x0v[pt], __fmul_rn(dxv[pt], u) * 0.5f);
-                const int kn = k + 1 <= n ? k + 1 : n;
-                const float tkn0 = __fadd_rn(x0v[0], __fmul_rn(dxv[0], a.ccs[kn] + 1.f) * 0.5f);     // (k + 1 >= 1: never node 0)
                 f32x4 acc0[4], acc1[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc0[t] = znext[t];
@@ -416,6 +420,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     });
                 }
                 // section B of the last hidden layer: the first tile's output goes into the output dot product
+                const float tkn0 = __fadd_rn(x0v[0], __fmul_rn(dxv[0], cs_next + 1.f) * 0.5f);     // (k + 1 >= 1: never node 0)
                 float sd0 = 0.f, sd1 = 0.f;
                 static_for(Slots{}, [&](auto ic) {
                     constexpr int i = decltype(ic)::value;
@@ -482,7 +487,10 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 constexpr int KSL = KT / 2;
                 constexpr bool HALFL = EXACT && (KT & 1);
                 const int ks = EXACT ? KSL : args.pl.ks32[l], to = EXACT ? OT : m.t_out[l + 1];
-                const unsigned short* img = lds16 + args.pl.off16[l] + lane * 8;
+                // (uniform exact shapes: the image offset is (l - 1) x a compile-time stride -- no scalar load from the arguments)
+                constexpr int IMG_STRIDE = TMAX * (KSM * NPARTS * 512 + (TMAX & 1) * NPARTS * 256);
+                const int off_l = (EXACT && TREST == 0) ? (l - 1) * IMG_STRIDE : args.pl.off16[l];
+                const unsigned short* img = lds16 + off_l + lane * 8;
                 // split + pack the activations into B fragments: K-step s <- tiles 2s, 2s+1
                 u32x4 bf[P][KSL > 0 ? KSL : 1][NPARTS];
 #pragma unroll
@@ -553,7 +561,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     }
                 }
                 if constexpr (HALFL) {
-                    const unsigned short* himg = lds16 + args.pl.off16[l] + OT * KSL * NPARTS * 512 + lane * 4;
+                    const unsigned short* himg = lds16 + off_l + OT * KSL * NPARTS * 512 + lane * 4;
                     u32x2 wh[TMAX][NPARTS];
 #pragma unroll
                     for (int t = 0; t < OT; ++t)
