@@ -305,6 +305,8 @@ def main():
         if on_bf16 and args.mode == "eval":
             hd, terms = cfg["hd"], (3 if "PARTS=2" in kernel_name else 6)
             per_tile_node = sum(-(-(hd[i + 1] + 1) // 16) * -(-(-(-(hd[i] + 1) // 16)) // 2) * terms for i in range(len(hd) - 1))
+            if "LIVE=13" in kernel_name and terms == 3:     # widths 48..51: the three terms share FIVE K-steps (merged layout)
+                per_tile_node = sum(-(-(hd[i + 1] + 1) // 16) * 5 for i in range(len(hd) - 1))
             if "PIPE" in kernel_name:     # + one remainder MFMA per fully live tile and split (see cc_forward_bf16.hip)
                 per_tile_node += sum((-(-(hd[i] + 1) // 4)) // 4 for i in range(len(hd) - 1))
             tiles = -(-cfg["rows"] * cfg["d"] // 16)
