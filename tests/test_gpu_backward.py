@@ -99,6 +99,38 @@ def test_backward_ragged_and_deep(dev):
     assert U.scaled_err(dth.cpu().numpy(), rflat) < TOL
 
 
+@pytest.mark.parametrize("hid,E,B,d", [([100, 100], 90, 41, 3), ([50, 50, 50], 30, 700, 5), ([20, 20], 4, 9, 2)])
+def test_first_layer_gradient_gemm_shapes(hid, E, B, d, dev):
+    """d W1[:,1:] / d b1 leave as a skinny GEMM over all integrals (cc_bwd_dw0_kernel: persistent blocks, fp32 MFMA): an
+    embedding wider than one launch's 40 output tiles, several chunks per block, and a batch smaller than one chunk."""
+    from umnn_amd import integral as I, _lib
+    from umnn_amd.nets import MlpSpec
+    rng = np.random.RandomState(11)
+    n = 16
+    sizes = [1 + E] + hid + [1]
+    Ws = [(rng.randn(sizes[i + 1], sizes[i]) * (1.2 / np.sqrt(sizes[i]))).astype(np.float32) for i in range(len(sizes) - 1)]
+    bs = [(rng.randn(sizes[i + 1]) * 0.3).astype(np.float32) for i in range(len(sizes) - 1)]
+    lin = []
+    for W, b in zip(Ws, bs):
+        m = torch.nn.Linear(W.shape[1], W.shape[0])
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(W))
+            m.bias.copy_(torch.from_numpy(b))
+        lin.append(m.to(dev))
+    spec = MlpSpec(lin, _lib.ACT_LEAKY_RELU, _lib.OUT_ELU_PLUS_ONE)
+    x = (rng.randn(B, d) * 2).astype(np.float32)
+    h = rng.randn(B, E * d).astype(np.float32)
+    g = rng.randn(B, d).astype(np.float32)
+    onet = O.Net(Ws, bs, O.LEAKY, O.ELU1)
+    dx0, dx, dh, dth = I.hip_backward(spec, None, t(x, dev), t(h, dev), t(g, dev), None, n)
+    _, rdx, rdh, _, _, rflat = O.integrate_backward(onet, np.zeros_like(x), x, h, n, g)
+    assert U.scaled_err(dh.cpu().numpy(), rdh) < TOL
+    got, ref = dth.cpu().numpy(), rflat
+    nW0 = sizes[1] * sizes[0]
+    assert U.scaled_err(got[:nW0 + sizes[1]], ref[:nW0 + sizes[1]]) < TOL      # W1 (x column and embedding columns) and b1
+    assert U.scaled_err(got, ref) < TOL
+
+
 def test_autograd_function_matches_reference_api(dev):
     """ParallelNeuralIntegral.apply / NeuralIntegral.apply through autograd (reference tests/test_jit.py:12-86 shape)."""
     import umnn_amd

@@ -409,45 +409,113 @@ __global__ __launch_bounds__(256) void cc_bwd_dcsum_kernel(float* __restrict__ d
 }
 
 // partial[blk][f][e] = sum_{q in chunk} dc[q][f] * hext[q][e],  hext[q][E] = 1  (-> dW1[:,1:], db1)
+// A skinny GEMM (H1 x (E+1) outputs, contraction over the chunk's integrals) on the fp32 matrix cores: the chunk of dc and of
+// the gathered embedding rows is staged in LDS -- dc integral-major with a row stride of 16 mod 32 floats (the four 16-float row
+// segments of a fragment read fall into four different bank groups), h column-major with a stride of chunk + 4 (lane (g, p) reads
+// bank 4 * (k p mod 16) + g): both the staging writes and the fragment reads are conflict-free -- every wave owns output tiles
+// (16 features x 16 embedding columns) and walks the chunk four integrals per v_mfma_f32_16x16x4_f32.  (Round 1-2 had one thread per output and two LDS reads per FMA:
+// 0.40 ms per C3 call against 165 MB of traffic; this one is bound by the dc / h stream.)
+__host__ __device__ inline int dw0_stride(int cols) { return ((cols + 15) / 16 * 16 + 16 + 31) / 32 * 32 - 16; }   // >= cols, = 16 mod 32
+__host__ __device__ inline size_t dw0_lds_floats(int chunk, int H1, int E) {
+    return (size_t)chunk * dw0_stride(H1) + (size_t)((E + 1 + 15) / 16 * 16) * (chunk + 4);
+}
+// DW0_MAXT = output tiles per wave (compile-time: the accumulators stay in registers): 2 covers the 48..64-wide, E <= 31 nets,
+// 4 the 100-wide ones, 10 = ceil(8 x 5 / 4) everything up to H1 = 127, E = 79 in one launch (wider embeddings: one launch per
+// 40 tiles, `tile_base`; every launch writes its own entries of the same partial slices).
+template <int DW0_MAXT>
 __global__ __launch_bounds__(256) void cc_bwd_dw0_kernel(const float* __restrict__ dc, const float* __restrict__ h,
                                                          float* __restrict__ partial, long long NI, int d, int E,
-                                                         int H1, int chunk, int h_bf16) {
+                                                         int H1, int chunk, int h_bf16, int tile_base) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* sdc = sm;                          // [chunk][H1]
-    float* sh = sm + chunk * H1;              // [chunk][E+1]
-    const int tid = threadIdx.x;
-    const long long q0 = (long long)blockIdx.x * chunk;
-    const int nq = (int)min((long long)chunk, NI - q0);
-    for (int i = tid; i < nq * H1; i += 256) {
-        sdc[i] = dc[q0 * H1 + i];
+    const int HS = dw0_stride(H1), CS = chunk + 4;
+    float* sdc = sm;                          // [chunk][HS]
+    float* sh = sm + chunk * HS;              // [16 ET][CS]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int FT = (H1 + 15) / 16, ET = (E + 1 + 15) / 16, ntiles = FT * ET;
+    const int g = lane >> 4, p = lane & 15;
+    const int lc = 31 - __clz(chunk);         // (chunk is a power of two)
+    const long long nchunks = (NI + chunk - 1) >> lc;
+    f32x4 acc[DW0_MAXT][2];
+#pragma unroll
+    for (int k = 0; k < DW0_MAXT; ++k) acc[k][0] = acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // persistent blocks: block b takes chunks b, b + gridDim.x, ... and keeps its output tiles in registers across them
+    for (long long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const long long q0 = c << lc;
+        const int nq = (int)min((long long)chunk, NI - q0);
+        for (int ql = wid; ql < chunk; ql += 4)
+            for (int f = lane; f < FT * 16; f += 64) sdc[ql * HS + f] = (ql < nq && f < H1) ? dc[(q0 + ql) * H1 + f] : 0.f;
+        {
+            // integral q0 + ql = sample b0 + (r0 + ql) / d, dimension (r0 + ql) % d: one 64-bit division per chunk, 32-bit ones per element
+            const long long b0 = q0 / d;
+            const int r0 = (int)(q0 - b0 * d);
+            const IoView hv = IoView{h, h_bf16} + b0 * ((long long)E * d);
+            for (int i = tid; i < chunk * ET * 16; i += 256) {
+                const int e = i >> lc, ql = i & (chunk - 1);
+                float v = 0.f;
+                if (ql < nq) {
+                    const int rb = (r0 + ql) / d, ri = (r0 + ql) - rb * d;
+                    v = e < E ? hv[(long long)(rb * E + e) * d + ri] : (e == E ? 1.f : 0.f);
+                }
+                sh[e * CS + ql] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < DW0_MAXT; ++k) {
+            const int tile = tile_base + wid + 4 * k;
+            if (tile < ntiles) {
+                const int ft = tile / ET, et = tile - ft * ET;
+                const float* pa = sdc + g * HS + 16 * ft + p;
+                const float* pb = sh + (16 * et + p) * CS + g;
+                for (int s = 0; s < chunk; s += 16) {          // (chunk is a multiple of 16; two accumulators: independent MFMAs)
+                    acc[k][0] = mfma16(pa[s * HS], pb[s], acc[k][0]);
+                    acc[k][1] = mfma16(pa[(s + 4) * HS], pb[s + 4], acc[k][1]);
+                    acc[k][0] = mfma16(pa[(s + 8) * HS], pb[s + 8], acc[k][0]);
+                    acc[k][1] = mfma16(pa[(s + 12) * HS], pb[s + 12], acc[k][1]);
+                }
+            }
+        }
+        __syncthreads();
     }
-    for (int i = tid; i < nq * (E + 1); i += 256) {
-        const int e = i / nq, ql = i - e * nq;
-        const long long q = q0 + ql, bi = q / d;
-        sh[ql * (E + 1) + e] = e < E ? io_ld(h, bi * ((long long)E * d) + (long long)e * d + (q - bi * d), h_bf16) : 1.f;
-    }
-    __syncthreads();
     const int nout = H1 * (E + 1);
-    for (int o = tid; o < nout; o += 256) {
-        const int f = o / (E + 1), e = o - f * (E + 1);
-        float s = 0.f;
-        for (int ql = 0; ql < nq; ++ql) s = fmaf(sdc[ql * H1 + f], sh[ql * (E + 1) + e], s);
-        partial[(size_t)blockIdx.x * nout + o] = s;
+    float* out = partial + (size_t)blockIdx.x * nout;
+#pragma unroll
+    for (int k = 0; k < DW0_MAXT; ++k) {
+        const int tile = tile_base + wid + 4 * k;
+        if (tile < ntiles) {
+            const int ft = tile / ET, et = tile - ft * ET;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * ft + 4 * g + r, e = 16 * et + p;
+                if (f < H1 && e < E + 1) out[f * (E + 1) + e] = acc[k][0][r] + acc[k][1][r];
+            }
+        }
     }
 }
 
-// dtheta[i] = sum_w partials[w][i]  (+ first-layer slices from the dw0 partials).  16 lanes per parameter: lane j sums
-// the slices j, j+16, ... , then the 16 partial sums are combined in a fixed butterfly order -- deterministic, and
-// enough threads in flight to hide the latency of a thousand-slice sum (small batches run many node-split waves).
+// dtheta[i] = sum_w partials[w][i]  (+ first-layer slices from the dw0 partials).  A block owns 32 consecutive parameters
+// (one 128-byte row segment per slice: coalesced) and splits the slices over 8 phases: thread (phase, i) sums the slices phase,
+// phase + 8, ..., then the 8 phase sums are combined through LDS in a fixed order -- deterministic, and enough loads in flight to
+// hide the latency of a thousand-slice sum (small batches run many node-split waves).
 __global__ __launch_bounds__(256) void cc_bwd_reduce_kernel(const float* __restrict__ partials, int nparts, int n_params,
                                                             const float* __restrict__ p0, int nparts0, int E, int H1,
                                                             int poffW0, int poffb0, float* __restrict__ dtheta) {
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int j = threadIdx.x & 15;
+    __shared__ float red[8][33];
+    const int il = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + il;
     const bool ok = i < n_params;
     float s = 0.f;
     if (ok) {
-        for (int w = j; w < nparts; w += 16) s += partials[(size_t)w * n_params + i];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int w = ph;
+        for (; w + 24 < nparts; w += 32) {
+            s0 += partials[(size_t)w * n_params + i];
+            s1 += partials[(size_t)(w + 8) * n_params + i];
+            s2 += partials[(size_t)(w + 16) * n_params + i];
+            s3 += partials[(size_t)(w + 24) * n_params + i];
+        }
+        for (; w < nparts; w += 8) s0 += partials[(size_t)w * n_params + i];
+        s = (s0 + s1) + (s2 + s3);
         // is i an entry of W0[:,1:] or b0 ?  those come from the dw0 partials
         int o = -1;
         if (i >= poffW0 && i < poffW0 + H1 * (1 + E)) {
@@ -458,12 +526,21 @@ __global__ __launch_bounds__(256) void cc_bwd_reduce_kernel(const float* __restr
         }
         if (o >= 0) {
             const int nout = H1 * (E + 1);
-            for (int w = j; w < nparts0; w += 16) s += p0[(size_t)w * nout + o];
+            float t0 = 0.f, t1 = 0.f;
+            int w2 = ph;
+            for (; w2 + 8 < nparts0; w2 += 16) { t0 += p0[(size_t)w2 * nout + o]; t1 += p0[(size_t)(w2 + 8) * nout + o]; }
+            for (; w2 < nparts0; w2 += 8) t0 += p0[(size_t)w2 * nout + o];
+            s += t0 + t1;
         }
     }
+    red[ph][il] = s;
+    __syncthreads();
+    if (ph == 0 && ok) {
+        float v = red[0][il];
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
-    if (ok && j == 0) dtheta[i] = s;
+        for (int k = 1; k < 8; ++k) v += red[k][il];
+        dtheta[i] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -584,10 +661,13 @@ static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan
     pl->nwaves = pl->nblocks * pl->wpb;
     a.ns = 1;
     const int H1 = net->widths[1];
-    pl->chunk0 = 256;
-    while (pl->chunk0 > 16 && (size_t)pl->chunk0 * (H1 + E + 1) * sizeof(float) > 96 * 1024) pl->chunk0 /= 2;
+    pl->chunk0 = 64;
+    while (pl->chunk0 > 16 && dw0_lds_floats(pl->chunk0, H1, E) * sizeof(float) > 32 * 1024) pl->chunk0 /= 2;
     while (pl->chunk0 > 16 && a.NI / pl->chunk0 < 2LL * umnn_num_cus()) pl->chunk0 /= 2;     // small batches: more, smaller chunks
-    pl->nparts0 = (int)((a.NI + pl->chunk0 - 1) / pl->chunk0);
+    {   // persistent blocks (four per CU), each accumulating its chunks in registers: at most that many partial slices
+        const long long nchunks = (a.NI + pl->chunk0 - 1) / pl->chunk0, cap = 4LL * umnn_num_cus();
+        pl->nparts0 = (int)(nchunks < cap ? nchunks : cap);
+    }
     long long o = 0;
     pl->ws_partials = o; o += (long long)pl->nwaves * a.n_params * 4; o = (o + 255) & ~255LL;
     pl->ws_dc = o; o += a.NI * H1 * 4 * pl->ns; o = (o + 255) & ~255LL;
@@ -722,10 +802,14 @@ extern "C" int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const
         umnn_note_launch("cc_bwd_dh");
     }
     if (dtheta) {
-        const size_t sm = (size_t)pl.chunk0 * (H1 + E + 1) * sizeof(float);
-        if (int rc = umnn_allow_lds((const void*)cc_bwd_dw0_kernel, sm)) return rc;
-        hipLaunchKernelGGL(cc_bwd_dw0_kernel, dim3(pl.nparts0), dim3(256), sm, stream, a.dc, h, p0, a.NI, d, E, H1, pl.chunk0, a.h_bf16);
-        hipLaunchKernelGGL(cc_bwd_reduce_kernel, dim3((a.n_params + 15) / 16), dim3(256), 0, stream,
+        const size_t sm = dw0_lds_floats(pl.chunk0, H1, E) * sizeof(float);
+        const int tiles_per_wave = (((H1 + 15) / 16) * ((E + 1 + 15) / 16) + 3) / 4;
+        auto dw0 = tiles_per_wave <= 2 ? cc_bwd_dw0_kernel<2> : tiles_per_wave <= 4 ? cc_bwd_dw0_kernel<4> : cc_bwd_dw0_kernel<10>;
+        const int per_launch = 4 * (tiles_per_wave <= 2 ? 2 : tiles_per_wave <= 4 ? 4 : 10);
+        if (int rc = umnn_allow_lds((const void*)dw0, sm)) return rc;
+        for (int tb = 0; tb < 4 * tiles_per_wave; tb += per_launch)
+            hipLaunchKernelGGL(dw0, dim3(pl.nparts0), dim3(256), sm, stream, a.dc, h, p0, a.NI, d, E, H1, pl.chunk0, a.h_bf16, tb);
+        hipLaunchKernelGGL(cc_bwd_reduce_kernel, dim3((a.n_params + 31) / 32), dim3(256), 0, stream,
                            a.partials, pl.nwaves, a.n_params, p0, pl.nparts0, E, H1, a.poffW[0], a.poffb[0], dtheta);
         umnn_note_launch("cc_bwd_reduce");
     }
