@@ -112,9 +112,12 @@ int umnn_flow_stack_block_forward_io(const umnn_mlp* net, const umnn_io* io, con
                                      const float* scaling, const float* cc_w, const float* cc_s, int nb_steps,
                                      long long B, int d, int E, int reverse_z, const void* log_jac_in,
                                      void* z, void* log_jac, void* f_x, void* f_x0, void* stream);
+/* umnn_cc_backward_io also takes inv_f (io may be null = fp32 storage): the backward of an integral of 1/f,
+ * ParallelNeuralIntegral.apply(..., inv_f=True) -- d_theta and d_h differentiate 1/f (computeIntegrand, ParallelNeuralIntegral.py:70-72),
+ * d_x / d_x0 keep f(x) g and -f(x0) g exactly as the reference's backward returns them (:117-123). */
 int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const void* x0, const void* x, const void* h,
                         const void* g, const void* g_fx,
-                        const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
+                        const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E, int inv_f,
                         void* dx0, void* dx, void* dh, float* dtheta,
                         void* workspace, long long workspace_bytes, void* stream);
 

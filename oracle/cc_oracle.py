@@ -180,8 +180,11 @@ def integrate_sequential(net, x0, x, h, nb_steps):
     return z * (xT - x0) / dt(2)
 
 
-def integrate_backward(net, x0, x, h, nb_steps, g):
+def integrate_backward(net, x0, x, h, nb_steps, g, inv_f=False):
     """Gradients the reference's custom backward returns for cotangent g [B,d].
+
+    inv_f (ParallelNeuralIntegral.py:70-72): d_theta and d_h differentiate 1/f, i.e. the node cotangent is
+    multiplied by -1/f^2; the Leibniz terms keep f itself (both branches of :120-123 are identical).
 
     d_theta, d_h: VJP of f at every node with cotangent g*(xT-x0)/2*w_k
     (ParallelNeuralIntegral.py:70-71,91-94).  d_x = f(x;h)*g, d_x0 = -f(x0;h)*g
@@ -201,7 +204,11 @@ def integrate_backward(net, x0, x, h, nb_steps, g):
     rows = rows_from(t.reshape(B * n1, d), hs, d)                         # [B*n1*d, 1+E]
     _, pres, acts = mlp_rows(net, rows, keep=True)
     L = len(net.Ws)
-    delta = (cot.reshape(-1) * _out_grad(pres[-1][:, 0], net.out_act))[:, None]   # [R,1]
+    dout = cot.reshape(-1) * _out_grad(pres[-1][:, 0], net.out_act)
+    if inv_f:
+        fval = _out(pres[-1][:, 0], net.out_act)
+        dout = -dout / (fval * fval)
+    delta = dout[:, None]                                                 # [R,1]
     dWs, dbs = [None] * L, [None] * L
     for l in range(L - 1, -1, -1):
         dWs[l] = delta.T @ acts[l]

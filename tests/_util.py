@@ -17,6 +17,10 @@ def g2_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "g2_*.npz")))
 
 
+def g7_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "g7_*.npz")))
+
+
 def g4_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "g4_*.npz")))
 

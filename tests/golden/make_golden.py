@@ -204,11 +204,48 @@ def g6():
     save("g6_invert", **arrs)
 
 
+# ------------------------------------------------- G7 inv_f = True through the operator (forward + custom backward)
+INV_CASES = [
+    # name, d, E, hidden, n, B, act, weight scale, x0 nonzero
+    ("power_d6", 6, 30, [50] * 4, 100, 12, "ELU", 2.0, True),
+    ("toy_d2", 2, 10, [100] * 4, 50, 12, "ELU", 1.5, False),
+    ("mnist_mixed_d8", 8, 30, [100, 50, 50, 50, 50], 50, 4, "ELU", 1.5, False),
+    ("sigmoid_d4", 4, 3, [30, 30, 30], 25, 8, "Sigmoid", 2.0, True),
+    ("narrow_d3", 3, 2, [20, 20], 20, 10, "ELU", 1.5, True),
+]
+
+
+def g7():
+    """ParallelNeuralIntegral.apply(..., inv_f=True) and its backward (ParallelNeuralIntegral.py:58-59,70-72,110-123): the
+    parameter / embedding gradients differentiate 1/f, the Leibniz terms keep f (both branches of :120-123 are the same)."""
+    for seed, (name, d, E, hid, n, B, act, wscale, x0nz) in enumerate(INV_CASES):
+        torch.manual_seed(7000 + seed)
+        net = IntegrandNetwork(d, 1 + E, hid, 1, act_func=act)
+        with torch.no_grad():
+            for p in net.net:
+                if isinstance(p, torch.nn.Linear):
+                    p.weight.mul_(wscale)
+                    p.bias.mul_(wscale)
+        x = torch.randn(B, d) * 2.0
+        x0 = torch.randn(B, d) * 0.7 if x0nz else torch.zeros(B, d)
+        h = torch.randn(B, E * d)
+        g = torch.randn(B, d)
+        arrs = dict(d=d, E=E, n=n, hidden=np.array(hid), act=act, x=x, x0=x0, h=h, g=g)
+        lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+        for l, m in enumerate(lin):
+            arrs[f"W{l}"], arrs[f"b{l}"] = m.weight, m.bias
+        net.zero_grad()
+        x0r, xr, hr = x0.clone().requires_grad_(), x.clone().requires_grad_(), h.clone().requires_grad_()
+        out = ParallelNeuralIntegral.apply(x0r, xr, net, flat(net.parameters()), hr, n, True)
+        out.backward(g)
+        arrs["F_inv"], arrs["dx0"], arrs["dx"], arrs["dh"] = out, x0r.grad, xr.grad, hr.grad
+        arrs["dtheta"] = flat([p.grad for p in net.parameters()])
+        save("g7_invf_" + name, **arrs)
+
+
 if __name__ == "__main__":
-    g1()
-    g23()
-    g4()
-    g5()
-    g6()
+    todo = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7"]      # (name a subset to leave the other fixtures untouched)
+    for name in todo:
+        globals()[name]()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print("total fixture bytes", tot)

@@ -49,6 +49,38 @@ def test_backward_matches_golden(name, dev, bwd_precision):
     assert U.scaled_err(dth.cpu().numpy(), G["dtheta_seq"]) < TOL
 
 
+@pytest.mark.parametrize("name", U.g7_names())
+def test_inverse_integrand_backward_matches_golden(name, dev, bwd_precision):
+    """ParallelNeuralIntegral.apply(..., inv_f=True).backward on the HIP kernels (one-pass bf16 / fp32, 100-wide, the three-stage
+    family for the 100-50-50-50-50 net) against the reference's own output: d_theta / d_h of 1/f, Leibniz terms of f
+    (ParallelNeuralIntegral.py:58-59,70-72,110-123)."""
+    import umnn_amd
+    from umnn_amd import integral as I, _lib
+    G = U.load(name)
+    net = build_integrand(G, dev)
+    x0 = t(G["x0"], dev).requires_grad_()
+    x = t(G["x"], dev).requires_grad_()
+    h = t(G["h"], dev).requires_grad_()
+    before = _lib.lib().umnn_launch_count()
+    out = I.ParallelNeuralIntegral.apply(x0, x, net, I._flatten(net.parameters()), h, int(G["n"]), True)
+    out.backward(t(G["g"], dev))
+    torch.cuda.synchronize()
+    from umnn_amd.nets import mlp_spec
+    if I._hip_backward_ok(mlp_spec(net), x, h):      # (fp32 mode sends the 100-50-50-50-50 net's gradient to the ATen chain by policy)
+        assert umnn_amd.path_taken() == "hip" and _lib.lib().umnn_launch_count() >= before + 3
+        assert "cc_bwd" in _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+    dth = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert U.rel_err(out.detach().cpu().numpy(), G["F_inv"]) < TOL
+    assert U.rel_err(x0.grad.cpu().numpy(), G["dx0"]) < TOL and U.rel_err(x.grad.cpu().numpy(), G["dx"]) < TOL
+    assert U.scaled_err(h.grad.cpu().numpy(), G["dh"]) < TOL
+    assert U.scaled_err(dth.cpu().numpy(), G["dtheta"]) < TOL
+    # the (d_theta, d_h) form of integrate(), which the reference's backward consumes
+    n = int(G["n"])
+    with torch.no_grad():
+        dth2, dh2 = I.integrate(x0.detach(), n, (x.detach() - x0.detach()) / n, net, h.detach(), True, t(G["g"], dev), True)
+    assert U.scaled_err(dth2.cpu().numpy(), G["dtheta"]) < TOL and U.scaled_err(dh2.reshape(h.shape).cpu().numpy(), G["dh"]) < TOL
+
+
 @pytest.mark.parametrize("name", ["g2_power_d6_w2", "g2_toy_d2_w2", "g2_sigmoid_d4", "g2_mnist_mixed_d8", "g2_odd_n_d3"])
 def test_backward_with_jacobian_cotangent(name, dev):
     """g_fx (cotangent of the f(x;h) output): VJP at node 0 incl. d f/d x, against the oracle's manual backprop."""
@@ -457,17 +489,18 @@ def test_integration_md_ctypes_stub_runs_as_written(dev):
     x = torch.randn(B, d, device=dev)
     h = torch.randn(B, E * d, device=dev)
     g = torch.randn(B, d, device=dev)
-    outs = []
-    for Op in (Stub, umnn_amd.ParallelNeuralIntegral):
-        xr, hr = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
-        flat = torch.cat([p.reshape(-1) for p in net.parameters()]).detach().requires_grad_(True)
-        for p in net.parameters():
-            p.grad = None
-        F = Op.apply(x0, xr, net, flat, hr, n, False)
-        F.backward(g)
-        torch.cuda.synchronize()
-        # the stub returns d_theta for the flat_params argument (the reference's convention); the package fills both
-        dth = flat.grad if flat.grad is not None else torch.cat([p.grad.reshape(-1) for p in net.parameters()])
-        outs.append((F.detach(), xr.grad, hr.grad, dth))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for inv_f in (False, True):
+        outs = []
+        for Op in (Stub, umnn_amd.ParallelNeuralIntegral):
+            xr, hr = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
+            flat = torch.cat([p.reshape(-1) for p in net.parameters()]).detach().requires_grad_(True)
+            for p in net.parameters():
+                p.grad = None
+            F = Op.apply(x0, xr, net, flat, hr, n, inv_f)
+            F.backward(g)
+            torch.cuda.synchronize()
+            # the stub returns d_theta for the flat_params argument (the reference's convention); the package fills both
+            dth = flat.grad if flat.grad is not None else torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+            outs.append((F.detach(), xr.grad, hr.grad, dth))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)

@@ -51,6 +51,19 @@ def test_backward_matches_reference(name):
         assert U.scaled_err(flat, G[f"dtheta_{tag}"]) < 5e-5
 
 
+@pytest.mark.parametrize("name", U.g7_names())
+def test_inverse_integrand_operator_matches_reference(name):
+    """inv_f=True through ParallelNeuralIntegral.apply and its backward (ParallelNeuralIntegral.py:58-59,70-72,110-123)."""
+    G = U.load(name)
+    net = U.net_from_g2(G)
+    n = int(G["n"])
+    assert U.rel_err(O.integrate_parallel(net, G["x0"], G["x"], G["h"], n, inv_f=True), G["F_inv"]) < TOL
+    dx0, dx, dh, _, _, flat = O.integrate_backward(net, G["x0"], G["x"], G["h"], n, G["g"], inv_f=True)
+    assert U.rel_err(dx0, G["dx0"]) < TOL and U.rel_err(dx, G["dx"]) < TOL
+    assert U.scaled_err(dh, G["dh"]) < 5e-5
+    assert U.scaled_err(flat, G["dtheta"]) < 5e-5
+
+
 @pytest.mark.parametrize("name", U.g2_names()[:4])
 def test_fp64_oracle_agrees(name):
     """fp32 oracle vs the same algorithm in fp64: the noise floor the 1e-4 tolerance sits on."""

@@ -53,7 +53,7 @@ SIGNATURES = {
                                                         ctypes.c_int, _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
                                                         _fp, _fp, _fp, _fp, _fp]),
     "umnn_cc_backward_io": (ctypes.c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(IoDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp,
-                                           ctypes.c_int, _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _ll, _fp]),
+                                           ctypes.c_int, _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _ll, _fp]),
     "umnn_flow_ll_block_forward": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                                   _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   _fp, _fp, _fp, _fp, _fp]),

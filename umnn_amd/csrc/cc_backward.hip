@@ -263,7 +263,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_kernel(const BwdArgs a) 
             }
 
             // ---------------- backward sweep ----------------
-            const float cot = fmaf(cotbase, wk, k == 0 ? gfxv : 0.f);
+            const float invs = a.inv_f ? -__frcp_rn(f * f) : 1.f;
+            const float cot = fmaf(cotbase * invs, wk, k == 0 ? gfxv : 0.f);
             const float dout = cot * fp;
             f32x4 delta[TMAX];
 #pragma unroll
@@ -712,13 +713,13 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
                                 const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
                                 float* dx0, float* dx, float* dh, float* dtheta,
                                 void* workspace, long long workspace_bytes, void* stream_) {
-    return umnn_cc_backward_io(net, nullptr, x0, x, h, g, g_fx, cc_w, cc_s, nb_steps, B, d, E, dx0, dx, dh, dtheta,
+    return umnn_cc_backward_io(net, nullptr, x0, x, h, g, g_fx, cc_w, cc_s, nb_steps, B, d, E, 0, dx0, dx, dh, dtheta,
                                workspace, workspace_bytes, stream_);
 }
 
 extern "C" int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const void* x0_, const void* x_, const void* h_,
                                    const void* g_, const void* g_fx_,
-                                   const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
+                                   const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E, int inv_f,
                                    void* dx0_, void* dx_, void* dh_, float* dtheta,
                                    void* workspace, long long workspace_bytes, void* stream_) {
     const float *x0 = (const float*)x0_, *x = (const float*)x_, *h = (const float*)h_, *g = (const float*)g_, *g_fx = (const float*)g_fx_;
@@ -743,6 +744,7 @@ extern "C" int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const
     a.x0 = x0; a.x = x; a.h = h; a.g = g; a.gfx = g_fx; a.ccw = cc_w; a.ccs = cc_s;
     a.dx0 = dx0; a.dx = dx; a.n = nb_steps;
     a.x_bf16 = io && io->x_dtype == UMNN_DTYPE_BF16; a.h_bf16 = io && io->h_dtype == UMNN_DTYPE_BF16;
+    a.inv_f = inv_f != 0;
     a.partials = (float*)(ws + pl.ws_partials);
     a.dc = (float*)(ws + pl.ws_dc);
     float* p0 = (float*)(ws + pl.ws_p0);

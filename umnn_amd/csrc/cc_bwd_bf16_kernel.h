@@ -408,7 +408,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
             }
 
             // ---------------- backward sweep ----------------
-            const float cot = fmaf(cotbase, wk, k == 0 ? gfxv : 0.f);
+            const float invs = a.inv_f ? -__frcp_rn(f * f) : 1.f;
+            const float cot = fmaf(cotbase * invs, wk, k == 0 ? gfxv : 0.f);
             const float dout = cot * fp;
             f32x4 delta[BT];
 #pragma unroll

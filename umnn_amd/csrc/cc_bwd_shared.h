@@ -20,6 +20,8 @@ struct BwdArgs {
     float* dc;                      // [NI][H1] (EDGE pass)
     float* partials;                // [nwaves][n_params]
     int x_bf16, h_bf16;             // storage of x, x0, g, g_fx, dx, dx0 / of h (and dh): 0 fp32, 1 bf16
+    int inv_f;                      // the quadrature integrated 1/f (ParallelNeuralIntegral.py:58-59,70-72): d_theta and d_h
+                                    // differentiate 1/f -- node cotangent x (-1/f^2); the Leibniz terms keep f (:120-123)
     long long NI;
     int d, E, n;
     unsigned ngroups;               // tiles of 16 integrals

@@ -301,9 +301,9 @@ def hip_flow_ll_block(spec, x, h, scaling, nb_steps, reverse_z, first, last, ll,
     return z
 
 
-def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True)):
+def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True), inv_f=False):
     """-> (dx0, dx, dh, dtheta_flat); entries are None where need[...] is False.  dx0/dx come back in x's dtype, dh in
-    h's, dtheta in fp32 (the weights' dtype)."""
+    h's, dtheta in fp32 (the weights' dtype).  inv_f: the operator integrated 1/f (ParallelNeuralIntegral.py:58-59,70-72)."""
     lib = _lib.lib()
     B, d, E = _shape(spec, x, h)
     x_dtype, h_dtype = x.dtype, h.dtype
@@ -320,13 +320,14 @@ def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True
         nbytes = lib.umnn_cc_backward_workspace_bytes(ctypes.byref(desc), B, d, E)
         ws = torch.empty(max(int(nbytes), 4), device=x.device, dtype=torch.uint8)
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        if io is None:
+        if io is None and not inv_f:
             rc = lib.umnn_cc_backward(ctypes.byref(desc), _ptr(x0), _ptr(x), _ptr(h), _ptr(g), _ptr(g_fx),
                                       _ptr(w), _ptr(s), int(nb_steps), B, d, E,
                                       _ptr(dx0), _ptr(dx), _ptr(dh), _ptr(dtheta), _ptr(ws), int(nbytes), stream)
         else:
-            rc = lib.umnn_cc_backward_io(ctypes.byref(desc), ctypes.byref(io), _ptr(x0), _ptr(x), _ptr(h), _ptr(g), _ptr(g_fx),
-                                         _ptr(w), _ptr(s), int(nb_steps), B, d, E,
+            rc = lib.umnn_cc_backward_io(ctypes.byref(desc), ctypes.byref(io) if io is not None else None,
+                                         _ptr(x0), _ptr(x), _ptr(h), _ptr(g), _ptr(g_fx),
+                                         _ptr(w), _ptr(s), int(nb_steps), B, d, E, int(bool(inv_f)),
                                          _ptr(dx0), _ptr(dx), _ptr(dh), _ptr(dtheta), _ptr(ws), int(nbytes), stream)
     _lib.check(rc, "umnn_cc_backward")
     _state.path = "hip"
@@ -470,8 +471,8 @@ def integrate(x0, nb_steps, step_sizes, integrand, h, compute_grad=False, x_tot=
             return aten_forward(integrand, x0, x, h, nb_steps, inv_f)
         with torch.no_grad():
             return aten_forward(integrand, x0, x, h, nb_steps, inv_f)
-    if _use_hip(spec, x) and not inv_f and _hip_backward_ok(spec, x, h):
-        _, _, dh, dtheta = hip_backward(spec, x0, x, h, x_tot, None, nb_steps, need=(False, False, True, True))
+    if _use_hip(spec, x) and _hip_backward_ok(spec, x, h):
+        _, _, dh, dtheta = hip_backward(spec, x0, x, h, x_tot, None, nb_steps, need=(False, False, True, True), inv_f=inv_f)
         return dtheta, dh
     return aten_backward(integrand, x0, x, h, x_tot, nb_steps, inv_f)
 
@@ -490,9 +491,9 @@ def _op_forward(ctx, x0, x, integrand, h, nb_steps, inv_f):
 def _op_backward(ctx, grad_output):
     x0, x, h = ctx.saved_tensors
     integrand, nb_steps, inv_f, spec = ctx.integrand, ctx.nb_steps, ctx.inv_f, ctx.spec
-    if _use_hip(spec, x) and not inv_f and _hip_backward_ok(spec, x, h):
+    if _use_hip(spec, x) and _hip_backward_ok(spec, x, h):
         need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[4], ctx.needs_input_grad[3])
-        dx0, dx, dh, dtheta = hip_backward(spec, x0, x, h, grad_output, None, nb_steps, need)
+        dx0, dx, dh, dtheta = hip_backward(spec, x0, x, h, grad_output, None, nb_steps, need, inv_f=inv_f)
         return dx0, dx, dtheta, dh
     dtheta, dh = aten_backward(integrand, x0, x, h, grad_output, nb_steps, inv_f)
     with torch.no_grad():
