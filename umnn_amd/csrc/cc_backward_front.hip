@@ -171,7 +171,9 @@ __device__ __forceinline__ void front_gemm(const unsigned short* base, int lane,
 }
 
 // ---------------------------------------------------------------------------------------------- stage A
-template <int T1>
+// NL2 > 0: the live-register count of hidden layer 2 at compile time (13 = widths 48..51) -- the per-register guards of the HBM
+// fragments then fold away (as runtime conditions each of them is a branch); 0 = read it from the arguments.
+template <int T1, int NL2>
 __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_fwd_kernel(const FrontArgs fa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const BwdArgs& a = fa.b;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_fwd_kernel(const Front
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, p = lane & 15;
     const int H1 = m.width[1];
-    const int E = a.E, d = a.d, n = a.n, nl2 = fa.nl2;
+    const int E = a.E, d = a.d, n = a.n, nl2 = NL2 > 0 ? NL2 : fa.nl2;
     const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
     unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
     stage_g1_image<T1, false, NPF>(m, lds16, tid, blockDim.x);
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_fwd_kernel(const Front
 }
 
 // ---------------------------------------------------------------------------------------------- stage C
-template <int T1>
+template <int T1, int NL2>
 __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const FrontArgs fa) {
     constexpr int KS1 = (T1 + 1) / 2;          // K-steps of 32 hidden-1 features (the last one half empty when T1 is odd)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, p = lane & 15;
     const int H1 = m.width[1], H2 = m.width[2];
-    const int E = a.E, d = a.d, n = a.n, nl2 = fa.nl2;
+    const int E = a.E, d = a.d, n = a.n, nl2 = NL2 > 0 ? NL2 : fa.nl2;
     const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
     unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
     stage_g1_image<T1, true, NPB>(m, lds16, tid, blockDim.x);
@@ -310,11 +312,19 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
 #pragma unroll
         for (int t = 0; t < T1; ++t) dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         const size_t frag0 = (size_t)item * (size_t)(n + 1) * nl2 * 64 + lane;
+        // delta_2 of node k, register j: fetched UNCONDITIONALLY (register index clamped, value masked afterwards) -- a guarded
+        // load per register turns into a branch and a full memory wait each, which is what this kernel used to spend half its
+        // time in -- and one node ahead
+        auto ld_d2 = [&](int k, int t, int r) {
+            const int j = 4 * t + r, jj = j < nl2 ? j : nl2 - 1;
+            const float v = fa.d2[frag0 + ((size_t)k * nl2 + jj) * 64];
+            return j < nl2 ? v : 0.f;
+        };
         f32x4 dnext[BT];
 #pragma unroll
         for (int t = 0; t < BT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dnext[t][r] = 4 * t + r < nl2 ? fa.d2[frag0 + (size_t)(4 * t + r) * 64] : 0.f;
+            for (int r = 0; r < 4; ++r) dnext[t][r] = ld_d2(0, t, r);
 
         for (int k = 0; k <= n; ++k) {
             const float u = a.ccs[k] + 1.f;
@@ -326,12 +336,12 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
                 for (int r = 0; r < 4; ++r) a1[t][r] = hidden_act_f(fmaf(w1x[t][r], tk, c[t][r]), slope);
 #pragma unroll
             for (int t = 0; t < BT; ++t) delta2[t] = dnext[t];
-            if (k < n) {
+            {
+                const int kn = k < n ? k + 1 : n;         // (the last node re-reads itself: harmless, and no branch)
 #pragma unroll
                 for (int t = 0; t < BT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (4 * t + r < nl2) dnext[t][r] = fa.d2[frag0 + ((size_t)(k + 1) * nl2 + 4 * t + r) * 64];
+                    for (int r = 0; r < 4; ++r) dnext[t][r] = ld_d2(kn, t, r);
             }
             // ---- packed two-piece fragments: delta_2 as a BFrag (two K-steps), a_1 as KS1 K-steps
             BFrag<NPB> bd;
@@ -453,10 +463,11 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
 // ------------------------------------------------------------------------------------------ host side
 typedef void (*front_kernel_t)(const FrontArgs);
 typedef void (*mid_kernel_t)(const BwdBf16Args);
-struct FrontVariant { int t1; front_kernel_t fwd, bwd; };
+struct FrontVariant { int t1, nl2; front_kernel_t fwd, bwd; };
+#define FRONT_VARIANT(T, N) {T, N, cc_front_fwd_kernel<T, N>, cc_front_bwd_kernel<T, N>}
 static const FrontVariant kFrontVariants[] = {
-    {5, cc_front_fwd_kernel<5>, cc_front_bwd_kernel<5>}, {6, cc_front_fwd_kernel<6>, cc_front_bwd_kernel<6>},
-    {7, cc_front_fwd_kernel<7>, cc_front_bwd_kernel<7>}, {8, cc_front_fwd_kernel<8>, cc_front_bwd_kernel<8>},
+    FRONT_VARIANT(5, 13), FRONT_VARIANT(6, 13), FRONT_VARIANT(7, 13), FRONT_VARIANT(8, 13),
+    FRONT_VARIANT(5, 0), FRONT_VARIANT(6, 0), FRONT_VARIANT(7, 0), FRONT_VARIANT(8, 0),
 };
 struct MidVariant { int lh, nrl; mid_kernel_t fn; const char* name; };
 #define MID_VARIANT(LHH, NR) { LHH, NR, cc_bwd_bf16_kernel<LHH, true, NR, true>, "cc_bwd_bf16<L=" #LHH ",EDGE=1,LIVE=" #NR ",FRONT>" }
@@ -492,7 +503,7 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
     const int T1 = m.t_out[1], LH = L - 1;
     const int nl2 = (m.width[2] + 1 + 3) / 4;
     const FrontVariant* fv = nullptr;
-    for (const FrontVariant& v : kFrontVariants) if (v.t1 == T1) fv = &v;
+    for (const FrontVariant& v : kFrontVariants) if (v.t1 == T1 && v.nl2 == (nl2 == 13 ? 13 : 0)) fv = &v;
     int nrl = m.ks_in[2];
     for (int l = 2; l <= L; ++l) if (m.ks_in[l] != nrl) nrl = 0;
     if (nrl != 13) nrl = 0;

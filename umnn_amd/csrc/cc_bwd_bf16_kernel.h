@@ -303,15 +303,21 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
         float fxv = 0.f, fx0v = 0.f, dfdt = 0.f;
         // FRONT: this tile's fragments in HBM, [node][register][lane]; the next node's pre-activations are fetched one
         // node ahead (a global load costs ~1 us here against ~5 us of work per node)
-        const size_t frag0 = FRONT ? (size_t)(grp - args.grp0) * (size_t)(n + 1) * args.nl2 * 64 + lane : 0;
+        const int nl2 = NRL > 0 ? NRL : args.nl2;      // (LIVE=13 variants: a compile-time count, the guards below fold away)
+        const size_t frag0 = FRONT ? (size_t)(grp - args.grp0) * (size_t)(n + 1) * nl2 * 64 + lane : 0;
+        // (FRONT) z_2 of node k, register j: unconditional loads (register index clamped, value masked afterwards) -- guarded ones
+        // become a branch and a memory wait per register
+        auto ld_z2 = [&](int k, int t, int r) {
+            const int j = 4 * t + r, jj = j < nl2 ? j : nl2 - 1;
+            const float v = args.z2[frag0 + ((size_t)k * nl2 + jj) * 64];
+            return j < nl2 ? v : 0.f;
+        };
         f32x4 znext[BT];
         if constexpr (FRONT) {
 #pragma unroll
             for (int t = 0; t < BT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    znext[t][r] = (4 * t + r < NLIVE && 4 * t + r < args.nl2)
-                                      ? args.z2[frag0 + ((size_t)k_lo * args.nl2 + 4 * t + r) * 64] : 0.f;
+                for (int r = 0; r < 4; ++r) znext[t][r] = 4 * t + r < NLIVE ? ld_z2(k_lo, t, r) : 0.f;
         }
 
         for (int k = k_lo; k < k_hi; ++k) {
@@ -326,13 +332,13 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
                 for (int t = 0; t < BT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) act[t][r] = 4 * t + r < NLIVE ? hidden_act_f(znext[t][r], slope) : 0.f;
-                if (k + 1 < k_hi) {
+                {
+                    const int kn = k + 1 < k_hi ? k + 1 : k;        // (the last node re-reads itself: no branch)
 #pragma unroll
                     for (int t = 0; t < BT; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (4 * t + r < NLIVE && 4 * t + r < args.nl2)
-                                znext[t][r] = args.z2[frag0 + ((size_t)(k + 1) * args.nl2 + 4 * t + r) * 64];
+                            if (4 * t + r < NLIVE) znext[t][r] = ld_z2(kn, t, r);
                 }
             } else {
 #pragma unroll
@@ -379,8 +385,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
                         // kernel propagated through the wide first hidden layer
                         float dz = w1x[t][r];
                         if constexpr (FRONT)
-                            dz = (4 * t + r < args.nl2 && args.tz2)
-                                     ? args.tz2[((size_t)(grp - args.grp0) * args.nl2 + 4 * t + r) * 64 + lane] : 0.f;
+                            dz = (4 * t + r < nl2 && args.tz2)
+                                     ? args.tz2[((size_t)(grp - args.grp0) * nl2 + 4 * t + r) * 64 + lane] : 0.f;
                         ta[t][r] = 4 * t + r < NLIVE ? dz * act_grad(asave[0], t, r, slope) : 0.f;
                     }
 #pragma unroll
@@ -462,8 +468,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
                 for (int t = 0; t < BT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (4 * t + r < NLIVE && 4 * t + r < args.nl2)
-                            args.d2[frag0 + ((size_t)k * args.nl2 + 4 * t + r) * 64] = delta[t][r];
+                        if (4 * t + r < NLIVE && 4 * t + r < nl2)
+                            args.d2[frag0 + ((size_t)k * nl2 + 4 * t + r) * 64] = delta[t][r];
             } else if (EDGE) {
 #pragma unroll
                 for (int t = 0; t < BT; ++t)
