@@ -7,9 +7,12 @@ typedef void (*fwd_bf16_kernel_t)(const FwdBf16Args);
 struct Bf16Variant { int tmax, nparts, p, exact, nrl, pipe; fwd_bf16_kernel_t fn; const char* name; };
 // first hidden layer T1 = 5..8 tiles, every other hidden layer at most four (zero-padded to four): MNISTExperiment's
 // 31-100-50-50-50-50-1.  Shape-exact: layer 1's GEMM contracts over T1 tiles, the others over four.
-struct Bf16WideFirst { int t1; fwd_bf16_kernel_t fn; const char* name; };
-#define BF16_WIDE_FIRST(T) { T, cc_fwd_bf16_kernel<T, 2, 1, true, 0, false, false, 4>, "cc_fwd_bf16<T1=" #T ",TREST=4,PARTS=2,P=1,EXACT=1>" }
-static const Bf16WideFirst kBf16WideFirst[] = { BF16_WIDE_FIRST(5), BF16_WIDE_FIRST(6), BF16_WIDE_FIRST(7), BF16_WIDE_FIRST(8) };
+// LIVE=13: every later layer 48..51 wide -- 13 live registers per lane and the merged five-K-step layout from layer 2 on.
+struct Bf16WideFirst { int t1, nrl, p; fwd_bf16_kernel_t fn; const char* name; };
+#define BF16_WIDE_FIRST(T, NR, PP) { T, NR, PP, cc_fwd_bf16_kernel<T, 2, PP, true, NR, false, false, 4>, "cc_fwd_bf16<T1=" #T ",TREST=4,PARTS=2,P=" #PP ",EXACT=1,LIVE=" #NR ">" }
+static const Bf16WideFirst kBf16WideFirst[] = { BF16_WIDE_FIRST(5, 13, 1), BF16_WIDE_FIRST(6, 13, 1), BF16_WIDE_FIRST(7, 13, 1), BF16_WIDE_FIRST(8, 13, 1),
+                                                BF16_WIDE_FIRST(5, 0, 1), BF16_WIDE_FIRST(6, 0, 1), BF16_WIDE_FIRST(7, 0, 1), BF16_WIDE_FIRST(8, 0, 1) };
+// (two point tiles per wave, P = 2: 260 registers = one wave per SIMD, 0.63 ms against 0.49 ms at the MNIST shape -- not instantiated)
 #define BF16_VARIANT(T, NP, PP, EX, NR) { T, NP, PP, EX, NR, 0, cc_fwd_bf16_kernel<T, NP, PP, (EX) != 0, NR>, "cc_fwd_bf16<T=" #T ",PARTS=" #NP ",P=" #PP ",EXACT=" #EX ",LIVE=" #NR ">" }
 #define BF16_PIPE_VARIANT(NP, PP, NR) { 4, NP, PP, 1, NR, 1, cc_fwd_bf16_kernel<4, NP, PP, true, NR, true>, "cc_fwd_bf16<T=4,PARTS=" #NP ",P=" #PP ",EXACT=1,LIVE=" #NR ",PIPE>" }
 static const Bf16Variant kBf16Variants[] = {
@@ -67,13 +70,18 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
                 ns = tiles16 * 4 <= slots ? 4 : tiles16 * 2 <= slots ? 2 : 1;
                 if (ns > nb_steps + 1) ns = 1;
             }
-            const size_t lds_bytes = ((size_t)args.f.m.lds_off[L] + (ns > 1 ? UMNN_WAVES_PER_BLOCK * 3 * 16 : 0)) * sizeof(float);
+            const int PW = 1;
+            const size_t lds_bytes = ((size_t)args.f.m.lds_off[L] + (ns > 1 ? UMNN_WAVES_PER_BLOCK * 3 * PW * 16 : 0)) * sizeof(float);
+            int nrest = a.m.ks_in[2];           // live registers of the later layers when they all agree (13 = widths 48..51)
+            for (int l = 2; l <= L; ++l) if (a.m.ks_in[l] != nrest) nrest = 0;
+            if (nrest != 13) nrest = 0;
             const Bf16WideFirst* pick = nullptr;
-            for (const Bf16WideFirst& v : kBf16WideFirst) if (v.t1 == T1) pick = &v;
+            for (const Bf16WideFirst& v : kBf16WideFirst) if (v.t1 == T1 && v.nrl == nrest && v.p == PW) pick = &v;
+            if (!pick) for (const Bf16WideFirst& v : kBf16WideFirst) if (v.t1 == T1 && v.nrl == nrest && v.p == 1) pick = &v;
             if (pick && lds_bytes <= 160 * 1024) {
                 if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
                 args.f.ns = ns;
-                args.f.ngroups = (unsigned)((a.NI + 15) / 16);
+                args.f.ngroups = (unsigned)((a.NI + 16 * pick->p - 1) / (16 * pick->p));
                 const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
                 const unsigned nblk = (args.f.ngroups + gpb - 1) / gpb;
                 umnn_prof_begin(stream);

@@ -36,7 +36,8 @@
 //   part 0:  k-slots 0-3 Whi of tile 2 (x ahi)  |  4: Whi, 5: Whi, 6: Wlo, 7: 0 of the lane group's tile-3 feature (x ahi, alo, ahi)
 //   part 1:  k-slots 0-3 Whi of tile 2 (x alo)  |  4-7 Wlo of tile 2 (x ahi)
 // and the kernels pack the B operands to match -- each lane group still supplies its own features only.
-template <int NPARTS, bool MERGE = false>
+// MERGE_FROM: first hidden layer whose image uses this layout (0 = none, 1 = every layer, 2 = all but the first: the wide-first family).
+template <int NPARTS, int MERGE_FROM = 0>
 __device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks32, const int* off16, const int* half_in,
                                                   unsigned short* lds16, int tid, int nthreads) {
     const int L = m.n_linear - 1;
@@ -62,7 +63,7 @@ __device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks
                 }
                 return v;
             };
-            if (MERGE && s == 1) {
+            if (MERGE_FROM > 0 && l >= MERGE_FROM && s == 1) {
                 const float v2 = wv(feat_of(2, j & 3, ln >> 4)), v3 = wv(feat_of(3, 0, ln >> 4));
                 const unsigned short h2 = bf16_rn_bits(v2), l2 = bf16_rn_bits(v2 - bf16_bits_to_f32(h2));
                 const unsigned short h3 = bf16_rn_bits(v3), l3 = bf16_rn_bits(v3 - bf16_bits_to_f32(h3));
@@ -144,8 +145,11 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
     static_assert(TREST == 0 || (EXACT && !PIPE && TREST < TMAX && (TREST & 1) == 0), "wide-first-layer variants: exact, plain loop");
     static_assert(!INV || (P == 1 && !PIPE), "inversion variants: plain loop, one tile per wave");
     constexpr int KSM = TMAX / 2;
-    constexpr int NLIVE = NRL > 0 ? NRL : 4 * TMAX;
+    // live registers per lane: of every layer, or (TREST > 0, wide-first family) all 4 * TMAX of layer 1 and NRL of the others
+    constexpr int NLIVE = (NRL > 0 && TREST == 0) ? NRL : 4 * TMAX;
+    constexpr int NREST = TREST > 0 ? (NRL > 0 ? NRL : 4 * TREST) : NLIVE;
     constexpr bool MERGE = EXACT && TMAX == 4 && NRL == 13 && NPARTS == 2 && TREST == 0;      // five K-steps per layer (see staging)
+    constexpr bool MERGE_REST = EXACT && TREST == 4 && NRL == 13 && NPARTS == 2;               // ... per layer from layer 2 on
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FwdArgs& a = args.f;
     const MlpDev& m = a.m;
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
     const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
     unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
 
-    stage_bf16_images<NPARTS, MERGE>(m, args.pl.ks32, args.pl.off16, args.pl.half_in, lds16, tid, UMNN_BLOCK);
+    stage_bf16_images<NPARTS, MERGE ? 1 : MERGE_REST ? 2 : 0>(m, args.pl.ks32, args.pl.off16, args.pl.half_in, lds16, tid, UMNN_BLOCK);
     __syncthreads();
 
     const int ns = a.ns;
@@ -486,6 +490,9 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 constexpr int OT = TREST > 0 ? TREST : TMAX;
                 constexpr int KSL = KT / 2;
                 constexpr bool HALFL = EXACT && (KT & 1);
+                constexpr int NIN = (TREST > 0 && !WIDE) ? NREST : NLIVE;      // live registers of the layer's input / output
+                constexpr int NOUT = TREST > 0 ? NREST : NLIVE;
+                constexpr bool MERGEL = MERGE || (MERGE_REST && !WIDE);
                 const int ks = EXACT ? KSL : args.pl.ks32[l], to = EXACT ? OT : m.t_out[l + 1];
                 // (uniform exact shapes: the image offset is (l - 1) x a compile-time stride -- no scalar load from the arguments)
                 constexpr int IMG_STRIDE = TMAX * (KSM * NPARTS * 512 + (TMAX & 1) * NPARTS * 256);
@@ -500,13 +507,13 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                         unsigned q0[NPARTS], q1[NPARTS], q2[NPARTS], q3[NPARTS];
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) q0[k2] = q1[k2] = q2[k2] = q3[k2] = 0u;
-                        if (8 * s + 0 < NLIVE) split_pair<NPARTS>(act[pt][2 * s][0], act[pt][2 * s][1], q0);
-                        if (8 * s + 2 < NLIVE) split_pair<NPARTS>(act[pt][2 * s][2], act[pt][2 * s][3], q1);
-                        if (8 * s + 4 < NLIVE) split_pair<NPARTS>(act[pt][2 * s + 1][0], act[pt][2 * s + 1][1], q2);
-                        if (8 * s + 6 < NLIVE) split_pair<NPARTS>(act[pt][2 * s + 1][2], act[pt][2 * s + 1][3], q3);
+                        if (8 * s + 0 < NIN) split_pair<NPARTS>(act[pt][2 * s][0], act[pt][2 * s][1], q0);
+                        if (8 * s + 2 < NIN) split_pair<NPARTS>(act[pt][2 * s][2], act[pt][2 * s][3], q1);
+                        if (8 * s + 4 < NIN) split_pair<NPARTS>(act[pt][2 * s + 1][0], act[pt][2 * s + 1][1], q2);
+                        if (8 * s + 6 < NIN) split_pair<NPARTS>(act[pt][2 * s + 1][2], act[pt][2 * s + 1][3], q3);
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) bf[pt][s][k2] = u32x4{q0[k2], q1[k2], q2[k2], q3[k2]};
-                        if constexpr (MERGE) {
+                        if constexpr (MERGEL) {
                             if (s == 1) {        // (tile 2 hi | tile-3 feature: hi, lo, hi, 0) and (tile 2 lo | tile 2 hi)
                                 bf[pt][1][0] = u32x4{q0[0], q1[0], q2[0] | (q2[NPARTS - 1] << 16), q2[0]};
                                 bf[pt][1][NPARTS - 1] = u32x4{q0[NPARTS - 1], q1[NPARTS - 1], q0[0], q1[0]};
@@ -521,8 +528,8 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                         unsigned q0[NPARTS], q1[NPARTS];
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) q0[k2] = q1[k2] = 0u;
-                        if (4 * (KT - 1) + 0 < NLIVE) split_pair<NPARTS>(act[pt][KT - 1][0], act[pt][KT - 1][1], q0);
-                        if (4 * (KT - 1) + 2 < NLIVE) split_pair<NPARTS>(act[pt][KT - 1][2], act[pt][KT - 1][3], q1);
+                        if (4 * (KT - 1) + 0 < NIN) split_pair<NPARTS>(act[pt][KT - 1][0], act[pt][KT - 1][1], q0);
+                        if (4 * (KT - 1) + 2 < NIN) split_pair<NPARTS>(act[pt][KT - 1][2], act[pt][KT - 1][3], q1);
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) hb[pt][k2] = u32x2{q0[k2], q1[k2]};
                     }
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                         for (int wa = 0; wa < NPARTS; ++wa)
 #pragma unroll
                             for (int ba = 0; ba < NPARTS; ++ba) {
-                                if (MERGE && s == 1) { if (wa != ba) continue; }      // merged K-steps: fragment k x operand k
+                                if (MERGEL && s == 1) { if (wa != ba) continue; }      // merged K-steps: fragment k x operand k
                                 else if (wa + ba >= NPARTS) continue;      // 2 parts: hh,hl,lh ; 3 parts: + h l2, l2 h, l l
 #pragma unroll
                                 for (int t = 0; t < OT; ++t)
@@ -586,7 +593,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     for (int t = 0; t < TMAX; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            act[pt][t][r] = (t < OT && (EXACT || t < to) && 4 * t + r < NLIVE) ? hidden_act_f(acc[pt][t][r], slope) : 0.f;
+                            act[pt][t][r] = (t < OT && (EXACT || t < to) && 4 * t + r < NOUT) ? hidden_act_f(acc[pt][t][r], slope) : 0.f;
             };
             if constexpr (TREST > 0) {
                 layer(std::true_type{}, 1);
@@ -602,7 +609,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 for (int t = 0; t < TMAX; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (4 * t + r < NLIVE) s = fmaf(wout[t][r], act[pt][t][r], s);
+                        if (4 * t + r < (TREST > 0 ? NREST : NLIVE)) s = fmaf(wout[t][r], act[pt][t][r], s);
                 s = group_allreduce(s);
                 const float f = out_act_f(s, m.out_act);
                 Facc[pt] = fmaf(wk, maybe_inverse(f, a.inv_f), Facc[pt]);

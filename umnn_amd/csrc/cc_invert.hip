@@ -12,9 +12,10 @@ typedef void (*inv_kernel_t)(const FwdBf16Args);
 struct InvVariant { int tmax, exact, nrl; inv_kernel_t fn; const char* name; };
 #define INV_VARIANT(T, EX, NR) { T, EX, NR, cc_fwd_bf16_kernel<T, 2, 1, (EX) != 0, NR, false, true>, "cc_invert_bf16<T=" #T ",EXACT=" #EX ",LIVE=" #NR ">" }
 // wide first hidden layer over a narrow rest (MNISTExperiment's integrand: sampling d = 784 images is 3 920 of these launches)
-struct InvWideFirst { int t1; inv_kernel_t fn; const char* name; };
-#define INV_WIDE_FIRST(T) { T, cc_fwd_bf16_kernel<T, 2, 1, true, 0, false, true, 4>, "cc_invert_bf16<T1=" #T ",TREST=4>" }
-static const InvWideFirst kInvWideFirst[] = { INV_WIDE_FIRST(5), INV_WIDE_FIRST(6), INV_WIDE_FIRST(7), INV_WIDE_FIRST(8) };
+struct InvWideFirst { int t1, nrl; inv_kernel_t fn; const char* name; };
+#define INV_WIDE_FIRST(T, NR) { T, NR, cc_fwd_bf16_kernel<T, 2, 1, true, NR, false, true, 4>, "cc_invert_bf16<T1=" #T ",TREST=4,LIVE=" #NR ">" }
+static const InvWideFirst kInvWideFirst[] = { INV_WIDE_FIRST(5, 13), INV_WIDE_FIRST(6, 13), INV_WIDE_FIRST(7, 13), INV_WIDE_FIRST(8, 13),
+                                              INV_WIDE_FIRST(5, 0), INV_WIDE_FIRST(6, 0), INV_WIDE_FIRST(7, 0), INV_WIDE_FIRST(8, 0) };
 static const InvVariant kInvVariants[] = {
     INV_VARIANT(4, 1, 13), INV_VARIANT(4, 1, 0),       // UCI / VAE nets (31-50^4-1) and every other 3..4-tile net (zero-padded)
     INV_VARIANT(7, 1, 26), INV_VARIANT(7, 1, 0),       // 100-wide toy nets
@@ -60,8 +61,11 @@ extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const f
             }
             a.m.lds_off[L] = (((o16 + 1) / 2) + 3) & ~3;
             const size_t lds_bytes = (size_t)a.m.lds_off[L] * sizeof(float);
+            int nrest = a.m.ks_in[2];           // live registers of the later layers when they all agree (13 = widths 48..51)
+            for (int l = 2; l <= L; ++l) if (a.m.ks_in[l] != nrest) nrest = 0;
+            if (nrest != 13) nrest = 0;
             const InvWideFirst* pick = nullptr;
-            for (const InvWideFirst& v : kInvWideFirst) if (v.t1 == T1) pick = &v;
+            for (const InvWideFirst& v : kInvWideFirst) if (v.t1 == T1 && v.nrl == nrest) pick = &v;
             if (pick && lds_bytes <= 160 * 1024) {
                 if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
                 a.ngroups = (unsigned)B;
