@@ -22,6 +22,9 @@ def init_from_env(backend=None):
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL / device-tensor sharing between the ranks of a node goes through dmabuf IPC on this driver stack; the legacy
+        # mode fails with "hipIpcGetMemHandle: invalid argument".  Only a default: an explicit setting wins.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = backend or os.environ.get("UMNN_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
         dist.init_process_group(backend, rank=rank, world_size=world,
                                 **({"device_id": device} if use_gpu and backend == "nccl" else {}))
