@@ -42,8 +42,8 @@ FULL_BATCH_ROWS = 65536            # BASELINE config C3's un-sharded batch
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 2:1-sparse figure is never used)
 # sources that define the dominant forward kernel: profiles/hbm_traffic.json is only trusted while their hash matches
-TRAFFIC_SOURCES = ["umnn_amd/csrc/cc_forward_bf16.hip", "umnn_amd/csrc/cc_fwd_shared.h", "umnn_amd/csrc/cc_common.h",
-                   "umnn_amd/csrc/cc_bf16.h", "umnn_amd/csrc/cc_forward.hip"]
+TRAFFIC_SOURCES = ["umnn_amd/csrc/cc_forward_bf16.hip", "umnn_amd/csrc/cc_fwd_bf16_kernel.h", "umnn_amd/csrc/cc_fwd_shared.h",
+                   "umnn_amd/csrc/cc_common.h", "umnn_amd/csrc/cc_bf16.h", "umnn_amd/csrc/cc_forward.hip"]
 
 
 def kernel_source_hash():
