@@ -330,13 +330,32 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 constexpr int i = decltype(ic)::value;
                 constexpr int MODE = decltype(first)::value;      // 0: raw MFMA output, 1: layer 1 (fma first), 2: already activated
                 constexpr bool FIRST = MODE == 1, PRE = MODE == 2;
-                constexpr int t_act = i <= 3 ? 0 : (i >= 5 && i <= 8) ? 1 : (i >= 11 && i <= 14) ? 2 : (NFULL == 4 && i >= 17 && i <= 20) ? 3 : -1;
-                constexpr int r_act = t_act == 0 ? i : t_act == 1 ? i - 5 : t_act == 2 ? i - 11 : i - 17;
-                constexpr int t_hi = i == 4 ? 0 : i == 9 ? 1 : i == 15 ? 2 : (NFULL == 4 && i == 21) ? 3 : -1;
-                constexpr int t_lo = i == 10 ? 0 : i == 16 ? 1 : i == (MERGE ? 19 : 20) ? 2 : (NFULL == 4 && i == 23) ? 3 : -1;
+                // slot plans.  24 slots (16 live registers): see above.  20 slots (MERGE): both cvt pairs of a K-step's quad are in
+                // place BEFORE its first remainder MFMA reads it (a quad that is read between two partial updates costs register copies):
+                //   act 0-3 (tile 0), 4-7 (tile 1), 12-15 (tile 2); cvt hi of tiles 0 and 1 in slot 8, their remainder MFMAs in slot 9;
+                //   tile 3's single register in 10, 11; cvt hi + remainder MFMA of tile 2 in 16; lo of tiles 0, 1, 2 in 17, 18, 19
+                constexpr int t_act = MERGE ? (i <= 3 ? 0 : (i >= 4 && i <= 7) ? 1 : (i >= 12 && i <= 15) ? 2 : -1)
+                                            : (i <= 3 ? 0 : (i >= 5 && i <= 8) ? 1 : (i >= 11 && i <= 14) ? 2 : (i >= 17 && i <= 20) ? 3 : -1);
+                constexpr int r_act = MERGE ? (t_act == 0 ? i : t_act == 1 ? i - 4 : i - 12)
+                                            : (t_act == 0 ? i : t_act == 1 ? i - 5 : t_act == 2 ? i - 11 : i - 17);
+                constexpr int t_hi = MERGE ? (i == 16 ? 2 : -1) : (i == 4 ? 0 : i == 9 ? 1 : i == 15 ? 2 : i == 21 ? 3 : -1);
+                constexpr int t_lo = MERGE ? (i == 17 ? 0 : i == 18 ? 1 : i == 19 ? 2 : -1) : (i == 10 ? 0 : i == 16 ? 1 : i == 20 ? 2 : i == 23 ? 3 : -1);
+                constexpr int T3A = MERGE ? 10 : -1, T3B = MERGE ? 11 : -1;
                 if constexpr (t_act >= 0 && !PRE) {
                     if constexpr (FIRST) z[t_act][r_act] = fmaf(w1x[t_act][r_act], tkv, cv[t_act][r_act]);
                     z[t_act][r_act] = hidden_act_f(z[t_act][r_act], slope);
+                }
+                if constexpr (MERGE && i == 8) {                  // leading pieces of tiles 0 and 1: the whole quad at once
+                    const bf16x2 a0 = __builtin_convertvector(f32x2{z[0][0], z[0][1]}, bf16x2);
+                    const bf16x2 a1 = __builtin_convertvector(f32x2{z[0][2], z[0][3]}, bf16x2);
+                    const bf16x2 b0 = __builtin_convertvector(f32x2{z[1][0], z[1][1]}, bf16x2);
+                    const bf16x2 b1 = __builtin_convertvector(f32x2{z[1][2], z[1][3]}, bf16x2);
+                    bfout[0][0] = u32x4{__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1),
+                                        __builtin_bit_cast(unsigned, b0), __builtin_bit_cast(unsigned, b1)};
+                }
+                if constexpr (MERGE && i == 9) {
+                    z[0] = mfma_bf16(sel[0], bfout[0][0], z[0]);          // exact remainders
+                    z[1] = mfma_bf16(sel[1], bfout[0][0], z[1]);
                 }
                 if constexpr (t_hi >= 0) {
                     const bf16x2 h0 = __builtin_convertvector(f32x2{z[t_hi][0], z[t_hi][1]}, bf16x2);
@@ -355,14 +374,14 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     bfout[t_lo / 2][1][2 * (t_lo % 2)] = __builtin_bit_cast(unsigned, l0);
                     bfout[t_lo / 2][1][2 * (t_lo % 2) + 1] = __builtin_bit_cast(unsigned, l1);
                 }
-                if constexpr (NFULL == 3 && i == 17) {           // tile 3 has one live register: split it on the VALU
+                if constexpr (i == T3A) {                        // tile 3 has one live register: split it on the VALU
                     if constexpr (FIRST) z[3][0] = fmaf(w1x[3][0], tkv, cv[3][0]);
                     rem_a = PRE ? z[3][0] : hidden_act_f(z[3][0], slope);
                     const bf16x2 h = __builtin_convertvector(f32x2{rem_a, 0.f}, bf16x2);
                     rem_hi = __builtin_bit_cast(unsigned, h);
                     bfout[1][0][3] = rem_hi;                     // k-slots 6,7: (hi, 0)
                 }
-                if constexpr (NFULL == 3 && i == 18) {
+                if constexpr (i == T3B) {
                     const bf16x2 l = __builtin_convertvector(f32x2{rem_a - __uint_as_float(rem_hi << 16), 0.f}, bf16x2);
                     bfout[1][0][2] = rem_hi | (__builtin_bit_cast(unsigned, l) << 16);      // k-slots 4,5: (hi, lo)
                 }
