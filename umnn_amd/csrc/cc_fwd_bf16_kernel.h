@@ -330,32 +330,38 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 constexpr int i = decltype(ic)::value;
                 constexpr int MODE = decltype(first)::value;      // 0: raw MFMA output, 1: layer 1 (fma first), 2: already activated
                 constexpr bool FIRST = MODE == 1, PRE = MODE == 2;
-                // slot plans.  24 slots (16 live registers): see above.  20 slots (MERGE): both cvt pairs of a K-step's quad are in
-                // place BEFORE its first remainder MFMA reads it (a quad that is read between two partial updates costs register copies):
-                //   act 0-3 (tile 0), 4-7 (tile 1), 12-15 (tile 2); cvt hi of tiles 0 and 1 in slot 8, their remainder MFMAs in slot 9;
-                //   tile 3's single register in 10, 11; cvt hi + remainder MFMA of tile 2 in 16; lo of tiles 0, 1, 2 in 17, 18, 19
+                // slot plans: both cvt pairs of a K-step's operand quad are in place BEFORE its first remainder MFMA reads it (a quad
+                // that is read between two partial updates costs register copies: 27 of 40 per node in the first version).
+                //   20 slots (MERGE)  act 0-3 (tile 0), 4-7 (tile 1), 12-15 (tile 2); cvt hi of tiles 0, 1 in slot 8, their remainder
+                //                     MFMAs in 9; tile 3's single register in 10, 11; cvt hi + remainder MFMA of tile 2 in 16;
+                //                     lo of tiles 0, 1, 2 in 17, 18, 19
+                //   24 slots          act 0-3, 4-7, 10-13 (tile 2), 14-17 (tile 3); cvt hi of tiles 0, 1 in 8 / of tiles 2, 3 in 18,
+                //                     remainder MFMAs in 9 / 19; lo of tiles 0..3 in 20, 21, 22, 23
                 constexpr int t_act = MERGE ? (i <= 3 ? 0 : (i >= 4 && i <= 7) ? 1 : (i >= 12 && i <= 15) ? 2 : -1)
-                                            : (i <= 3 ? 0 : (i >= 5 && i <= 8) ? 1 : (i >= 11 && i <= 14) ? 2 : (i >= 17 && i <= 20) ? 3 : -1);
+                                            : (i <= 3 ? 0 : (i >= 4 && i <= 7) ? 1 : (i >= 10 && i <= 13) ? 2 : (i >= 14 && i <= 17) ? 3 : -1);
                 constexpr int r_act = MERGE ? (t_act == 0 ? i : t_act == 1 ? i - 4 : i - 12)
-                                            : (t_act == 0 ? i : t_act == 1 ? i - 5 : t_act == 2 ? i - 11 : i - 17);
-                constexpr int t_hi = MERGE ? (i == 16 ? 2 : -1) : (i == 4 ? 0 : i == 9 ? 1 : i == 15 ? 2 : i == 21 ? 3 : -1);
-                constexpr int t_lo = MERGE ? (i == 17 ? 0 : i == 18 ? 1 : i == 19 ? 2 : -1) : (i == 10 ? 0 : i == 16 ? 1 : i == 20 ? 2 : i == 23 ? 3 : -1);
+                                            : (t_act == 0 ? i : t_act == 1 ? i - 4 : t_act == 2 ? i - 10 : i - 14);
+                constexpr int t_hi = MERGE ? (i == 16 ? 2 : -1) : -1;
+                constexpr int t_lo = MERGE ? (i == 17 ? 0 : i == 18 ? 1 : i == 19 ? 2 : -1) : (i >= 20 ? i - 20 : -1);
                 constexpr int T3A = MERGE ? 10 : -1, T3B = MERGE ? 11 : -1;
+                constexpr int QCVT = (!MERGE && i == 18) ? 1 : (i == 8 ? 0 : -1);        // quad (tiles 2q, 2q+1): cvt hi of both tiles
+                constexpr int QSEL = (!MERGE && i == 19) ? 1 : (i == 9 ? 0 : -1);        // ... and their remainder MFMAs
                 if constexpr (t_act >= 0 && !PRE) {
                     if constexpr (FIRST) z[t_act][r_act] = fmaf(w1x[t_act][r_act], tkv, cv[t_act][r_act]);
                     z[t_act][r_act] = hidden_act_f(z[t_act][r_act], slope);
                 }
-                if constexpr (MERGE && i == 8) {                  // leading pieces of tiles 0 and 1: the whole quad at once
-                    const bf16x2 a0 = __builtin_convertvector(f32x2{z[0][0], z[0][1]}, bf16x2);
-                    const bf16x2 a1 = __builtin_convertvector(f32x2{z[0][2], z[0][3]}, bf16x2);
-                    const bf16x2 b0 = __builtin_convertvector(f32x2{z[1][0], z[1][1]}, bf16x2);
-                    const bf16x2 b1 = __builtin_convertvector(f32x2{z[1][2], z[1][3]}, bf16x2);
-                    bfout[0][0] = u32x4{__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1),
-                                        __builtin_bit_cast(unsigned, b0), __builtin_bit_cast(unsigned, b1)};
+                if constexpr (QCVT >= 0) {                        // leading pieces of tiles 2q and 2q+1: the whole quad at once
+                    constexpr int ta = 2 * QCVT, tb = 2 * QCVT + 1;
+                    const bf16x2 a0 = __builtin_convertvector(f32x2{z[ta][0], z[ta][1]}, bf16x2);
+                    const bf16x2 a1 = __builtin_convertvector(f32x2{z[ta][2], z[ta][3]}, bf16x2);
+                    const bf16x2 b0 = __builtin_convertvector(f32x2{z[tb][0], z[tb][1]}, bf16x2);
+                    const bf16x2 b1 = __builtin_convertvector(f32x2{z[tb][2], z[tb][3]}, bf16x2);
+                    bfout[QCVT][0] = u32x4{__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1),
+                                           __builtin_bit_cast(unsigned, b0), __builtin_bit_cast(unsigned, b1)};
                 }
-                if constexpr (MERGE && i == 9) {
-                    z[0] = mfma_bf16(sel[0], bfout[0][0], z[0]);          // exact remainders
-                    z[1] = mfma_bf16(sel[1], bfout[0][0], z[1]);
+                if constexpr (QSEL >= 0) {
+                    z[2 * QSEL] = mfma_bf16(sel[0], bfout[QSEL][0], z[2 * QSEL]);          // exact remainders
+                    z[2 * QSEL + 1] = mfma_bf16(sel[1], bfout[QSEL][0], z[2 * QSEL + 1]);
                 }
                 if constexpr (t_hi >= 0) {
                     const bf16x2 h0 = __builtin_convertvector(f32x2{z[t_hi][0], z[t_hi][1]}, bf16x2);
