@@ -37,6 +37,9 @@
 //   part 1:  k-slots 0-3 Whi of tile 2 (x alo)  |  4-7 Wlo of tile 2 (x ahi)
 // and the kernels pack the B operands to match -- each lane group still supplies its own features only.
 // MERGE_FROM: first hidden layer whose image uses this layout (0 = none, 1 = every layer, 2 = all but the first: the wide-first family).
+// One (fragment group, lane) per thread and iteration: the lane's 8 (or 4) k-slots of every piece are built in registers and leave
+// as 16-byte (8-byte) LDS stores -- one index computation per 8 weights (round 1-2 staged one bf16 per iteration: 7x the
+// instructions; at the toy shape's 147 KB of images that was a fifth of a workgroup's time).
 template <int NPARTS, int MERGE_FROM = 0>
 __device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks32, const int* off16, const int* half_in,
                                                   unsigned short* lds16, int tid, int nthreads) {
@@ -47,57 +50,63 @@ __device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks
         const float* __restrict__ W = m.W[l];
         const float* __restrict__ b = m.b[l];
         unsigned short* img = lds16 + off16[l];
-        const int total = to * ks * 512;
-#pragma unroll 8
-        for (int idx = tid; idx < total; idx += nthreads) {      // (unrolled: the weight loads of 8 iterations in flight)
-            const int j = idx & 7, ln = (idx >> 3) & 63, ts = idx >> 9;
+        // weight of (output feature fo, input feature fi) incl. the bias column and the constant-one carrier
+        auto wv = [&](int fo, int fi) {
+            float v = 0.f;
+            if (fo < Hout) {
+                if (fi < Hin) v = W[fo * Hin + fi];
+                else if (fi == Hin) v = b[fo];
+            } else if (fo == Hout && fi == Hin) {
+                v = 1.f;
+            }
+            return v;
+        };
+        // pieces of 8 values -> pk[part][0..3] (two bf16 per dword, k-slot 2e in the low half)
+        auto split8 = [&](const float (&v)[8], unsigned (&pk)[NPARTS][4]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned q[NPARTS];
+                split_pair<NPARTS>(v[2 * e], v[2 * e + 1], q);
+#pragma unroll
+                for (int part = 0; part < NPARTS; ++part) pk[part][e] = q[part];
+            }
+        };
+        const int total = to * ks * 64;
+        for (int idx = tid; idx < total; idx += nthreads) {
+            const int ln = idx & 63, ts = idx >> 6;
             const int s = ts % ks, t = ts / ks;
-            const int fo = fout_of(t, ln & 15);
-            auto wv = [&](int fi) {
-                float v = 0.f;
-                if (fo < Hout) {
-                    if (fi < Hin) v = W[fo * Hin + fi];
-                    else if (fi == Hin) v = b[fo];
-                } else if (fo == Hout && fi == Hin) {
-                    v = 1.f;
-                }
-                return v;
-            };
+            const int fo = fout_of(t, ln & 15), g = ln >> 4;
+            u32x4* dst = reinterpret_cast<u32x4*>(img + (ts * NPARTS) * 512 + ln * 8);       // fragment `part` at dst[part * 64]
+            float v[8];
+            unsigned pk[NPARTS][4];
             if (MERGE_FROM > 0 && l >= MERGE_FROM && s == 1) {
-                const float v2 = wv(feat_of(2, j & 3, ln >> 4)), v3 = wv(feat_of(3, 0, ln >> 4));
-                const unsigned short h2 = bf16_rn_bits(v2), l2 = bf16_rn_bits(v2 - bf16_bits_to_f32(h2));
-                const unsigned short h3 = bf16_rn_bits(v3), l3 = bf16_rn_bits(v3 - bf16_bits_to_f32(h3));
-                img[(ts * NPARTS + 0) * 512 + ln * 8 + j] = j < 4 ? h2 : j < 6 ? h3 : j == 6 ? l3 : (unsigned short)0;
-                img[(ts * NPARTS + 1) * 512 + ln * 8 + j] = j < 4 ? h2 : l2;
+                // tile 2's four features and the lane group's tile-3 feature; see the layout note above
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = wv(fo, feat_of(2, jj, g));
+                v[4] = wv(fo, feat_of(3, 0, g)); v[5] = 0.f; v[6] = 0.f; v[7] = 0.f;
+                split8(v, pk);
+                const unsigned h3 = pk[0][2] & 0xffffu, l3 = pk[NPARTS - 1][2] & 0xffffu;
+                dst[0] = u32x4{pk[0][0], pk[0][1], h3 | (h3 << 16), l3};
+                dst[64] = u32x4{pk[0][0], pk[0][1], pk[NPARTS - 1][0], pk[NPARTS - 1][1]};
                 continue;
             }
-            float v = wv(feat_of(2 * s + (j >> 2), j & 3, ln >> 4));
 #pragma unroll
-            for (int part = 0; part < NPARTS; ++part) {
-                const unsigned short hb = bf16_rn_bits(v);
-                img[(ts * NPARTS + part) * 512 + ln * 8 + j] = hb;
-                v -= bf16_bits_to_f32(hb);
-            }
+            for (int jj = 0; jj < 8; ++jj) v[jj] = wv(fo, feat_of(2 * s + (jj >> 2), jj & 3, g));
+            split8(v, pk);
+#pragma unroll
+            for (int part = 0; part < NPARTS; ++part) dst[part * 64] = u32x4{pk[part][0], pk[part][1], pk[part][2], pk[part][3]};
         }
         if (half_in[l]) {
             unsigned short* himg = img + to * ks * NPARTS * 512;
-            for (int idx = tid; idx < to * 256; idx += nthreads) {
-                const int j = idx & 3, ln = (idx >> 2) & 63, t = idx >> 8;
-                const int fo = fout_of(t, ln & 15);
-                const int fi = feat_of(2 * ks, j, ln >> 4);
-                float v = 0.f;
-                if (fo < Hout) {
-                    if (fi < Hin) v = W[fo * Hin + fi];
-                    else if (fi == Hin) v = b[fo];
-                } else if (fo == Hout && fi == Hin) {
-                    v = 1.f;
-                }
+            for (int idx = tid; idx < to * 64; idx += nthreads) {
+                const int ln = idx & 63, t = idx >> 6;
+                const int fo = fout_of(t, ln & 15), g = ln >> 4;
+                unsigned q0[NPARTS], q1[NPARTS];
+                split_pair<NPARTS>(wv(fo, feat_of(2 * ks, 0, g)), wv(fo, feat_of(2 * ks, 1, g)), q0);
+                split_pair<NPARTS>(wv(fo, feat_of(2 * ks, 2, g)), wv(fo, feat_of(2 * ks, 3, g)), q1);
 #pragma unroll
-                for (int part = 0; part < NPARTS; ++part) {
-                    const unsigned short hb = bf16_rn_bits(v);
-                    himg[(t * NPARTS + part) * 256 + ln * 4 + j] = hb;
-                    v -= bf16_bits_to_f32(hb);
-                }
+                for (int part = 0; part < NPARTS; ++part)
+                    *reinterpret_cast<u32x2*>(himg + (t * NPARTS + part) * 256 + ln * 4) = u32x2{q0[part], q1[part]};
             }
         }
     }
