@@ -539,7 +539,8 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
     int off16 = 0;
     for (int l = 1; l < LH; ++l) { mid.off_fwd[l] = off16; off16 += BT * BKS * NPF * FRAG; }
     for (int l = 1; l < LH; ++l) { mid.off_tr[l] = off16; off16 += BT * BKS * NPB * FRAG; }
-    mid.off_trtile = 0;
+    mid.off_trtile = off16;
+    off16 += UMNN_WAVES_PER_BLOCK * NPB * 16 * TRS;
     const size_t lds_mid = (size_t)off16 * sizeof(unsigned short);
     const size_t lds_a = ((size_t)BT * (T1 / 2) * NPF * FRAG + (T1 & 1 ? BT * NPF * 256 : 0)) * sizeof(unsigned short);
     const size_t lds_c = (size_t)T1 * BKS * NPB * FRAG * sizeof(unsigned short);

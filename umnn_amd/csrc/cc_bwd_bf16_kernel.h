@@ -211,7 +211,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
     }
     __syncthreads();
     const unsigned short* frag_base = lds16 + lane * 8;
-    constexpr bool TRL = !FRONT;                       // dW operands transposed through LDS (one-pass kernels)
+    constexpr bool TRL = true;                         // dW operands transposed through LDS (ds_read_b64_tr_b16)
     unsigned short* tr_tile = lds16 + args.off_trtile + wid * (NPB * 16 * TRS);
 
     // selection fragments of the matrix-core transpose: lane (g, n) sets k-slot 4h + (n>>2) to 1.0 iff (n&3) == g
