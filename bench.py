@@ -165,6 +165,9 @@ def main():
                     help="replay the step as one captured hipGraph (umnn_amd.GraphedLL / GraphedTrainStep) -- for the "
                          "launch-bound small workloads; the eval roofline record then comes from an eager pass after the "
                          "timed region")
+    ap.add_argument("--embedding", default="fp32", choices=["fp32", "bf16"],
+                    help="storage of the [B, E*d] embedding between conditioner and quadrature kernels (bf16: configuration C4's "
+                         "storage mode -- the kernels load bf16, arithmetic stays fp32; reported in config.embedding_storage)")
     ap.add_argument("--precision", default="", choices=["", "fp32", "bf16x3", "bf16x6"],
                     help="forward arithmetic (default: the library default, bf16x3)")
     args = ap.parse_args()
@@ -183,6 +186,8 @@ def main():
     precision = _lib.get_forward_precision()
 
     model = build_model(cfg, device)
+    if args.embedding == "bf16":
+        model.set_embedding_dtype(torch.bfloat16)
     x, ctx = make_inputs(cfg, cfg["rows"], device, 1000 + rank)    # every rank owns a different shard of the global batch
 
     def ll_of(xb, cb):
@@ -323,6 +328,7 @@ def main():
                        "nb_flow": cfg["nb_flow"], "embedding": cfg["E"], "integrand": cfg["hd"], "made": cfg["he"],
                        "cond_in": cfg.get("cond", 0),
                        "sharding": f"batch x{world}, no forward collective",
+                       "embedding_storage": args.embedding,
                        "integrals_per_s": value * cfg["d"] * cfg["nb_flow"]},
             # achieved = ALGORITHMIC fp32 FLOPs (backward = 3 x forward) / kernel time; peak = dense MFMA peak
             # of the dtype the matrix instructions execute.  The bf16-split kernels issue 3 (or 6) bf16 MFMAs per fp32
