@@ -458,6 +458,56 @@ def test_pipelined_kernel_shapes_against_oracle(hid, relu, sigmoid, inv_f, n, NS
     assert U.rel_err(fx0.cpu().numpy(), O.integrand(net, x0, h)) < TOL
 
 
+@pytest.mark.parametrize("hid,relu,sigmoid,inv_f,n", [
+    ([50, 50], False, False, False, 100),            # one hidden->hidden layer
+    ([50, 50, 50], True, False, False, 51),          # ReLU, odd node count
+    ([48, 51, 50, 49], False, True, False, 40),      # the flagship depth, mixed widths 48..51, Sigmoid output
+    ([51, 51, 51, 51, 51], False, False, True, 20),  # five hidden layers of the widest member, 1/f integrand
+])
+def test_mfma_32x32x16_formulation_against_oracle(hid, relu, sigmoid, inv_f, n, dev, opts):
+    """The opt-in 32x32x16 formulation of the 48..51-wide shapes (cc_forward_p32.hip: the wave's 32 integrals are the N dimension
+    of one matrix instruction, pipelined in 20-slot sections): against the oracle, ragged batch, x0 != 0, and through the flow
+    entry point (same epilogue as every other forward kernel)."""
+    import umnn_amd
+    from umnn_amd import integral as I, _lib
+    from umnn_amd.nets import MlpSpec
+    if umnn_amd.get_forward_precision() != "bf16x3":
+        pytest.skip("the 32x32x16 formulation exists for bf16x3 only")
+    opts(fwd_pipe=2)
+    B, d, E = 37, 5, 7
+    rng = np.random.RandomState(len(hid) * 19 + n)
+    sizes = [1 + E] + hid + [1]
+    Ws = [(rng.randn(sizes[i + 1], sizes[i]) * (1.6 / np.sqrt(sizes[i]))).astype(np.float32) for i in range(len(sizes) - 1)]
+    bs = [(rng.randn(sizes[i + 1]) * 0.3).astype(np.float32) for i in range(len(sizes) - 1)]
+    lin = []
+    for W, b in zip(Ws, bs):
+        m = torch.nn.Linear(W.shape[1], W.shape[0])
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(W))
+            m.bias.copy_(torch.from_numpy(b))
+        lin.append(m.to(dev))
+    spec = MlpSpec(lin, _lib.ACT_RELU if relu else _lib.ACT_LEAKY_RELU, _lib.OUT_SIGMOID if sigmoid else _lib.OUT_ELU_PLUS_ONE)
+    net = O.Net(Ws, bs, O.RELU if relu else O.LEAKY, O.SIGMOID if sigmoid else O.ELU1)
+    x = (rng.randn(B, d) * 2).astype(np.float32)
+    x0 = (rng.randn(B, d) * 0.5).astype(np.float32)
+    h = rng.randn(B, E * d).astype(np.float32)
+    F, fx, fx0 = I.hip_forward(spec, t(x0, dev), t(x, dev), t(h, dev), n, inv_f=inv_f)
+    kname = _lib.lib().umnn_last_kernel_name().decode()
+    assert "32x32x16" in kname, kname
+    assert U.rel_err(F.cpu().numpy(), O.integrate_parallel(net, x0, x, h, n, inv_f=inv_f)) < TOL
+    assert U.rel_err(fx.cpu().numpy(), O.integrand(net, x, h)) < TOL
+    assert U.rel_err(fx0.cpu().numpy(), O.integrand(net, x0, h)) < TOL
+    # flow-block entry (z, log_jac in the kernel's epilogue): same values as the default kernel's to rounding
+    if not inv_f and not sigmoid and not relu:
+        sc = t(rng.randn(d).astype(np.float32) * 0.1, dev)
+        z2, lj2 = I.hip_flow_block(spec, t(x, dev), t(h, dev), sc, n)[:2]
+        opts(fwd_pipe=1)
+        z1, lj1 = I.hip_flow_block(spec, t(x, dev), t(h, dev), sc, n)[:2]
+        assert "32x32x16" not in _lib.lib().umnn_last_kernel_name().decode()
+        assert float((z1 - z2).abs().max()) < 2e-5 * max(1.0, float(z1.abs().max()))
+        assert float((lj1 - lj2).abs().max()) < 2e-5
+
+
 def test_stack_block_entry_reverses_z_and_accumulates_log_jac(dev):
     """umnn_flow_stack_block_forward = umnn_flow_block_forward + the glue between the blocks of a flow
     (UMNNMAFFlow.py:109-123): same bits, z stored reversed, log_jac added to the running sum."""

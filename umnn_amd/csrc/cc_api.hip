@@ -82,7 +82,7 @@ static void load_env(UmnnOptions& o) {
     int v = env_int("UMNN_FWD_P", -1); o.fwd_p = v == 1 || v == 2 ? v : -1;
     v = env_int("UMNN_FWD_NS", -1); o.fwd_ns = v == 1 || v == 2 || v == 4 ? v : -1;
     v = env_int("UMNN_FWD_TAIL", -1); o.fwd_tail = v < 0 ? -1 : (v != 0);
-    o.fwd_pipe = env_int("UMNN_FWD_PIPE", 1) != 0;
+    o.fwd_pipe = env_int("UMNN_FWD_PIPE", 1);          // 0 plain loop, 1 pipelined 16x16x32 loop, 2 the 32x32x16 formulation (experimental)
     o.fwd_pad = env_int("UMNN_FWD_PAD", 1) != 0;
     o.fwd_pad_min = env_int("UMNN_FWD_PAD_MIN", 1);
     v = env_int("UMNN_BWD_NS", -1); o.bwd_ns = v >= 1 && v <= 32 ? v : -1;

@@ -26,6 +26,8 @@ static const Bf16Variant kBf16Variants[] = {
     BF16_VARIANT(8, 2, 1, 0, 0), BF16_VARIANT(8, 2, 2, 0, 0),   // (8 tiles x 3 parts does not fit the register file: fp32 kernels instead)
 };
 
+int umnn_launch_forward_p32(FwdArgs& a, const umnn_mlp* net, int nb_steps, hipStream_t stream);      // cc_forward_p32.hip
+
 // Returns 0 and launches, UMNN_EUNSUPPORTED (without setting the error text's prefix) if the shape does not fit
 // this kernel family (caller then uses the fp32-MFMA kernels), or another error code.
 int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps,
@@ -120,6 +122,12 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
         args.f.m.lds_off[L] = (((off16 + 1) / 2) + 3) & ~3;
     }
     const bool want_pipe = opt.fwd_pipe != 0 && L >= 2;
+    // the 32x32x16 formulation of the flagship shape: opt-in (UMNN_FWD_PIPE=2 / option fwd_pipe = 2).  Same wall time as the
+    // default at C3 with 10 % fewer cycles -- the chip clocks it lower (the kernel is power-bound)
+    if (opt.fwd_pipe == 2 && exact && T == 4 && nparts == 2 && nrl == 13) {
+        const int rc = umnn_launch_forward_p32(a, net, nb_steps, stream);
+        if (rc != UMNN_EUNSUPPORTED) return rc;
+    }
     // the pipelined loop needs two point tiles per wave and pays off as soon as that still leaves a wave per SIMD
     // (measured at the POWER and VAE shapes: P=2, NS=1 beats every P=1 split by 6-7 %)
     if (want_pipe && exact && T == 4 && nparts == 2 && !p_forced && !ns_forced &&
