@@ -70,59 +70,108 @@ def make_inputs(cfg, rows, device, seed):
     return x, ctx
 
 
-def cpu_baseline(cfg, model, budget_s=26.0):
+def cpu_baseline(cfg, model, budget_s=45.0):
     """Time the torch port of the reference's compute_ll with BOTH of its quadrature solvers -- the materialised
     ``ParallelNeuralIntegral`` (ParallelNeuralIntegral.py:37-65) and the node-by-node ``NeuralIntegral``
     (NeuralIntegral.py:37-66) -- on the host cores, on a bounded sample of the same workload (row chunks; the un-chunked
-    node axis of the parallel solver would need terabytes).  ``value`` is the FASTER solver."""
+    node axis of the parallel solver would need terabytes).  Protocol: per solver a short thread-count sweep
+    (torch's all-cores default is pathological on a 256-core host for these skinny GEMMs), then at the best count 3 warm-up
+    calls and the median of 10 timed calls alternating between TWO different row chunks -- fewer, with ``budget_limited``
+    set, when the solver's share of ``budget_s`` runs out -- and the all-cores setting reported beside it.
+    ``value`` is the FASTER solver at its best thread count."""
     from oracle import torch_port as TP
     ncpu = os.cpu_count() or 1
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     blocks = TP.blocks_from_state_dict(sd, cfg["nb_flow"])
     chunk = 128 if cfg["d"] > 8 else 1024
-    torch.manual_seed(123)
-    x = torch.randn(chunk, cfg["d"])
-    ctx = torch.randn(chunk, cfg["cond"]) if cfg.get("cond", 0) else None
+    chunks = []
+    for seed in (123, 456):
+        g = torch.Generator().manual_seed(seed)
+        chunks.append((torch.randn(chunk, cfg["d"], generator=g),
+                       torch.randn(chunk, cfg["cond"], generator=g) if cfg.get("cond", 0) else None))
     solvers = {}
     old_threads = torch.get_num_threads()
+    WARMUP, REPS = 3, 10
     with torch.no_grad():
-        for name, solver, share in (("parallel", "CCParallel", 0.6), ("sequential", "CC", 0.4)):
-            run = lambda: TP.flow_compute_ll(blocks, x, cfg["n"], solver=solver, context=ctx)      # noqa: E731
-            # torch's default (all cores) is pathological on many-core hosts for these skinny GEMMs: give the CPU its
-            # best thread count among a few candidates, then spend the rest of this solver's budget at that setting
-            t_start = time.perf_counter()
-            best = (float("inf"), 1)
-            for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
-                torch.set_num_threads(th)
-                run()                                               # warm-up at this setting
+        for name, solver, share in (("sequential", "CC", 0.45), ("parallel", "CCParallel", 0.55)):
+            def run(i=0):
+                xx, cc = chunks[i % 2]
+                return TP.flow_compute_ll(blocks, xx, cfg["n"], solver=solver, context=cc)
+
+            def timed(i=0):
                 t0 = time.perf_counter()
+                run(i)
+                return time.perf_counter() - t0
+            t_start = time.perf_counter()
+            deadline = t_start + share * budget_s
+            # 1. thread sweep: one warm-up + one timed call per candidate (stops once a setting is clearly slower)
+            best = (float("inf"), 1)
+            sweep = {}
+            for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+                torch.set_num_threads(th)
                 run()
-                dt = time.perf_counter() - t0
+                dt = timed()
+                sweep[th] = chunk / dt
                 if dt < best[0]:
                     best = (dt, th)
-                if dt > 1.5 * best[0] or time.perf_counter() - t_start > 0.6 * share * budget_s:
+                if dt > 1.5 * best[0] or time.perf_counter() - t_start > 0.3 * share * budget_s:
                     break
             one, threads = best
+            # 2. the protocol at the best thread count
             torch.set_num_threads(threads)
-            left = share * budget_s - (time.perf_counter() - t_start)
-            reps = max(2, min(10, int(left / max(one, 1e-3))))
+            warm = 0
+            while warm < WARMUP and (warm < 1 or time.perf_counter() + one < deadline - 4 * one):
+                run(warm)
+                warm += 1
             times = []
-            for _ in range(reps):
-                t0 = time.perf_counter()
-                run()
-                times.append(time.perf_counter() - t0)
+            while len(times) < REPS and (len(times) < 3 or time.perf_counter() + one < deadline - 2.5 * one):
+                times.append(timed(len(times)))
             med = sorted(times)[len(times) // 2]
-            solvers[name] = {"evals_per_s": chunk / med, "threads": threads, "chunk_rows": chunk, "reps": reps,
+            # 3. all host cores (torch's default), beside it -- in a child process with a hard time limit: on a 256-core host
+            # the all-cores setting can take minutes per call for these skinny GEMMs, and a torch call cannot be interrupted
+            allc = None
+            if threads != ncpu:
+                allc = _all_cores_probe(sd, cfg, solver, chunks[0], ncpu, limit_s=max(8.0, 0.25 * share * budget_s))
+            solvers[name] = {"evals_per_s": chunk / med, "threads": threads, "chunk_rows": chunk, "chunks": 2,
+                             "warmup": warm, "reps": len(times), "budget_limited": len(times) < REPS or warm < WARMUP,
+                             "min_ms": 1e3 * min(times), "median_ms": 1e3 * med, "max_ms": 1e3 * max(times),
+                             "thread_sweep_evals_per_s": sweep, "all_cores": allc,
                              "integrals_per_s": chunk * cfg["d"] * cfg["nb_flow"] / med,
                              "reference": "models/UMNN/ParallelNeuralIntegral.py:37-65" if name == "parallel"
                              else "models/UMNN/NeuralIntegral.py:37-66"}
     torch.set_num_threads(old_threads)
     fast = max(solvers, key=lambda k: solvers[k]["evals_per_s"])
     return {"value": solvers[fast]["evals_per_s"], "unit": "evals/s", "cores": solvers[fast]["threads"], "kind": "port",
-            "solver": fast, "solvers": solvers, "host_cores": ncpu,
-            "sample": f"{chunk}-row chunks of the same flow through oracle/torch_port.py (torch CPU port of the reference's "
-                      f"compute_ll), median of {solvers[fast]['reps']} calls per solver at its best thread count; value = the "
-                      f"faster solver ({fast})"}
+            "solver": fast, "solvers": solvers, "host_cores": ncpu, "torch_parallel_info": torch.__config__.parallel_info().split("\n")[0:3],
+            "sample": f"two {chunk}-row chunks of the same flow through oracle/torch_port.py (torch CPU port of the reference's "
+                      f"compute_ll); per solver: thread sweep, {WARMUP} warm-up calls, median of {solvers[fast]['reps']} calls "
+                      f"alternating between the chunks at the best thread count (budget_limited says when fewer fitted), "
+                      f"all-cores setting beside it; value = the faster solver ({fast})"}
+
+
+def _all_cores_probe(sd, cfg, solver, chunk, ncpu, limit_s):
+    """One warm-up and one timed call of the CPU port at torch.set_num_threads(all cores), in a child process that is killed
+    after ``limit_s`` seconds (then only an upper bound on the rate is known)."""
+    import subprocess
+    import tempfile
+    xx, cc = chunk
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "w.pt")
+        torch.save({"sd": sd, "x": xx, "c": cc}, path)
+        code = ("import sys, time, torch; sys.path.insert(0, %r); from oracle import torch_port as TP; "
+                "d = torch.load(%r); torch.set_num_threads(%d); b = TP.blocks_from_state_dict(d['sd'], %d); "
+                "f = lambda: TP.flow_compute_ll(b, d['x'], %d, solver=%r, context=d['c']); "
+                "torch.set_grad_enabled(False); f(); t = time.perf_counter(); f(); print('ALLCORES', time.perf_counter() - t)"
+                % (ROOT, path, ncpu, cfg["nb_flow"], cfg["n"], solver))
+        try:
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=limit_s)
+            dt = float([l for l in r.stdout.splitlines() if l.startswith("ALLCORES")][-1].split()[1])
+            return {"threads": ncpu, "evals_per_s": xx.shape[0] / dt, "reps": 1, "warmup": 1, "budget_limited": True}
+        except subprocess.TimeoutExpired:
+            return {"threads": ncpu, "timed_out_after_s": limit_s, "evals_per_s_upper_bound": xx.shape[0] / (limit_s / 2),
+                    "note": "warm-up + one call at all cores did not finish inside the limit"}
+        except Exception as e:          # a failed probe must not take the bench line down
+            return {"threads": ncpu, "error": f"{type(e).__name__}: {e}"}
 
 
 def hbm_traffic(workload, live, extra_args):
@@ -156,6 +205,7 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact_fp32 and full_batch_n1 records (profiling runs)")
+    ap.add_argument("--no-telemetry", action="store_true", help="do not sample socket power / shader clock during the timed region")
     ap.add_argument("--live-traffic", action="store_true",
                     help="measure roofline.traffic now with two rocprofv3 PMC child runs instead of reading profiles/")
     ap.add_argument("--mode", default="eval", choices=["eval", "train"],
@@ -217,10 +267,20 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # socket power / shader clock while the timed region runs (rank 0; a background thread polling the SMU metrics table)
+    sampler = None
+    if rank == 0 and not args.no_telemetry:
+        try:
+            from tools.telemetry import Sampler
+            sampler = Sampler(device.index or 0)
+        except Exception:
+            sampler = None
     lib.umnn_profile_enable(1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if sampler is not None:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ll, _ = step()
@@ -228,6 +288,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    telemetry = sampler.stop() if sampler is not None else None
     fwd = _lib.profile_read(_lib.PROF_FORWARD)
     bwd = _lib.profile_read(_lib.PROF_BACKWARD)
     fin = _lib.profile_read(_lib.PROF_FINISH)
@@ -248,19 +309,20 @@ def main():
     if extras and precision != "fp32":
         import umnn_amd
         umnn_amd.set_precision("fp32")              # forward kernels AND conditioner GEMMs in the reference's arithmetic
-        for _ in range(2):
+        for _ in range(args.warmup):
             eager_step()
         lib.umnn_profile_enable(1)
         torch.cuda.synchronize()
         te = time.perf_counter()
-        for _ in range(3):
+        for _ in range(args.steps):
             eager_step()
         torch.cuda.synchronize()
         te = time.perf_counter() - te
         e_ms, e_n, e_fl = _lib.profile_read(_lib.PROF_FORWARD)
         lib.umnn_profile_enable(0)
         tf = e_fl / max(e_ms, 1e-9) / 1e9
-        exact = {"value": cfg["rows"] * 3 / te, "ms_per_step": 1e3 * te / 3, "kernel": lib.umnn_last_kernel_name().decode(),
+        exact = {"value": cfg["rows"] * args.steps / te, "ms_per_step": 1e3 * te / args.steps, "steps": args.steps,
+                 "warmup": args.warmup, "kernel": lib.umnn_last_kernel_name().decode(),
                  "avg_launch_ms": e_ms / max(1, e_n), "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
                  "frac": tf / PEAK_FP32_MFMA_TFLOPS, "conditioner": "fp32 F.linear"}
         umnn_amd.set_precision(precision)
@@ -269,17 +331,19 @@ def main():
     if extras and args.workload == "bsds300" and not args.rows and not args.graph:
         xf, cf = make_inputs(cfg, FULL_BATCH_ROWS, device, 4242)
         with torch.no_grad():
-            for _ in range(2):
+            for _ in range(args.warmup):
                 ll_of(xf, cf)
             torch.cuda.synchronize()
             tfb = time.perf_counter()
-            for _ in range(3):
+            for _ in range(args.steps):
                 llf, _ = ll_of(xf, cf)
             torch.cuda.synchronize()
             tfb = time.perf_counter() - tfb
         assert torch.isfinite(llf).all()
-        full = {"rows": FULL_BATCH_ROWS, "value": FULL_BATCH_ROWS * 3 / tfb, "unit": "evals/s", "ms_per_step": 1e3 * tfb / 3,
-                "steps": 3, "note": "BASELINE config C3's whole batch on one GPU (strong-scaling anchor for the N=8 run)"}
+        full = {"rows": FULL_BATCH_ROWS, "value": FULL_BATCH_ROWS * args.steps / tfb, "unit": "evals/s",
+                "ms_per_step": 1e3 * tfb / args.steps, "steps": args.steps, "warmup": args.warmup,
+                "note": "BASELINE config C3's whole batch on one GPU (strong-scaling anchor for the N=8 run); parity of this "
+                        "exact batch: tests/test_gpu_round3.py::test_full_65536_row_batch_compute_ll_matches_oracle_on_sampled_rows"}
         del xf, llf
 
     ranks = [{"rank": rank, "device": torch.cuda.get_device_name(device),
@@ -344,7 +408,12 @@ def main():
                          "peak_dtype": "bf16 dense MFMA" if on_bf16 else "fp32 MFMA",
                          "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "executed_mfma_tflops": executed,
-                         "executed_frac_of_peak": executed / peak if executed else None},
+                         "executed_frac_of_peak": executed / peak if executed else None,
+                         # the clock this kernel ran at: the SMU lowers it under dense MFMA work (profiles/r03/power_fwd.json)
+                         "sclk_mhz": telemetry.get("sclk_mhz") if telemetry else None,
+                         "power_w": telemetry.get("power_w") if telemetry else None,
+                         "power_cap_w": telemetry.get("power_cap_w") if telemetry else None,
+                         "telemetry": telemetry},
             "ranks_seen": len(ranks), "ranks": ranks,
             "dist": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
                      "backend": dist.get_backend() if dist.is_initialized() else None},

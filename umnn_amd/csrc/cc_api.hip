@@ -86,6 +86,7 @@ static void load_env(UmnnOptions& o) {
     o.fwd_pad = env_int("UMNN_FWD_PAD", 1) != 0;
     o.fwd_pad_min = env_int("UMNN_FWD_PAD_MIN", 1);
     v = env_int("UMNN_BWD_NS", -1); o.bwd_ns = v >= 1 && v <= 32 ? v : -1;
+    o.bwd_swp = env_int("UMNN_BWD_SWP", 1) != 0;
 }
 UmnnOptions& umnn_options() {
     static UmnnOptions opts;
@@ -107,11 +108,27 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "fwd_pad")) return &o.fwd_pad;
     if (!strcmp(name, "fwd_pad_min")) return &o.fwd_pad_min;
     if (!strcmp(name, "bwd_ns")) return &o.bwd_ns;
+    if (!strcmp(name, "bwd_swp")) return &o.bwd_swp;
     return nullptr;
+}
+// the same per-option ranges load_env accepts (anything else would reach the launchers as "no such variant")
+static bool option_value_ok(const char* name, int v) {
+    if (!strcmp(name, "fwd_precision")) return v >= UMNN_PRECISION_FP32 && v <= UMNN_PRECISION_BF16X6;
+    if (!strcmp(name, "bwd_precision")) return v == UMNN_PRECISION_FP32 || v == UMNN_PRECISION_BF16X3;
+    if (!strcmp(name, "fwd_p")) return v == -1 || v == 1 || v == 2;
+    if (!strcmp(name, "fwd_ns")) return v == -1 || v == 1 || v == 2 || v == 4;
+    if (!strcmp(name, "fwd_tail")) return v == -1 || v == 0 || v == 1;
+    if (!strcmp(name, "fwd_pipe")) return v >= 0 && v <= 2;
+    if (!strcmp(name, "fwd_pad")) return v == 0 || v == 1;
+    if (!strcmp(name, "fwd_pad_min")) return v >= 0 && v <= 127;
+    if (!strcmp(name, "bwd_ns")) return v == -1 || (v >= 1 && v <= 32);
+    if (!strcmp(name, "bwd_swp")) return v == 0 || v == 1;
+    return true;
 }
 extern "C" int umnn_set_option(const char* name, int value) {
     std::atomic<int>* s = option_slot(name);
     if (!s) return umnn_fail(UMNN_EINVAL, "umnn_set_option: unknown option name");
+    if (!option_value_ok(name, value)) return umnn_fail(UMNN_EINVAL, "umnn_set_option: value out of range for this option");
     s->store(value, std::memory_order_relaxed);
     return 0;
 }

@@ -674,7 +674,9 @@ static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan
     pl->ws_dc = o; o += a.NI * H1 * 4 * pl->ns; o = (o + 255) & ~255LL;
     pl->ws_p0 = o; o += (long long)pl->nparts0 * H1 * (E + 1) * 4; o = (o + 255) & ~255LL;
     pl->ws_front = o;
-    pl->ws_front_bytes = (umnn_backward_front_shape(a.m) && pl->wpb == 4) ? umnn_backward_front_scratch_bytes(a.m, a.NI) : 0;
+    // (only the bf16x3 staged kernels use it: under bwd_precision = fp32 the reservation would be a dead 2 GiB per call)
+    pl->ws_front_bytes = (umnn_options().bwd_precision == UMNN_PRECISION_BF16X3 && umnn_backward_front_shape(a.m) && pl->wpb == 4)
+                             ? umnn_backward_front_scratch_bytes(a.m, a.NI) : 0;
     o += pl->ws_front_bytes; o = (o + 255) & ~255LL;
     pl->ws_total = o;
     return 0;

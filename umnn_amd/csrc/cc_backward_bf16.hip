@@ -2,6 +2,7 @@
 // template, with its layout notes, lives in cc_bwd_bf16_kernel.h and is shared with the staged backward of
 // cc_backward_front.hip).
 #include "cc_bwd_bf16_kernel.h"
+#include "cc_bwd_swp_kernel.h"
 
 // ------------------------------------------------------------------------------------------
 typedef void (*bwd_bf16_kernel_t)(const BwdBf16Args);
@@ -13,6 +14,14 @@ struct BwdBf16Variant { int lh, edge, nrl; bwd_bf16_kernel_t fn; const char* nam
 static const BwdBf16Variant kBwdBf16Variants[] = {
     BWD_BF16_VARIANT(4, 1, 13), BWD_BF16_VARIANT(3, 1, 13), BWD_BF16_VARIANT(2, 1, 13),
     BWD_BF16_VARIANT(4, 1, 0), BWD_BF16_VARIANT(3, 1, 0), BWD_BF16_VARIANT(2, 1, 0),
+};
+
+// software-pipelined loop (cc_bwd_swp_kernel.h): same variants, same results, one shared W / W^T image
+struct BwdSwpVariant { int lh, nrl; bwd_bf16_kernel_t fn; const char* name; };
+#define BWD_SWP_VARIANT(LHH, NR) { LHH, NR, cc_bwd_swp_kernel<LHH, NR>, "cc_bwd_bf16<L=" #LHH ",LIVE=" #NR ",SWP>" }
+static const BwdSwpVariant kBwdSwpVariants[] = {
+    BWD_SWP_VARIANT(4, 13), BWD_SWP_VARIANT(3, 13), BWD_SWP_VARIANT(2, 13),
+    BWD_SWP_VARIANT(4, 0), BWD_SWP_VARIANT(3, 0), BWD_SWP_VARIANT(2, 0),
 };
 
 // Plans and launches the main backward pass with the bf16 kernels.  Returns UMNN_EUNSUPPORTED when the shape is
@@ -33,6 +42,29 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
     }
     if (tmax < 3) return UMNN_EUNSUPPORTED;        // one or two tiles per layer: the fp32 kernels waste less
     if (nrl != 13) nrl = 0;
+    a.ngroups = (unsigned)((a.NI + 15) / 16);
+    if (a.ns > a.n + 1) a.ns = a.n + 1;
+    if (umnn_options().bwd_swp) {
+        const BwdSwpVariant* sv = nullptr;
+        for (const BwdSwpVariant& c : kBwdSwpVariants)
+            if (c.nrl == nrl && c.lh == L) { sv = &c; break; }
+        const size_t lds_swp = ((size_t)(L - 1) * BT * BKS * NPF * FRAG + (size_t)UMNN_WAVES_PER_BLOCK * L * NPB * 16 * TRS) * sizeof(unsigned short);
+        if (sv && lds_swp <= 160 * 1024) {
+            const long long items = (long long)a.ngroups * (a.ns > 1 ? a.ns : 1);
+            int nblocks = nblocks_max;
+            if ((long long)nblocks * UMNN_WAVES_PER_BLOCK > items)
+                nblocks = (int)((items + UMNN_WAVES_PER_BLOCK - 1) / UMNN_WAVES_PER_BLOCK);
+            if (nblocks < 1) nblocks = 1;
+            *nwaves_out = nblocks * UMNN_WAVES_PER_BLOCK;
+            a.l_lo = 1;
+            if (int rc = umnn_allow_lds((const void*)sv->fn, lds_swp)) return rc;
+            umnn_prof_begin(stream);
+            hipLaunchKernelGGL(sv->fn, dim3(nblocks), dim3(UMNN_BLOCK), lds_swp, stream, args);
+            umnn_prof_end(stream, 3.0 * umnn_cc_forward_flops_per_integral(net, a.n) * (double)a.NI, UMNN_PROF_BACKWARD);
+            umnn_note_launch(sv->name);
+            return umnn_check(hipGetLastError(), "cc_bwd_bf16 (swp) launch");
+        }
+    }
     int off16 = 0;
     for (int l = 1; l < L; ++l) { args.off_fwd[l] = off16; off16 += BT * BKS * NPF * FRAG; }
     for (int l = 1; l < L; ++l) { args.off_tr[l] = off16; off16 += BT * BKS * NPB * FRAG; }
@@ -40,7 +72,6 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
     off16 += UMNN_WAVES_PER_BLOCK * NPB * 16 * TRS;
     const size_t lds_bytes = (size_t)off16 * sizeof(unsigned short);
     if (lds_bytes > 160 * 1024) return UMNN_EUNSUPPORTED;
-    a.ngroups = (unsigned)((a.NI + 15) / 16);
     const long long items = (long long)a.ngroups * (a.ns > 1 ? a.ns : 1);
     int nblocks = nblocks_max;
     if ((long long)nblocks * UMNN_WAVES_PER_BLOCK > items)

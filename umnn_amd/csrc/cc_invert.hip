@@ -37,6 +37,10 @@ extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const f
     if (!h || !z || !scaling || !cc_w || !cc_s || !x_inv) return umnn_fail(UMNN_EINVAL, "invert: null pointer");
     const int L = a.m.n_linear - 1;
     if (L < 2) return umnn_fail(UMNN_EUNSUPPORTED, "invert: the matrix-core kernels need at least two hidden layers");
+    // the search kernels exist in bf16x3 arithmetic only: under fwd_precision = fp32 / bf16x6 ("exact products everywhere") the
+    // caller keeps its host-driven search on the forward kernels of that mode instead of silently sampling with ~6e-6 integrals
+    if (umnn_options().fwd_precision != UMNN_PRECISION_BF16X3)
+        return umnn_fail(UMNN_EUNSUPPORTED, "invert: the in-kernel search is bf16x3 arithmetic; the forward precision asks for exact products");
     a.x0 = nullptr; a.x = nullptr; a.h = h; a.ccw = cc_w; a.ccs = cc_s;
     a.F = a.fx = a.fx0 = nullptr; a.scaling = scaling; a.z = nullptr; a.logjac = nullptr; a.logjac_in = nullptr;
     a.reverse_z = 0; a.ll = nullptr; a.row_cnt = nullptr; a.ll_first = a.ll_last = 0;

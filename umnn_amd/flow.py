@@ -226,7 +226,9 @@ class UMNNMAF(nn.Module):
                 scaling = self.scaling.detach().float().contiguous()
                 done = True
                 for j in range(self.input_size):
-                    h = self.net.make_embeding(x_inv, context).contiguous()
+                    # umnn_flow_invert_dim reads an fp32 embedding (it has no umnn_io descriptor): a bf16 embedding
+                    # (set_embedding_dtype, autocast) is widened here -- exact -- instead of being misread as fp32
+                    h = self.net.make_embeding(x_inv, context).float().contiguous()
                     if not _I.hip_invert_dim(spec, h, z, scaling, self.nb_steps, j, iter, x_inv):
                         done = False
                         break
@@ -352,11 +354,12 @@ class UMNNMAFFlow(nn.Module):
                 x = x.contiguous()
                 ll = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
                 scratch = torch.empty_like(x)
+                cnt = _I.ll_counters(x.shape[0], x.device)      # (under a hipGraph capture: this call's own zeroed buffer)
                 nb = len(self.nets)
                 for i, net in enumerate(self.nets):
                     h = net.net.make_embeding(x, context)
                     x = _I.hip_flow_ll_block(mlp_spec(net.net.parallel_nets), x, h.contiguous(), net.scaling, net.nb_steps,
-                                             reverse_z=i + 1 < nb, first=i == 0, last=i + 1 == nb, ll=ll, scratch=scratch)
+                                             reverse_z=i + 1 < nb, first=i == 0, last=i + 1 == nb, ll=ll, scratch=scratch, cnt=cnt)
             return ll, x
         z, log_jac = self._stack(x, context, True)
         log_prob_gauss = -.5 * (torch.log(self.pi * 2) + z ** 2).sum(1)

@@ -39,12 +39,8 @@ class GraphedLL:
                     self._run()
             torch.cuda.current_stream(self.x.device).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
-            made._CAPTURE["cache_ok"] = True
-            try:
-                with torch.cuda.graph(self.graph):
-                    self.out = self._run()
-            finally:
-                made._CAPTURE["cache_ok"] = False
+            with made.capture_may_cache(), torch.cuda.graph(self.graph):
+                self.out = self._run()
         self._seen = self._versions()
         self.captures += 1
 

@@ -32,9 +32,15 @@ from . import _lib
 from .nets import mlp_spec
 from .quadrature import compute_cc_weights, device_tables
 
-_state = threading.local()
-_force_generic = False
-_warned_host = False
+_state = threading.local()           # per-thread: last path taken, force_generic nesting
+_warned = set()                       # fallbacks announced once per process (see _warn_once)
+
+
+def _warn_once(key, message):
+    """Every fallback off the HIP kernels is announced the first time it is taken (and ``path_taken()`` reports it)."""
+    if key not in _warned:
+        _warned.add(key)
+        warnings.warn(message, RuntimeWarning, stacklevel=3)
 
 
 def path_taken():
@@ -43,15 +49,15 @@ def path_taken():
 
 
 class force_generic:
-    """Context manager: integrate MLP integrands with the generic ATen path too (A/B comparisons)."""
+    """Context manager: integrate MLP integrands with the generic ATen path too (A/B comparisons).  Thread-local: only the
+    calling thread's integrals are rerouted (autograd's backward worker threads are told through the saved context)."""
 
     def __enter__(self):
-        global _force_generic
-        self._old, _force_generic = _force_generic, True
+        self._old = getattr(_state, "force_generic", False)
+        _state.force_generic = True
 
     def __exit__(self, *exc):
-        global _force_generic
-        _force_generic = self._old
+        _state.force_generic = self._old
 
 
 def _flatten(sequence):
@@ -101,14 +107,11 @@ def _desc(spec):
 
 
 def _use_hip(spec, x):
-    global _warned_host
-    if spec is None or _force_generic:
+    if spec is None or getattr(_state, "force_generic", False):
         return False
     if not x.is_cuda:
-        if not _warned_host:
-            warnings.warn("umnn_amd: MLP integrand on host tensors -> generic ATen quadrature "
-                          "(the HIP kernels need GPU tensors; move the model and data to 'cuda').")
-            _warned_host = True
+        _warn_once("host", "umnn_amd: MLP integrand on host tensors -> generic ATen quadrature "
+                           "(the HIP kernels need GPU tensors; move the model and data to 'cuda').")
         return False
     if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         return False
@@ -140,6 +143,11 @@ def _hip_backward_ok(spec, x, h):
     if kind is None:
         desc, keep = _desc(spec)
         kind = _bwd_kind[key] = _lib.lib().umnn_cc_backward_kind(ctypes.byref(desc), E)
+    if kind < 0:
+        _warn_once(("bwd-aten", key[0]),
+                   f"umnn_amd: the HIP backward has no shape-exact kernel for integrand widths {[w for _, w in key[0]]} "
+                   "(several unequal hidden layers above 63 units): differentiating with the materialised ATen chain on the "
+                   "GPU instead (forward stays on the HIP kernel; umnn_amd.set_backward_wide(True) forces the HIP kernels).")
     return kind >= 0
 
 
@@ -264,6 +272,10 @@ def hip_invert_dim(spec, h, z, scaling, nb_steps, j, iters, x_inv):
         rc = lib.umnn_flow_invert_dim(ctypes.byref(desc), _ptr(h), _ptr(z), _ptr(scaling), _ptr(w), _ptr(s), int(nb_steps),
                                       B, d, E, int(j), int(iters), _ptr(x_inv), stream)
     if rc == _lib.EUNSUPPORTED:
+        _warn_once(("invert-host", tuple(l.out_features for l in spec.linears), _lib.get_forward_precision()),
+                   "umnn_amd: no in-kernel inversion for this integrand / arithmetic mode "
+                   f"({_lib.lib().umnn_last_error().decode('utf-8', 'replace')}): UMNNMAF.invert runs the host-driven bracket "
+                   "search (d x iter forward launches per block).")
         return False
     _lib.check(rc, "umnn_flow_invert_dim")
     _state.path = "hip"
@@ -274,16 +286,30 @@ _row_counters = {}     # (device index, stream handle) -> zeroed uint32 [>= B] a
 
 
 def _counters(B, device, stream_handle):
+    """Row-arrival counters of the one-pass log-likelihood.  Eager calls share one zeroed buffer per (device, stream): the
+    finishing wave of every row resets its counter, so the buffer is all-zero again when the launch retires.  Under a
+    hipGraph capture nothing may be created-and-cached (a tensor born in a capture lives in that graph's private pool and
+    its zero-fill is a captured node, not an executed one): ``compute_ll`` asks ``fresh_counters`` for a buffer per captured
+    call instead, whose memset is then part of every replay of that graph."""
     key = (device.index, stream_handle)
     t = _row_counters.get(key)
     if t is None or t.numel() < B:
+        assert not torch.cuda.is_current_stream_capturing()
         t = _row_counters[key] = torch.zeros(max(B, 1024), dtype=torch.int32, device=device)
     return t
 
 
-def hip_flow_ll_block(spec, x, h, scaling, nb_steps, reverse_z, first, last, ll, scratch):
+def ll_counters(B, device):
+    """Counter buffer for one ``UMNNMAFFlow.compute_ll`` call on the current stream (see _counters)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(B, dtype=torch.int32, device=device)        # this graph's own buffer and memset node
+    return _counters(B, device, torch.cuda.current_stream(device).cuda_stream)
+
+
+def hip_flow_ll_block(spec, x, h, scaling, nb_steps, reverse_z, first, last, ll, scratch, cnt=None):
     """One link of UMNNMAFFlow.compute_ll with the whole log-likelihood arithmetic inside the launch
-    (umnn_flow_ll_block_forward): -> z; ``ll`` [B] is updated in place, ``scratch`` [B,d] is this launch's own."""
+    (umnn_flow_ll_block_forward): -> z; ``ll`` [B] is updated in place, ``scratch`` [B,d] is this launch's own; ``cnt`` the
+    zeroed int32 [>= B] row-arrival counters (``ll_counters``; the launch leaves them zero)."""
     lib = _lib.lib()
     B, d, E = _shape(spec, x, h)
     z = torch.empty_like(x)
@@ -291,7 +317,8 @@ def hip_flow_ll_block(spec, x, h, scaling, nb_steps, reverse_z, first, last, ll,
     desc, keep = _desc(spec)
     with torch.cuda.device(x.device):
         handle = torch.cuda.current_stream(x.device).cuda_stream
-        cnt = _counters(B, x.device, handle)
+        if cnt is None:
+            cnt = ll_counters(B, x.device)
         rc = lib.umnn_flow_ll_block_forward(ctypes.byref(desc), _ptr(x), _ptr(h), _ptr(scaling), _ptr(w), _ptr(s),
                                             int(nb_steps), B, d, E, 1 if reverse_z else 0, 1 if first else 0,
                                             1 if last else 0, _ptr(z), _ptr(scratch), _ptr(ll), _ptr(cnt),
@@ -483,7 +510,8 @@ def _op_forward(ctx, x0, x, integrand, h, nb_steps, inv_f):
     ctx.spec = spec
     # clones: callers mutate their tensors in place after the call (UMNNMAF.compute_ll clamps z, :150)
     ctx.save_for_backward(x0.clone(), x.clone(), h)
-    if _use_hip(spec, x):
+    ctx.use_hip = _use_hip(spec, x)       # decided on the calling thread (force_generic is thread-local; backward runs elsewhere)
+    if ctx.use_hip:
         return hip_forward(spec, x0, x, h, nb_steps, inv_f)[0]
     return aten_forward(integrand, x0, x, h, nb_steps, inv_f)
 
@@ -491,7 +519,7 @@ def _op_forward(ctx, x0, x, integrand, h, nb_steps, inv_f):
 def _op_backward(ctx, grad_output):
     x0, x, h = ctx.saved_tensors
     integrand, nb_steps, inv_f, spec = ctx.integrand, ctx.nb_steps, ctx.inv_f, ctx.spec
-    if _use_hip(spec, x) and _hip_backward_ok(spec, x, h):
+    if ctx.use_hip and _hip_backward_ok(spec, x, h):
         need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[4], ctx.needs_input_grad[3])
         dx0, dx, dh, dtheta = hip_backward(spec, x0, x, h, grad_output, None, nb_steps, need, inv_f=inv_f)
         return dx0, dx, dtheta, dh

@@ -16,6 +16,8 @@ keeps the fp32 ``F.linear`` chain.
 import ctypes
 import math
 import os
+import threading
+import warnings
 
 import numpy as np
 import torch
@@ -23,7 +25,19 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-_CAPTURE = {"cache_ok": False}
+_capture_state = threading.local()      # .cache_ok: a capture on THIS thread that tracks weight versions itself (GraphedLL)
+
+
+class capture_may_cache:
+    """Context manager (graphs.GraphedLL): the hipGraph being captured on this thread re-captures when a weight version
+    moves, so the conditioner's cached masked / packed weights may be baked into it."""
+
+    def __enter__(self):
+        self._old = getattr(_capture_state, "cache_ok", False)
+        _capture_state.cache_ok = True
+
+    def __exit__(self, *exc):
+        _capture_state.cache_ok = self._old
 
 
 class MaskedLinear(nn.Linear):
@@ -51,7 +65,7 @@ class MaskedLinear(nn.Linear):
     @staticmethod
     def _capturing(t):
         # a capture that tracks the weights' versions itself (graphs.GraphedLL re-captures when they move) may bake the caches in
-        return t.is_cuda and not _CAPTURE["cache_ok"] and torch.cuda.is_current_stream_capturing()
+        return t.is_cuda and not getattr(_capture_state, "cache_ok", False) and torch.cuda.is_current_stream_capturing()
 
     def masked_weight(self):
         if torch.is_grad_enabled() and self.weight.requires_grad:
@@ -117,14 +131,17 @@ def _fast_path_ok(x):
     if not _FAST["enabled"]:
         return False
     if _FAST["ok"] is None:
+        from . import _lib
+        _lib.lib()              # a missing HIP library is an error on a GPU box (HipLibraryMissing), never a silent fallback
         try:
-            from . import _lib
-            _lib.lib()
             a = torch.zeros(8, 8, dtype=torch.bfloat16, device=x.device)
             torch.mm(a, a.t(), out_dtype=torch.float32)
             _FAST["ok"] = True
-        except Exception:       # older torch without out_dtype, or library missing: fp32 F.linear chain
+        except (TypeError, RuntimeError, NotImplementedError) as e:     # a torch build without mm(out_dtype=) on this device
             _FAST["ok"] = False
+            warnings.warn("umnn_amd: torch.mm(bf16, bf16, out_dtype=float32) is not available here "
+                          f"({type(e).__name__}: {e}); the inference conditioner runs the fp32 F.linear chain instead of the "
+                          "K-concatenated bf16 GEMMs.", RuntimeWarning, stacklevel=3)
     return _FAST["ok"]
 
 

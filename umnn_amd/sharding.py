@@ -9,8 +9,9 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Join the process group torchrun described in the environment.  Returns (rank, world, device)."""
+def init_from_env(backend=None, force_group=False):
+    """Join the process group torchrun described in the environment.  Returns (rank, world, device).  ``force_group``: create
+    the group even for WORLD_SIZE=1 (a one-rank RCCL group: lets a single-GPU box exercise the collective code paths)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -20,8 +21,9 @@ def init_from_env(backend=None):
     device = torch.device("cuda", local % torch.cuda.device_count()) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         # RCCL / device-tensor sharing between the ranks of a node goes through dmabuf IPC on this driver stack; the legacy
         # mode fails with "hipIpcGetMemHandle: invalid argument".  Only a default: an explicit setting wins.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -54,13 +56,14 @@ def _all_reduce_sum(flat):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
 
-def allreduce_gradients(module, world=None, average=True):
+def allreduce_gradients(module, world=None, average=True, force=False):
     """One flattened all-reduce(SUM) over every trainable gradient (a few MB: latency-bound on xGMI, so one
     message is the right shape), then scatter back.  Call after backward and BEFORE gradient clipping so that
-    clipping sees the same global gradient a single process would (UCIExperiments.py:143)."""
+    clipping sees the same global gradient a single process would (UCIExperiments.py:143).  ``force``: issue the collective
+    even in a one-rank group (tests of the RCCL path on a single GPU)."""
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return
     params = [p for p in module.parameters() if p.requires_grad]
     for p in params:
@@ -76,9 +79,9 @@ def allreduce_gradients(module, world=None, average=True):
         p.grad = v
 
 
-def broadcast_parameters(module, src=0):
-    """Make every replica start from rank src's weights (and buffers)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def broadcast_parameters(module, src=0, force=False):
+    """Make every replica start from rank src's weights (and buffers).  ``force``: also in a one-rank group."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return
     from .made import invalidate_caches
     with torch.no_grad():
