@@ -248,6 +248,11 @@ def main():
         sharding.broadcast_parameters(model)
         opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, capturable=bool(args.graph))
         step = make_train_step(model, opt, x, ctx, world)
+        graph_note = None
+        if args.graph and world > 1 and dist.get_backend() == "nccl":
+            # RCCL collectives cannot be captured in a hipGraph on this stack (umnn_amd/graphs.py): eager step instead
+            graph_note = "--graph ignored: data-parallel training runs the eager step (RCCL collectives cannot be captured)"
+            args.graph = False
         if args.graph:      # the whole step (fwd, HIP bwd, all-reduce hook, clipping, Adam) as one replayed hipGraph
             import umnn_amd
             gstep = umnn_amd.GraphedTrainStep(model, opt, x, context=ctx, clip_value=10.0,
@@ -426,6 +431,8 @@ def main():
             out["full_batch_n1"] = full
         if args.mode == "train":
             out["config"]["mode"] = "train: fwd + HIP bwd + flattened gradient all-reduce (RCCL) + value clipping + Adam"
+            if graph_note:
+                out["config"]["graph"] = graph_note
             out["train_kernels"] = {
                 "forward": {"ms": fwd[0], "launches": fwd[1], "avg_launch_ms": fwd[0] / max(1, fwd[1])},
                 "backward_main": {"ms": bwd[0], "launches": bwd[1], "avg_launch_ms": bwd[0] / max(1, bwd[1])},

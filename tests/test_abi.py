@@ -86,3 +86,25 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.HipLibraryMissing):
         _lib.lib()
+
+
+def test_set_option_validates_ranges_without_gpu():
+    """umnn_set_option accepts exactly the values load_env accepts: anything else is UMNN_EINVAL and leaves
+    the option untouched; the documented values round-trip."""
+    for name, good, bad in (("fwd_p", (1, 2, -1), (0, 3)), ("fwd_ns", (1, 2, 4, -1), (3, 8)), ("fwd_precision", (0, 1, 2), (-1, 3, 7)),
+                            ("bwd_precision", (0, 1), (2,)), ("bwd_ns", (1, 32, -1), (0, 33, 64)), ("fwd_pipe", (0, 1, 2), (3, -1)),
+                            ("bwd_swp", (0, 1), (2, -1)), ("fwd_tail", (0, 1, -1), (2,))):
+        old = _lib.get_option(name)
+        try:
+            for v in good:
+                _lib.set_option(name, v)
+                assert _lib.get_option(name) == v
+            for v in bad:
+                before = _lib.get_option(name)
+                with pytest.raises(RuntimeError):
+                    _lib.set_option(name, v)
+                assert _lib.get_option(name) == before
+        finally:
+            _lib.set_option(name, old)
+    with pytest.raises(RuntimeError):
+        _lib.set_option("no_such_option", 1)

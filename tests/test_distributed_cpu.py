@@ -132,3 +132,42 @@ def test_bench_train_step_two_ranks_equals_single_process():
     for k in ref:
         assert torch.allclose(parts[0][k], parts[1][k], atol=0, rtol=0), k             # replicas stay bit-identical
         assert torch.allclose(parts[0][k], ref[k], atol=2e-6, rtol=1e-5), k
+
+
+def _one_rank_worker(port, q):
+    import os
+    os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    import umnn_amd
+    from umnn_amd import sharding
+    rank, world, dev = sharding.init_from_env(backend="gloo", force_group=True)
+    assert dist.is_initialized() and dist.get_world_size() == 1
+    torch.manual_seed(0)
+    model = umnn_amd.UMNNMAFFlow(nb_flow=1, nb_in=3, hidden_derivative=[16, 16], hidden_embedding=[16], embedding_s=4,
+                                 nb_steps=10, solver="CCParallel")
+    w0 = [p.detach().clone() for p in model.parameters()]
+    sharding.broadcast_parameters(model, force=True)
+    assert all(torch.equal(a, b) for a, b in zip(w0, model.parameters()))
+    ll, _ = model.compute_ll(torch.randn(8, 3))
+    (-ll.mean()).backward()
+    g0 = [p.grad.clone() for p in model.parameters() if p.requires_grad]
+    sharding.allreduce_gradients(model, world)                 # world == 1: early return, gradients untouched
+    assert all(p.grad._base is None for p in model.parameters() if p.requires_grad)
+    sharding.allreduce_gradients(model, world, force=True)     # the collective path: flattened buffer, views back
+    g1 = [p.grad for p in model.parameters() if p.requires_grad]
+    assert all(torch.equal(a, b) for a, b in zip(g0, g1)) and all(g._base is not None for g in g1)
+    dist.destroy_process_group()
+    q.put("ok")
+
+
+def test_one_rank_group_forced_collectives():
+    """sharding's ``force`` switches (used by the one-rank RCCL test on the GPU box) on the gloo backend: a world-size-1
+    group, broadcast and the flattened all-reduce really run and leave the gradients as views of one buffer."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_one_rank_worker, args=(29671, q))
+    pr.start()
+    pr.join(120)
+    assert pr.exitcode == 0 and q.get(timeout=5) == "ok"

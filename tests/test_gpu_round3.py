@@ -191,44 +191,78 @@ sys.path.insert(0, {root!r})
 os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29653")
 import umnn_amd
 from umnn_amd import sharding
+def mark(m): print("MARK", m, flush=True)
 rank, world, dev = sharding.init_from_env(backend="nccl", force_group=True)
+mark("group")
 assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1 and dev.type == "cuda"
 torch.manual_seed(0)
 model = umnn_amd.UMNNMAFFlow(nb_flow=2, nb_in=6, hidden_derivative=[50] * 4, hidden_embedding=[64, 64], embedding_s=30,
                              nb_steps=20, solver="CCParallel").to(dev).train()
 w0 = [p.detach().clone() for p in model.parameters()]
 sharding.broadcast_parameters(model, force=True)                      # RCCL broadcast of every parameter and buffer
+mark("broadcast")
 assert all(torch.equal(a, b) for a, b in zip(w0, model.parameters()))
 t = torch.arange(1024., device=dev)
 sharding._all_reduce_sum(t)                                           # RCCL all_reduce on a device tensor
 torch.cuda.synchronize()
 assert torch.equal(t, torch.arange(1024., device=dev))
+mark("all_reduce")
 x = torch.randn(100, 6, device=dev)
 ll, _ = model.compute_ll(x)
 (-ll.mean()).backward()
+del ll                    # no autograd graph built on the DEFAULT stream may outlive this point: its AccumulateGrad nodes would
+torch.cuda.synchronize()  # run on the legacy stream during the capture below (see GraphedTrainStep's docstring)
+mark("backward")
 g0 = [p.grad.detach().clone() for p in model.parameters() if p.requires_grad]
 sharding.allreduce_gradients(model, world, force=True)                # the flattened all-reduce, not short-circuited
 g1 = [p.grad for p in model.parameters() if p.requires_grad]
 assert all(torch.equal(a, b) for a, b in zip(g0, g1))
 base = g1[0]._base if g1[0]._base is not None else g1[0]
 assert all((g._base is base) for g in g1), "gradients must be views of the one reduced buffer"
-# the whole optimisation step as one hipGraph WITH the collective inside
+mark("allreduce_gradients")
+# one eager data-parallel optimisation step with the collective, on a side stream as a training loop would run it
 opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, capturable=True)
-step = umnn_amd.GraphedTrainStep(model, opt, x, clip_value=10.0,
-                                 grad_hook=lambda m: sharding.allreduce_gradients(m, world, force=True))
+ref = [p.detach().clone() for p in model.parameters()]
+losses = []
+for it in range(3):
+    opt.zero_grad(set_to_none=True)
+    ll, _ = model.compute_ll(x)
+    loss = -ll.mean()
+    loss.backward()
+    sharding.allreduce_gradients(model, world, force=True)
+    torch.nn.utils.clip_grad_value_(list(model.parameters()), 10.0)
+    opt.step()
+    losses.append(float(loss))
+    del ll, loss
+assert losses[2] < losses[0] and any(not torch.equal(a, b) for a, b in zip(ref, model.parameters()))
+mark("eager steps %s" % losses)
+# graphs: inference capture works beside the process group; a captured training step must REFUSE a collective hook
+model.eval()
+gl = umnn_amd.GraphedLL(model, x)
+with torch.no_grad():
+    assert torch.equal(gl()[0], model.compute_ll(x)[0])
+model.train()
+try:
+    umnn_amd.GraphedTrainStep(model, opt, x, clip_value=10.0, grad_hook=lambda m: sharding.allreduce_gradients(m, world, force=True))
+    raise SystemExit("GraphedTrainStep accepted a collective hook under a nccl group")
+except NotImplementedError:
+    mark("graphed train step refuses the collective hook")
+step = umnn_amd.GraphedTrainStep(model, opt, x, clip_value=10.0)          # without a hook it captures beside the group
 l1 = float(step()); l2 = float(step()); l3 = float(step(torch.randn(100, 6, device=dev)))
 assert all(map(lambda v: v == v and abs(v) < 1e6, (l1, l2, l3))), (l1, l2, l3)
-assert l2 < l1 + 1.0
+assert l2 < l1
 dist.barrier()
 dist.destroy_process_group()
-print("RCCL_WORLD1_OK", l1, l2, l3)
+print("RCCL_WORLD1_OK", losses, l1, l2, l3)
 """
 
 
 def test_one_rank_rccl_group_broadcast_allreduce_and_captured_train_step(dev, tmp_path):
     """RCCL had never executed for this code.  One GPU allows a one-rank ``nccl`` group: init with
-    ``device_id=``, ``broadcast_parameters``, a forced ``_all_reduce_sum`` / ``allreduce_gradients`` on device tensors, and
-    ``GraphedTrainStep`` captured with the gradient hook issuing the collective (not the world == 1 early return)."""
+    ``device_id=``, ``broadcast_parameters``, a forced ``_all_reduce_sum`` / ``allreduce_gradients`` on device tensors, eager
+    optimisation steps with the collective, hipGraph captures beside the group.  First contact found that capturing an RCCL
+    collective in a hipGraph segfaults on this stack: ``GraphedTrainStep`` refuses a gradient hook under a nccl group
+    (umnn_amd/graphs.py has the details), which is asserted here."""
     script = tmp_path / "rccl_world1.py"
     script.write_text(_RCCL_SCRIPT.format(root=ROOT))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -255,7 +289,7 @@ def test_fallbacks_off_the_hip_kernels_warn_once_and_report_their_path(dev):
         F = umnn_amd.ParallelNeuralIntegral.apply(torch.zeros_like(x), x, net, umnn_amd.flow._flatten(net.parameters()), h, 20)
         assert umnn_amd.path_taken() == "hip"
         F.sum().backward()
-        assert umnn_amd.path_taken() == "aten"
+        assert umnn_amd.backward_path_taken() == "aten"      # (backward runs on autograd's thread: process-wide record)
         n_first = sum("materialised ATen chain" in str(w.message) for w in rec)
         F2 = umnn_amd.ParallelNeuralIntegral.apply(torch.zeros_like(x), x, net, umnn_amd.flow._flatten(net.parameters()), h, 20)
         F2.sum().backward()
@@ -310,11 +344,14 @@ def test_set_option_rejects_out_of_range_values(dev):
 @pytest.mark.parametrize("shape", [(257, 63, 30, [50] * 4, 100), (100, 6, 30, [50] * 3, 50), (64, 5, 8, [50] * 2, 20),
                                    (33, 7, 12, [40, 56, 33, 48], 30), (5, 3, 4, [48, 60, 36], 7), (2000, 2, 10, [50] * 4, 20)])
 @pytest.mark.parametrize("with_gfx", [False, True])
-def test_software_pipelined_backward_is_bit_identical_to_the_round2_loop(shape, with_gfx, dev):
+def test_software_pipelined_backward_agrees_with_the_round2_loop(shape, with_gfx, dev):
     """cc_bwd_swp_kernel (F(k+1) overlapped with B(k), a_l through LDS slots, W^T fragments read out of the forward image
     with transposing reads) performs the same MFMAs on the same operands in the same accumulation order as
-    cc_bwd_bf16_kernel: every output must match bit for bit, for every variant (L = 2..4 hidden layers, LIVE = 13 / 0),
-    small batches with the node-range split included."""
+    cc_bwd_bf16_kernel.  The Leibniz outputs (dx0, dx) and the output layer's gradient must match bit for bit (the forward
+    recompute is the same instruction stream); d_h and the hidden layers' d_theta may differ in the last bits -- the
+    compiler contracts the split residual ``x - bf16(x)`` with the product that formed x differently in the two code shapes
+    (measured 1e-7 of the largest entry) -- so they are held to 2e-6, two orders inside the path tolerance.  Every variant
+    (L = 2..4 hidden layers, LIVE = 13 / 0) and the small-batch node-range split are covered."""
     import umnn_amd
     from umnn_amd import _lib
     from umnn_amd import integral as I
@@ -335,5 +372,10 @@ def test_software_pipelined_backward_is_bit_identical_to_the_round2_loop(shape, 
             outs[swp] = I.hip_backward(spec, x0, x, h, gg, gf, n)
             name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
             assert ("SWP" in name) == bool(swp), name
-    for a_, b_ in zip(outs[0], outs[1]):
-        assert torch.equal(a_, b_)
+            again = I.hip_backward(spec, x0, x, h, gg, gf, n)
+            assert all(torch.equal(u, v) for u, v in zip(outs[swp], again)), "each loop is bit-reproducible"
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    n_last = spec.linears[-1].weight.numel() + 1
+    assert torch.equal(outs[0][3][-n_last:], outs[1][3][-n_last:])
+    for a_, b_ in zip(outs[0][2:], outs[1][2:]):
+        assert U.scaled_err(b_.cpu().numpy(), a_.cpu().numpy()) < 2e-6

@@ -1,34 +1,47 @@
 // Software-pipelined one-pass backward on the bf16 matrix cores (round 3).  Same arithmetic, operands and accumulation
-// order as cc_bwd_bf16_kernel (cc_bwd_bf16_kernel.h; reference lines ParallelNeuralIntegral.py:66-94,110-123) -- results are
-// bit-identical -- but the node loop is restructured so that ONE wave carries TWO independent dependency chains:
+// order as cc_bwd_bf16_kernel (cc_bwd_bf16_kernel.h; reference lines ParallelNeuralIntegral.py:66-94,110-123): dx, dx0 and the
+// output layer's gradient are bit-identical, d_h and the hidden layers' d_theta agree to ~1e-7 of their largest entry (the
+// compiler contracts the split residual with the product that formed the value differently in the two code shapes).  What
+// changes is the node loop: ONE wave now carries TWO independent dependency chains,
 //
 //     iteration k :   B(k)   = backward sweep of node k        (delta chain through W^T, dW += delta (x) a)
 //                     F(k+1) = forward recompute of node k+1   (six-term split GEMMs, activations, output layer)
 //
-// The old loop ran F(k) then B(k): split -> GEMM -> activation -> split -> ... is one serial chain, and with one wave per
-// SIMD (the 192 dW accumulators need the whole register file) every MFMA -> VALU -> MFMA dependency was exposed: matrix
-// pipe 53 % busy.  Here stage i of an iteration pairs F's layer i with B's layer L-i:
-//     S1  a_{L-i}(k): transposed dW operand + sign piece read from its LDS slot X
-//     S2  split a_i(k+1) (3 pieces), pieces 0/1 stored INTO X (B's reads of X were issued first; LDS is in order)
-//     S3  split delta_{L-i+1}(k) (2 pieces), stored to the delta slot
-//     S4  W^T GEMM (24 MFMA)        S5  forward GEMM (48 MFMA)
-//     S6  dW += delta (x) a (48 MFMA) -- feeds accumulators only: S7 and the next stage's S1..S3 (all VALU / LDS) run in
-//     S7  activations of both chains      its issue shadow.
+// and every instruction of the loop body sits in an explicit slot: one MFMA, the vector / LDS work that rides behind it, a
+// scheduling fence.  The round-2 loop ran F(k) then B(k) -- split -> GEMM -> activation -> split -> ... is one serial chain
+// -- and with one wave per SIMD (the 192 dW accumulators need the whole register file) every MFMA -> VALU -> MFMA
+// dependency and every LDS fetch was exposed: matrix pipe 55 % busy, 14 % of the wave's time parked on s_waitcnt.
+//
+// Stage i of an iteration pairs F's layer i (GEMM i -> i+1 of node k+1) with B's layer l = L - i (delta_{l+1} -> delta_l,
+// dW_l of node k), in two regions:
+//   region G  72 MFMAs: the W^T GEMM (24) and the forward GEMM (48), interleaved in groups that share a fragment set.  The
+//             fragments come through register buffers loaded 8..20 slots ahead of their first use (two W buffers, one W^T
+//             buffer, 16 registers each); the split of K-step 1's operands (register pairs 4..7) rides behind the first 16
+//             slots -- K-step 1's MFMAs start at slot 36.  At the end: a_l^T and the sign piece of a_l are read out of the
+//             LDS slot X, THEN F's a_i(k+1) pieces are stored into X (LDS executes a wave's accesses in order), and delta^T
+//             is read back from the delta slot.
+//   region D  48 MFMAs dW_l += delta_{l+1} (x) a_l (accumulators only).  Behind them: the activations of both chains (one
+//             register per slot), the split of K-step 0 of the NEXT stage's operands, the first W set of the next region G;
+//             at the last stage instead B's tail (delta_1 -> dc, dW1[:,0]), F's output layer for node k+1 (delta_L, dwo) and
+//             layer 1 of node k+2.
 // What makes that fit:
-//   * a_l no longer lives in registers between F and B (48 registers in the old kernel): its two leading bf16 pieces go to
-//     an LDS slot when they are split -- the same [piece][point][slot] tile the dW product transposes through with
-//     ds_read_b64_tr_b16 -- and the sign of a_l (activation derivative) is read back from there.  F runs one node ahead
-//     and produces a_1..a_{L-1} in the order B consumes them backwards, so L-1 slots rotate (stage i frees the slot of
-//     a_{L-i}(k) for a_i(k+1)): (L-1) + 1 slots of 4.5 KB per wave.
+//   * a_l no longer lives in registers between F and B (48 registers in the round-2 kernel): its two leading bf16 pieces go
+//     to an LDS slot -- the same [piece][point][slot] tile the dW product transposes through with ds_read_b64_tr_b16 -- and
+//     the sign of a_l (activation derivative) is read back from there.  F runs one node ahead and produces a_1..a_{L-1} in
+//     the order B consumes them backwards, so L-1 slots rotate (stage i frees the slot of a_{L-i}(k) for a_i(k+1)):
+//     (L-1) + 1 slots of 4.5 KB per wave.
 //   * ONE weight image serves W and W^T.  The forward fragment image (3 pieces, 24 KB per layer) is read with
 //     ds_read_b128 by the recompute and with ds_read_b64_tr_b16 by the delta chain: lane (g', p) of a W^T fragment (t, s)
 //     wants k-slots j = 4h + e  <->  W[16 (2s+h) + 4e + g'][16t + 4 (p&3) + (p>>2)]; in the forward image those are, for
 //     fixed (h, e), 4 consecutive bf16 of the lane (g'_f = p&3, rho_f = 4 g' + e) of fragment (2s+h, t>>1), half t&1 --
-//     exactly the 4 x 16 block a transposing read delivers.  72 KB instead of 120 KB of images; the 16-byte units of a
-//     fragment are rotated by 8 for g'_f >= 2 so the transposing reads are 2-way conflicted (inherent: 32 lanes read
-//     the same 8-byte half of 16 units) instead of 4-way, and the b128 reads stay conflict-free.
+//     exactly the 4 x 16 block a transposing read delivers.  72 KB instead of 120 KB of images (144 KB of LDS in all); the
+//     16-byte units of a fragment are rotated by 8 for g'_f >= 2 so the transposing reads are 2-way conflicted (inherent:
+//     32 lanes read the same 8-byte half of 16 units) instead of 4-way, and the b128 reads stay conflict-free.
 //     The constant-one feature (bias column / unit row of the forward image) forms a closed subspace under W^T -- it only
 //     ever feeds the constant feature's own delta, whose dW rows and dc entries are discarded at write-out.
+// Measured at C3 (8192 x 63, n = 100; profiles/r03): 14.8-15.1 ms (round-2 loop) -> 13.5-13.9 ms; wave cycles per tile-node
+// 10.6 k -> 9.6 k, parked on s_waitcnt 14 % -> 10 %, matrix pipe 55 % -> 60 % busy.  DESIGN 4.2 has the other variants that
+// were measured (slots only in the dW regions: 16.2 ms; the two chains in antiphase: 15.1-15.5 ms) and what bounds this one.
 #pragma once
 #include <type_traits>
 #include <utility>
@@ -107,8 +120,10 @@ __device__ __forceinline__ void gemm_frags_T(const unsigned short* imgT, const B
 // activation derivative off the sign of the leading bf16 piece, pieces given as the two u32x4 (K-steps) a lane stored
 __device__ __forceinline__ float act_grad_q(const u32x4 (&hi)[BKS], int t, int r, float slope) {
     const unsigned u = hi[t >> 1][(t & 1) * 2 + (r >> 1)];
-    const int hi16 = (r & 1) ? (int)(u & 0xffff0000u) : (int)(u << 16);
-    return hi16 > 0 ? 1.f : slope;
+    // a_l > 0  <=>  its leading bf16 piece > 0: the high half as "dword > 0xffff" (signed), the low half as a signed 16-bit
+    // compare of the dword's low word -- no shift / mask instruction in front of the compare
+    const bool pos = (r & 1) ? ((int)u > 0xffff) : ((short)(u & 0xffffu) > 0);
+    return pos ? 1.f : slope;
 }
 
 // one rounding stage of a pair split: returns the packed bf16 pair, leaves the residuals in x0 / x1 (same arithmetic, same
@@ -256,8 +271,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
         // transposed a_l operand of the dW product and the sign piece of a_l
         BFrag<NPF> bfv[2];
         BFrag<NPB> bdv[2];
-        u32x2 aTv[2][BT][NPB];
-        u32x4 sgv[2][BKS];
+        u32x2 aT[BT][NPB];                              // (single: read at the end of a GEMM region, dead after the dW region)
+        u32x4 sgq[BKS];
         unsigned qF[8][NPF], qB[8][NPB];                // packed pieces of pair j (regs 2j, 2j+1) on their way into bfv / bdv
         float rf0[8], rf1[8], rb0[8], rb1[8];           // split residuals in flight
 #pragma unroll
@@ -268,11 +283,17 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
             for (int k2 = 0; k2 < NPB; ++k2) qB[j][k2] = 0u;
         }
         // -- micro-operations of "prepare stage i" (S1..S3 of the header), cut so that they can ride behind single MFMAs
-        auto prep_reads = [&](auto curc, int X) __attribute__((always_inline)) {          // S1
-            constexpr int cur = decltype(curc)::value;
-            tr_tile_read(lds16 + X, g, p, aTv[cur]);
+        auto read_aT = [&](auto tauc, int X) __attribute__((always_inline)) {              // S1, one slot tile of a_l^T
+            constexpr int tau = decltype(tauc)::value;
 #pragma unroll
-            for (int s = 0; s < BKS; ++s) sgv[cur][s] = *reinterpret_cast<const u32x4*>(lds16 + X + own + s * 8);
+            for (int part2 = 0; part2 < NPB; ++part2) {
+                const unsigned short* src = lds16 + X + (part2 * 16 + 4 * g + (p >> 2)) * TRS + 16 * tau + 4 * (p & 3);
+                aT[tau][part2] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4v __attribute__((address_space(3)))*)(src)));
+            }
+        };
+        auto read_sg = [&](int X) __attribute__((always_inline)) {                         // the sign piece of a_l (own k-slots)
+#pragma unroll
+            for (int s = 0; s < BKS; ++s) sgq[s] = *reinterpret_cast<const u32x4*>(lds16 + X + own + s * 8);
         };
         auto pairF = [&](auto jc, auto stc) __attribute__((always_inline)) {              // S2, one rounding stage of pair j
             constexpr int j = decltype(jc)::value, st = decltype(stc)::value, t = j / 2, r = 2 * (j & 1);
@@ -289,33 +310,28 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
                 if constexpr (st == 1) qB[j][1] = split_last(rb0[j], rb1[j]);
             }
         };
-        auto commit = [&](auto curc, auto sc, int X) __attribute__((always_inline)) {     // K-step s complete: operands + LDS
+        auto commit = [&](auto curc, auto sc) __attribute__((always_inline)) {            // K-step s split: operands, delta to LDS
             constexpr int cur = decltype(curc)::value, s = decltype(sc)::value;
 #pragma unroll
             for (int k2 = 0; k2 < NPF; ++k2) bfv[cur].v[s][k2] = u32x4{qF[4 * s][k2], qF[4 * s + 1][k2], qF[4 * s + 2][k2], qF[4 * s + 3][k2]};
 #pragma unroll
             for (int k2 = 0; k2 < NPB; ++k2) bdv[cur].v[s][k2] = u32x4{qB[4 * s][k2], qB[4 * s + 1][k2], qB[4 * s + 2][k2], qB[4 * s + 3][k2]};
 #pragma unroll
-            for (int k2 = 0; k2 < NPB; ++k2) {
-                *reinterpret_cast<u32x4*>(lds16 + X + k2 * 16 * TRS + own + s * 8) = bfv[cur].v[s][k2];
+            for (int k2 = 0; k2 < NPB; ++k2)
                 *reinterpret_cast<u32x4*>(lds16 + sdel + k2 * 16 * TRS + own + s * 8) = bdv[cur].v[s][k2];
-            }
         };
-        auto prep_plain = [&](auto curc, int X) __attribute__((always_inline)) {          // the whole preparation, un-overlapped
-            prep_reads(curc, X);
-            swp_static_for<8>([&](auto jc) {
-                pairF(jc, std::integral_constant<int, 0>{}); pairF(jc, std::integral_constant<int, 1>{}); pairF(jc, std::integral_constant<int, 2>{});
-                pairB(jc, std::integral_constant<int, 0>{}); pairB(jc, std::integral_constant<int, 1>{});
-            });
-            commit(curc, std::integral_constant<int, 0>{}, X);
-            commit(curc, std::integral_constant<int, 1>{}, X);
+        auto store_bf = [&](auto curc, auto sc, int X) __attribute__((always_inline)) {   // a_i(k+1) pieces 0/1 into the slot B just read
+            constexpr int cur = decltype(curc)::value, s = decltype(sc)::value;
+#pragma unroll
+            for (int k2 = 0; k2 < NPB; ++k2)
+                *reinterpret_cast<u32x4*>(lds16 + X + k2 * 16 * TRS + own + s * 8) = bfv[cur].v[s][k2];
         };
         // -- S7 for one register: activation of the F chain, cotangent of the B chain through act'(a_l)
-        auto s7_reg = [&](auto ec, auto curc, const f32x4 (&acc)[BT], const f32x4 (&nd)[BT]) __attribute__((always_inline)) {
-            constexpr int e = decltype(ec)::value, cur = decltype(curc)::value, t = e / 4, r = e % 4;
+        auto s7_reg = [&](auto ec, const f32x4 (&acc)[BT], const f32x4 (&nd)[BT]) __attribute__((always_inline)) {
+            constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
             if constexpr (e < NLIVE) {
                 actF[t][r] = hidden_act_f(acc[t][r], slope);
-                delta[t][r] = nd[t][r] * act_grad_q(sgv[cur], t, r, slope);
+                delta[t][r] = nd[t][r] * act_grad_q(sgq, t, r, slope);
             }
         };
         // -- output layer of the F chain's node kn in three cuts: dot product, scalar part, cotangent of the last layer
@@ -416,7 +432,40 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
         swp_static_for<4 * BT>(out_reg);               // delta = delta_L(k_lo), dwo
         float tkF = node_t(k_lo + 1 < k_hi ? k_lo + 1 : k_hi - 1);
         layer1(tkF);                                    // actF = a_1(k_lo + 1)
-        prep_plain(std::integral_constant<int, 1>{}, so[L - 2]);       // stage 1 of the first iteration
+        // fragment buffers of the GEMM regions (two per operand kind, see the load plan below)
+        u32x4 bufW[2][BT], bufT[BT];
+        auto loadW = [&](auto layerc, auto kc, auto tc) __attribute__((always_inline)) {        // W set k = 3 s + piece, tile t
+            constexpr int li = decltype(layerc)::value, kk = decltype(kc)::value, t = decltype(tc)::value;
+            constexpr int s = kk / 3, piece = kk % 3;
+            bufW[kk & 1][t] = *reinterpret_cast<const u32x4*>(fragF + (li - 1) * IMG + ((t * BKS + s) * NPF + piece) * FRAG);
+        };
+        auto loadT = [&](auto layerc, auto kc, auto tc) __attribute__((always_inline)) {        // W^T set k = 2 s + piece, tile t
+            constexpr int li = decltype(layerc)::value, kk = decltype(kc)::value, t = decltype(tc)::value;
+            constexpr int s = kk / 2, piece = kk % 2;
+            const unsigned short* lo = fragT + (li - 1) * IMG + (((2 * s + 0) * BKS + (t >> 1)) * NPF + piece) * FRAG + 4 * (t & 1);
+            const unsigned short* hi = fragT + (li - 1) * IMG + (((2 * s + 1) * BKS + (t >> 1)) * NPF + piece) * FRAG + 4 * (t & 1);
+            const u32x2 x0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4v __attribute__((address_space(3)))*)(lo)));
+            const u32x2 x1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4v __attribute__((address_space(3)))*)(hi)));
+            bufT[t] = u32x4{x0[0], x0[1], x1[0], x1[1]};
+        };
+        // preparation of a stage's K-step 0 (pairs 0..3), cut into 16 micro-operations: m -> pair m / 4, stage m % 4
+        auto pair_op = [&](auto jc, auto opc) __attribute__((always_inline)) {
+            constexpr int op = decltype(opc)::value;
+            if constexpr (op == 0) pairF(jc, std::integral_constant<int, 0>{});
+            if constexpr (op == 1) pairB(jc, std::integral_constant<int, 0>{});
+            if constexpr (op == 2) pairF(jc, std::integral_constant<int, 1>{});
+            if constexpr (op == 3) { pairF(jc, std::integral_constant<int, 2>{}); pairB(jc, std::integral_constant<int, 1>{}); }
+        };
+        // prologue of the pipeline: stage 1 of the first iteration, K-step 0 (K-step 1 is split inside the GEMM region)
+        {
+            constexpr std::integral_constant<int, 1> c1{};
+            swp_static_for<16>([&](auto mc) {
+                constexpr int mm = decltype(mc)::value;
+                pair_op(std::integral_constant<int, mm / 4>{}, std::integral_constant<int, mm % 4>{});
+            });
+            commit(c1, std::integral_constant<int, 0>{});
+            swp_static_for<BT>([&](auto tc) { loadW(c1, std::integral_constant<int, 0>{}, tc); });
+        }
 
         // ---------------- pipelined node loop: B(k) with F(k+1) ----------------
         for (int k = k_lo; k < k_hi; ++k) {
@@ -426,46 +475,97 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
             swp_static_for<NG>([&](auto iic) {
                 constexpr int i = decltype(iic)::value + 1;          // F's layer (GEMM i -> i+1)
                 constexpr int l = L - i;                                // B's layer: delta_{l+1} -> delta_l, dW_l
-                constexpr int cur = i & 1, nxt = (i + 1) & 1;
+                constexpr int cur = i & 1, nxt = i < NG ? (i + 1) & 1 : 1;
+                constexpr int inext = i < NG ? i + 1 : 1;               // F's layer of the stage that follows
                 constexpr std::integral_constant<int, cur> curc{};
                 constexpr std::integral_constant<int, nxt> nxtc{};
-                // ---- region G: the two GEMMs the chains wait for (S4, S5), back to back on the matrix pipe
+                constexpr std::integral_constant<int, i> ic{};
+                constexpr std::integral_constant<int, l> lc{};
+                const int X = so[l - 1];                                // slot of a_l(k), receiving a_i(k+1)
                 f32x4 nd[BT], acc[BT];
-                gemm_frags_T(fragT + (l - 1) * IMG, bdv[cur], nd);
-                gemm_frags<NPF>(fragF + (i - 1) * IMG, bfv[cur], acc);
                 u32x2 dT[BT][NPB];
-                tr_tile_read(lds16 + sdel, g, p, dT);
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- region D: dW_l += delta_{l+1} (x) a_l, one MFMA per slot; the vector work of S7 and of the NEXT stage's
-                // S1..S3 (or, at the last stage, the tail of the node) rides behind the MFMAs, one cut per slot
+                // ---- region G: the 72 MFMAs of the two GEMMs, one per slot.  Fragments arrive through four register
+                // buffers loaded 8..20 slots ahead of their first use (W sets k = 3s + piece -> bufW[k & 1], W^T sets
+                // k = 2s + piece -> bufT[k & 1]; W set 0 was loaded in the previous region D).  The vector work of K-step 1's
+                // split (pairs 4..7; K-step 1's MFMAs start at slot 36) rides behind the first slots.
+                swp_static_for<72>([&](auto nc) {
+                    constexpr int nn = decltype(nc)::value, s = nn / 36, idx = nn % 36;
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (idx < 12) {
+                        constexpr int t = idx % 4, ba = idx / 4;
+                        acc[t] = mfma_bf16(bufW[(3 * s) & 1][t], bfv[cur].v[s][ba], (s == 0 && idx < 4) ? zero : acc[t]);
+                    } else if constexpr (idx < 20) {
+                        constexpr int t = (idx - 12) % 4, ba = (idx - 12) / 4;
+                        nd[t] = mfma_bf16(bufT[t], bdv[cur].v[s][ba], (s == 0 && idx < 16) ? zero : nd[t]);
+                    } else if constexpr (idx < 28) {
+                        constexpr int t = (idx - 20) % 4, ba = (idx - 20) / 4;
+                        acc[t] = mfma_bf16(bufW[(3 * s + 1) & 1][t], bfv[cur].v[s][ba], acc[t]);
+                    } else if constexpr (idx < 32) {
+                        constexpr int t = idx - 28;
+                        nd[t] = mfma_bf16(bufT[t], bdv[cur].v[s][0], nd[t]);
+                    } else {
+                        constexpr int t = idx - 32;
+                        acc[t] = mfma_bf16(bufW[(3 * s + 2) & 1][t], bfv[cur].v[s][0], acc[t]);
+                    }
+                    // fragment loads, one fragment per slot: W set k -> bufW[k & 1] (k = 0 came with the previous region D),
+                    // W^T set k -> bufT, each 8+ slots ahead of its first MFMA and after the last MFMA of the set it replaces
+                    if constexpr (nn >= 0 && nn < 4) loadT(lc, std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 0>{});      // used 12..19
+                    if constexpr (nn >= 4 && nn < 8) loadW(ic, std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 4>{});      // used 20..27
+                    if constexpr (nn >= 12 && nn < 16) loadW(ic, std::integral_constant<int, 2>{}, std::integral_constant<int, nn - 12>{});   // used 32..35
+                    if constexpr (nn >= 20 && nn < 24) loadT(lc, std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 20>{});   // used 28..31
+                    if constexpr (nn >= 28 && nn < 32) loadW(ic, std::integral_constant<int, 3>{}, std::integral_constant<int, nn - 28>{});   // used 36..47
+                    if constexpr (nn >= 32 && nn < 36) loadT(lc, std::integral_constant<int, 2>{}, std::integral_constant<int, nn - 32>{});   // used 48..55
+                    if constexpr (nn >= 40 && nn < 44) loadW(ic, std::integral_constant<int, 4>{}, std::integral_constant<int, nn - 40>{});   // used 56..63
+                    if constexpr (nn >= 48 && nn < 52) loadW(ic, std::integral_constant<int, 5>{}, std::integral_constant<int, nn - 48>{});   // used 68..71
+                    if constexpr (nn >= 56 && nn < 60) loadT(lc, std::integral_constant<int, 3>{}, std::integral_constant<int, nn - 56>{});   // used 64..67
+                    // K-step 1 of this stage's operands: pairs 4..7, then delta's K-step 1 to LDS
+                    if constexpr (nn < 16) pair_op(std::integral_constant<int, 4 + nn / 4>{}, std::integral_constant<int, nn % 4>{});
+                    if constexpr (nn == 16) commit(curc, std::integral_constant<int, 1>{});
+                    // operands of region D: a_l^T and its sign piece out of X, THEN a_i(k+1) into X; delta^T out of the delta slot
+                    if constexpr (nn >= 60 && nn < 64) read_aT(std::integral_constant<int, nn - 60>{}, X);
+                    if constexpr (nn == 64) read_sg(X);
+                    if constexpr (nn == 65) store_bf(curc, std::integral_constant<int, 0>{}, X);
+                    if constexpr (nn == 66) store_bf(curc, std::integral_constant<int, 1>{}, X);
+                    if constexpr (nn >= 67 && nn < 71) {
+                        constexpr int to = nn - 67;
+#pragma unroll
+                        for (int part2 = 0; part2 < NPB; ++part2) {
+                            const unsigned short* src = lds16 + sdel + (part2 * 16 + 4 * g + (p >> 2)) * TRS + 16 * to + 4 * (p & 3);
+                            dT[to][part2] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4v __attribute__((address_space(3)))*)(src)));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                // ---- region D: dW_l += delta_{l+1} (x) a_l, one MFMA per slot; behind them S7 of this stage and K-step 0 of the
+                // NEXT stage's operands (at the last stage: the tail of node k, the output layer of node k+1, layer 1 of k+2 first)
                 swp_static_for<NDW>([&](auto nc) {
                     constexpr int nn = decltype(nc)::value;
-                    constexpr int term = nn / (BT * BT), to = (nn % (BT * BT)) / BT, ti = nn % BT;
+                    // (output-row tile outermost: delta^T tile `to` is dead after its 12 slots; per accumulator the order of
+                    // the three cross terms is the round-2 kernel's)
+                    constexpr int to = nn / (3 * BT), term = (nn % (3 * BT)) / BT, ti = nn % BT;
                     constexpr int wa = term == 2 ? 1 : 0, ba = term == 1 ? 1 : 0;
-                    dW[l - 1][to][ti] = mfma_bf16_k16(dT[to][wa], aTv[cur][ti][ba], dW[l - 1][to][ti]);
+                    dW[l - 1][to][ti] = mfma_bf16_k16(dT[to][wa], aT[ti][ba], dW[l - 1][to][ti]);
+                    if constexpr (nn < 16) s7_reg(std::integral_constant<int, nn>{}, acc, nd);
                     if constexpr (i < NG) {
-                        // per pair j six cuts: S7 of its two registers, then the rounding stages of both splits
-                        constexpr int j = nn / 6, op = nn % 6;
-                        constexpr std::integral_constant<int, j> jc{};
-                        const int Xn = so[l - 2];                       // slot of a_{l-1}(k): next stage's X
-                        if constexpr (nn == 1) prep_reads(nxtc, Xn);
-                        if constexpr (op == 0) s7_reg(std::integral_constant<int, 2 * j>{}, curc, acc, nd);
-                        if constexpr (op == 1) s7_reg(std::integral_constant<int, 2 * j + 1>{}, curc, acc, nd);
-                        if constexpr (op == 2) pairF(jc, std::integral_constant<int, 0>{});
-                        if constexpr (op == 3) pairB(jc, std::integral_constant<int, 0>{});
-                        if constexpr (op == 4) pairF(jc, std::integral_constant<int, 1>{});
-                        if constexpr (op == 5) { pairF(jc, std::integral_constant<int, 2>{}); pairB(jc, std::integral_constant<int, 1>{}); }
-                        if constexpr (nn == 6 * 3 + 5) commit(nxtc, std::integral_constant<int, 0>{}, Xn);
-                        if constexpr (nn == 6 * 7 + 5) commit(nxtc, std::integral_constant<int, 1>{}, Xn);
+                        if constexpr (nn >= 16 && nn < 32) pair_op(std::integral_constant<int, (nn - 16) / 4>{}, std::integral_constant<int, (nn - 16) % 4>{});
+                        if constexpr (nn == 33) commit(nxtc, std::integral_constant<int, 0>{});
                     } else {
-                        // last stage: S7 (delta becomes delta_1(k), actF a_L(k+1)), B's tail, F's output layer, layer 1 of node k+2
-                        if constexpr (nn < 16) s7_reg(std::integral_constant<int, nn>{}, curc, acc, nd);
-                        else if constexpr (nn < 24) { tail_reg(std::integral_constant<int, 2 * (nn - 16)>{}, tkB); tail_reg(std::integral_constant<int, 2 * (nn - 16) + 1>{}, tkB); }
-                        else if constexpr (nn < 28) swp_static_for<4>([&](auto uc) { out_dot(std::integral_constant<int, 4 * (nn - 24) + decltype(uc)::value>{}); });
-                        else if constexpr (nn == 28) out_scalar(kn, has_next ? 1.f : 0.f);
-                        else if constexpr (nn < 37) { out_reg(std::integral_constant<int, 2 * (nn - 29)>{}); out_reg(std::integral_constant<int, 2 * (nn - 29) + 1>{}); }
-                        else if constexpr (nn < 45) { layer1_reg(std::integral_constant<int, 2 * (nn - 37)>{}, tkN); layer1_reg(std::integral_constant<int, 2 * (nn - 37) + 1>{}, tkN); }
+                        // B's tail rides with S7 (tail_reg of registers 2m, 2m+1 after both have their delta_1)
+                        if constexpr (nn >= 8 && nn < 16) { tail_reg(std::integral_constant<int, 2 * (nn - 8)>{}, tkB); tail_reg(std::integral_constant<int, 2 * (nn - 8) + 1>{}, tkB); }
+                        if constexpr (nn >= 16 && nn < 20) swp_static_for<4>([&](auto uc) { out_dot(std::integral_constant<int, 4 * (nn - 16) + decltype(uc)::value>{}); });
+                        if constexpr (nn == 20) out_scalar(kn, has_next ? 1.f : 0.f);
+                        if constexpr (nn >= 21 && nn < 29) { out_reg(std::integral_constant<int, 2 * (nn - 21)>{}); out_reg(std::integral_constant<int, 2 * (nn - 21) + 1>{}); }
+                        if constexpr (nn >= 29 && nn < 37) { layer1_reg(std::integral_constant<int, 2 * (nn - 29)>{}, tkN); layer1_reg(std::integral_constant<int, 2 * (nn - 29) + 1>{}, tkN); }
+                        // K-step 0 of stage 1 of the next iteration: B's pairs as soon as out_reg wrote them, F's after layer 1
+                        if constexpr (nn >= 25 && nn < 29) pairB(std::integral_constant<int, nn - 25>{}, std::integral_constant<int, 0>{});
+                        if constexpr (nn >= 29 && nn < 33) pairB(std::integral_constant<int, nn - 29>{}, std::integral_constant<int, 1>{});
+                        if constexpr (nn >= 33 && nn < 37) pairF(std::integral_constant<int, nn - 33>{}, std::integral_constant<int, 0>{});
+                        if constexpr (nn >= 37 && nn < 41) pairF(std::integral_constant<int, nn - 37>{}, std::integral_constant<int, 1>{});
+                        if constexpr (nn >= 41 && nn < 45) pairF(std::integral_constant<int, nn - 41>{}, std::integral_constant<int, 2>{});
+                        if constexpr (nn == 45) commit(nxtc, std::integral_constant<int, 0>{});
                     }
+                    // first W set of the next GEMM region
+                    if constexpr (nn >= 40 && nn < 44) loadW(std::integral_constant<int, inext>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 40>{});
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
@@ -473,8 +573,6 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
             tkF = tkN;
             // slot rotation: stage i stored a_i(k+1) where a_{L-i}(k) was
             if constexpr (NG >= 2) { const int tmp = so[0]; so[0] = so[NG - 1]; so[NG - 1] = tmp; }
-            // stage 1 of the next iteration (its vector work is what is still exposed per node)
-            prep_plain(std::integral_constant<int, 1>{}, so[L - 2]);
         }
 
         if (ok) {

@@ -7,6 +7,14 @@ long kernel per block and a graph buys nothing."""
 import torch
 
 
+def _capture_mode():
+    """``capture_error_mode`` for torch.cuda.graph: with an initialised process group the backend's watchdog thread polls
+    events while we capture; under the default "global" mode that is an illegal call during capture (on this stack the process
+    dies with SIGSEGV, measured with a one-rank nccl group) -- "thread_local" confines the capture rules to this thread."""
+    import torch.distributed as dist
+    return "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+
+
 class GraphedLL:
     """``GraphedLL(model, x_example)(x)`` -> the captured ``(ll, z)`` tensors (overwritten by the next call).
 
@@ -39,7 +47,7 @@ class GraphedLL:
                     self._run()
             torch.cuda.current_stream(self.x.device).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
-            with made.capture_may_cache(), torch.cuda.graph(self.graph):
+            with made.capture_may_cache(), torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
                 self.out = self._run()
         self._seen = self._versions()
         self.captures += 1
@@ -72,10 +80,28 @@ class GraphedTrainStep:
 
         step = umnn_amd.GraphedTrainStep(model, opt, x_example)
         for x in loader: loss = step(x)          # loss: 0-dim device tensor, overwritten by the next call
-    """
+
+    ``grad_hook(model)`` runs between backward and clipping, inside the graph.  It must not issue RCCL collectives: with an
+    initialised ``nccl`` process group this class refuses a hook (NotImplementedError) -- first contact with RCCL on this
+    stack (ROCm 7.2 / torch 2.10, one-rank group, tools/_rccl_capture_probe.py) showed that (i) capturing ``all_reduce``
+    in a hipGraph segfaults, and (ii) the obvious workaround -- graph A (forward + backward) -> eager all-reduce -> graph B
+    (clipping + optimizer) -- trains to different weights depending on where the host synchronises between the pieces.
+    Data-parallel training therefore runs the eager step (``bench.py --mode train`` does so by itself when ``--graph`` is
+    asked for with more than one rank).
+
+    PyTorch constraint worth knowing (it cost a segfault at ``capture_end`` here): autograd binds a parameter's AccumulateGrad
+    node to the stream that was current when the node was created.  If an autograd graph built on the DEFAULT stream over
+    these parameters is still alive (e.g. the loss tensor of an earlier eager step kept in a variable), the captured backward
+    accumulates on the legacy stream, which a capture cannot wait on.  Build the step before any eager training step, or
+    drop every reference to earlier graphs first."""
 
     def __init__(self, model, optimizer, x_example, context=None, warmup=3, clip_value=None, grad_hook=None):
         assert x_example.is_cuda, "hipGraph capture needs device tensors"
+        import torch.distributed as dist
+        if grad_hook is not None and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+            raise NotImplementedError(
+                "GraphedTrainStep: a gradient hook under an initialised nccl process group would put RCCL collectives inside "
+                "a hipGraph capture, which segfaults on this stack; run the eager optimisation step for data-parallel training")
         self.x = x_example.clone()
         self.context = context.clone() if context is not None else None
         params = [p for g in optimizer.param_groups for p in g["params"]]
@@ -99,7 +125,7 @@ class GraphedTrainStep:
                 one_step()
         torch.cuda.current_stream(x_example.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             self.loss = one_step()
 
     def __call__(self, x=None, context=None):

@@ -43,9 +43,18 @@ def _warn_once(key, message):
         warnings.warn(message, RuntimeWarning, stacklevel=3)
 
 
+_last_backward = {"path": None}      # process-wide: backward runs on autograd's worker threads, not on the caller's
+
+
 def path_taken():
-    """'hip' or 'aten': which path the calling thread's most recent forward/backward used."""
+    """'hip' or 'aten': which path the calling thread's most recent forward (or directly called backward helper) used."""
     return getattr(_state, "path", None)
+
+
+def backward_path_taken():
+    """'hip' or 'aten': the path of the most recent quadrature BACKWARD in this process.  (autograd runs backward on its own
+    worker threads, so the thread-local ``path_taken()`` of the caller does not see it.)"""
+    return _last_backward["path"]
 
 
 class force_generic:
@@ -357,7 +366,7 @@ def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True
                                          _ptr(w), _ptr(s), int(nb_steps), B, d, E, int(bool(inv_f)),
                                          _ptr(dx0), _ptr(dx), _ptr(dh), _ptr(dtheta), _ptr(ws), int(nbytes), stream)
     _lib.check(rc, "umnn_cc_backward")
-    _state.path = "hip"
+    _state.path = _last_backward["path"] = "hip"
     if x_dtype != xd:
         dx0 = dx0.to(x_dtype) if dx0 is not None else None
         dx = dx.to(x_dtype) if dx is not None else None
@@ -425,7 +434,7 @@ def aten_backward(integrand, x0, x, h, g, nb_steps, inv_f=False):
                 acc += gr
         if grads[-1] is not None:
             g_h += grads[-1].view(b - a, B, -1).sum(0)
-    _state.path = "aten"
+    _state.path = _last_backward["path"] = "aten"
     return (_flatten(g_params) if params else None), g_h
 
 
