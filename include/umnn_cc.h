@@ -242,6 +242,23 @@ const char* umnn_last_kernel_name_of(int tag);
  * [Wh | Wh | Wl | bh | bl | 0...] it gives W a + b to ~3e-6 of the output range. */
 int umnn_made_split3(const float* x, long long rows, int cols, int relu, void* out_bf16, int ld_out, void* stream);
 
+/* The whole MADE conditioner of one flow block as ONE launch (reference models/UMNN/made.py:16-27 MaskedLinear, :113-119
+ * MADE.forward, :165-168 ConditionnalMADE.forward; called once per block, UMNNMAF.py:79):
+ *     h = W_L relu( ... relu(W_1 x + b_1) ... ) + b_L,   x [B, widths[0]] fp32  ->  h [B, widths[n_layers]] fp32 or bf16.
+ * W[l]: the MASKED weight of layer l as bf16 MFMA fragments [tile t][K-step s][piece (hi, lo)][lane 64][8 bf16], lane
+ * (g = lane>>4, rho = lane&15) slot j holding piece(W[16 t + rho][32 s + 16 (j>>2) + 4 g + (j&3)]) (zero outside the matrix)
+ * -- the K order in which the kernel's accumulators become the next layer's operand; b[l]: fp32 bias.  Input and hidden
+ * widths up to 512 (UMNN_EUNSUPPORTED beyond: the caller keeps the library GEMMs); products as xh Wh + xl Wh + xh Wl with
+ * fp32 accumulation (the arithmetic of umnn_made_split3's GEMMs), bias added in fp32. */
+#define UMNN_MADE_MAX_LAYERS 8
+typedef struct umnn_made_net {
+    int n_layers;
+    int widths[UMNN_MADE_MAX_LAYERS + 1];
+    const void* W[UMNN_MADE_MAX_LAYERS];
+    const float* b[UMNN_MADE_MAX_LAYERS];
+} umnn_made_net;
+int umnn_made_mlp_forward(const umnn_made_net* net, const float* x, long long B, void* h_out, int out_bf16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

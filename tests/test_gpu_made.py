@@ -101,3 +101,75 @@ def test_made_split3_edge_shapes(dev):
         assert torch.equal(out, want), (rows, cols, relu)
     with pytest.raises(RuntimeError):
         _lib.check(lib.umnn_made_split3(x.data_ptr(), 1, 4, 0, out.data_ptr(), 5, stream), "split3")
+
+
+@pytest.mark.parametrize("nin,hid,E,B", [(63, [512, 512], 30, 8192), (6, [512, 512], 30, 10000), (2, [100] * 4, 10, 4096),
+                                         (5, [33], 3, 19), (3, [16, 8, 24], 2, 1), (7, [48, 500], 5, 257), (20, [512], 1, 130)])
+@pytest.mark.parametrize("out_dtype", [None, torch.bfloat16])
+def test_fused_conditioner_kernel_matches_per_layer_path_and_oracle(dev, nin, hid, E, B, out_dtype):
+    """umnn_made_mlp_forward (the whole masked MLP in one launch: csrc/made_fused.hip) against the per-layer fast path (same
+    bf16x3 products, bias there in bf16 pieces, here in fp32), the fp32 chain and the float64 oracle of models/UMNN/made.py:113-119
+    -- over widths that are not multiples of 16 / 32, fewer tiles than waves, batches that do not fill a row tile, both
+    row-tile variants (RT = 1 / 4), fp32 and bf16 output."""
+    import umnn_amd
+    from umnn_amd import MADE, _lib
+    from umnn_amd.made import MaskedLinear
+    torch.manual_seed(nin + B)
+    made = MADE(nin, hid, nin * E, num_masks=1, natural_ordering=True).to(dev)
+    with torch.no_grad():
+        for m in made.net:
+            if isinstance(m, MaskedLinear):
+                m.bias.uniform_(-1.0, 1.0)
+    x = torch.randn(B, nin, device=dev) * 2
+    outs = {}
+    try:
+        with torch.no_grad():
+            for fused in (True, False):
+                umnn_amd.set_made_fused(fused, wide_out=True)       # (wide outputs too: the kernel's multi-pass output layer)
+                launches = _lib.lib().umnn_launch_count()
+                outs[fused] = made.raw(x, out_dtype=out_dtype)
+                # (the per-layer path's operand builder + library GEMMs are not counted launches of the library)
+                assert _lib.lib().umnn_launch_count() - launches == (1 if fused else 0)
+                if fused:
+                    assert "made_fused" in _lib.lib().umnn_last_kernel_name().decode()
+            umnn_amd.set_made_fast_path(False)
+            exact = made.raw(x)
+    finally:
+        umnn_amd.set_made_fused(True, wide_out=False)
+        umnn_amd.set_made_fast_path(True)
+    assert outs[True].dtype == (out_dtype or torch.float32) and outs[True].shape == exact.shape
+    scale = exact.abs().max().item()
+    tol = 2e-5 if out_dtype is None else 6e-3           # bf16 storage: 2^-9 of the value, relative to the largest entry
+    assert (outs[True].float() - exact).abs().max().item() <= tol * scale
+    assert (outs[True].float() - outs[False].float()).abs().max().item() <= (1e-5 if out_dtype is None else 8e-3) * scale
+    lin = [m for m in made.net if isinstance(m, MaskedLinear)]
+    ref = O.made_forward([m.weight.detach().cpu().numpy().astype(np.float64) for m in lin],
+                         [m.bias.detach().cpu().numpy().astype(np.float64) for m in lin],
+                         [m.mask.cpu().numpy().astype(np.float64) for m in lin], x[:64].cpu().numpy().astype(np.float64))
+    assert np.abs(outs[True][:64].float().cpu().numpy() - ref).max() <= tol * scale
+
+
+def test_fused_conditioner_falls_back_beyond_512_and_sees_weight_updates(dev):
+    """Hidden layers wider than 512 (MNISTExperiment's [1024]*3) keep the per-layer library GEMMs; the fused path's packed
+    fragments follow in-place weight updates (version-keyed cache) and explicit cache invalidation."""
+    import umnn_amd
+    from umnn_amd import MADE, _lib
+    torch.manual_seed(0)
+    wide = MADE(8, [1024, 1024], 16, num_masks=1, natural_ordering=True).to(dev)
+    x = torch.randn(40, 8, device=dev)
+    with torch.no_grad():
+        n0 = _lib.lib().umnn_launch_count()
+        wide.raw(x)
+        assert _lib.lib().umnn_launch_count() == n0, "widths beyond 512 keep the per-layer path"
+        made = MADE(8, [64, 64], 16, num_masks=1, natural_ordering=True).to(dev)
+        a = made.raw(x).clone()
+        assert _lib.lib().umnn_launch_count() == n0 + 1 and "made_fused" in _lib.lib().umnn_last_kernel_name().decode()
+        made.net[0].weight.mul_(1.5)                      # in place: the version counter moves, the fragments are re-packed
+        b = made.raw(x)
+        assert not torch.equal(a, b)
+        umnn_amd.set_made_fast_path(False)
+        try:
+            exact = made.raw(x)
+        finally:
+            umnn_amd.set_made_fast_path(True)
+        assert (b - exact).abs().max().item() <= 2e-5 * exact.abs().max().item()

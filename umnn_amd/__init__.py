@@ -4,7 +4,7 @@ Import surface mirrors models/UMNN/__init__.py:1-6 of the reference.
 """
 from .flow import UMNNMAFFlow, UMNNMAF, EmbeddingNetwork, IntegrandNetwork, ListModule
 from .monotonic import MonotonicNN, IntegrandNN
-from .made import MADE, ConditionnalMADE, MaskedLinear, invalidate_caches, set_made_fast_path, get_made_fast_path
+from .made import MADE, ConditionnalMADE, MaskedLinear, invalidate_caches, set_made_fast_path, get_made_fast_path, set_made_fused
 from .integral import NeuralIntegral, ParallelNeuralIntegral, IntegralWithJacobian, integrate, path_taken, backward_path_taken, set_backward_wide
 from .nets import compute_lipschitz_linear
 from .quadrature import compute_cc_weights
@@ -33,4 +33,4 @@ __all__ = ["UMNNMAFFlow", "UMNNMAF", "EmbeddingNetwork", "IntegrandNetwork", "Li
            "IntegrandNN", "MADE", "ConditionnalMADE", "MaskedLinear", "NeuralIntegral", "ParallelNeuralIntegral",
            "IntegralWithJacobian", "integrate", "compute_cc_weights", "path_taken", "GraphedLL", "GraphedTrainStep",
            "set_precision", "invalidate_caches", "set_made_fast_path", "get_made_fast_path", "set_forward_precision", "get_forward_precision", "set_backward_precision", "get_backward_precision",
-           "set_backward_wide", "compute_lipschitz_linear", "backward_path_taken"]
+           "set_backward_wide", "compute_lipschitz_linear", "backward_path_taken", "set_made_fused"]

@@ -87,7 +87,16 @@ SIGNATURES = {
                                              ctypes.POINTER(ctypes.c_double)]),
     "umnn_last_kernel_name_of": (ctypes.c_char_p, [ctypes.c_int]),
     "umnn_made_split3": (ctypes.c_int, [_fp, _ll, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]),
+    "umnn_made_mlp_forward": (ctypes.c_int, [ctypes.c_void_p, _fp, _ll, _fp, ctypes.c_int, _fp]),
 }
+
+MADE_MAX_LAYERS = 8
+
+
+class MadeNet(ctypes.Structure):
+    """struct umnn_made_net (include/umnn_cc.h)."""
+    _fields_ = [("n_layers", ctypes.c_int), ("widths", ctypes.c_int * (MADE_MAX_LAYERS + 1)),
+                ("W", ctypes.c_void_p * MADE_MAX_LAYERS), ("b", ctypes.c_void_p * MADE_MAX_LAYERS)]
 
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}
 PROF_FORWARD, PROF_BACKWARD, PROF_FINISH = 0, 1, 2

@@ -1,0 +1,228 @@
+// The MADE conditioner of one flow block as ONE launch (the optional half; reference
+// models/UMNN/made.py:16-27 MaskedLinear, :113-119 MADE.forward, :165-168 ConditionnalMADE.forward, called once per block by
+// UMNNMAF.py:79):   h = W_L relu( ... relu(W_1 x + b_1) ... ) + b_L   with the masks folded into the weights by the host.
+//
+// Why: at the launch-bound shapes (2-D toy flow, POWER d = 6, the VAE's prior flow) a step was 60-80 % quadrature and the rest
+// two launches per masked linear (operand split + hipBLASLt GEMM): 6-10 short launches per block.  Here the whole masked MLP
+// runs in one kernel; the large shapes (BSDS300: 8192 x 512 x 1890 output layer) keep the library GEMMs.
+//
+// Arithmetic = the inference fast path's: x W^T ~= xh Wh + xl Wh + xh Wl with bf16 pieces and fp32 accumulation on
+// v_mfma_f32_16x16x32_bf16 (3e-6 of the output range; masked entries are exact zeros in both pieces, so the autoregressive
+// property holds bit for bit); the bias is added in fp32.
+//
+// Layout.  D[out feature][row] = A[out feature][k] B[k][row]: a workgroup (4 waves) owns RT tiles of 16 rows; wave w owns the
+// output tiles t = w, w+4, ... of every layer, eight at a time, for ALL the workgroup's rows -- a weight fragment fetched
+// from L2 is used for RT row tiles x 3 cross terms.  The activations of the current layer live in LDS as ready-made B operands
+// [row tile][K-step][piece][lane][8 bf16]: after MFMA a lane (g, p) holds features 16t + 4g + r of row p, so with the K order
+//       k-slot (s, g, j)  <->  feature 32 s + 16 (j >> 2) + 4 g + (j & 3)
+// every lane packs the next layer's operand out of its own accumulators (no cross-lane movement); the host packs the weight
+// fragments [tile][K-step][piece][lane][8 bf16] in that K order (umnn_amd/made.py: pack_fragments).  Two barriers per layer.
+#include <hip/hip_runtime.h>
+#include "cc_bf16.h"
+#include "cc_host.h"
+#include "../../include/umnn_cc.h"
+
+namespace {
+constexpr int MF_WAVES = 4;
+constexpr int MF_TPC = 8;              // output tiles per wave and pass
+constexpr int MF_SMAX = 16;            // K-steps of 32: widths up to 512
+constexpr int MF_FRAG = 512;           // ushorts per fragment (64 lanes x 8)
+
+struct MadeArgs {
+    const unsigned short* W[UMNN_MADE_MAX_LAYERS];     // packed fragments of layer l
+    const float* b[UMNN_MADE_MAX_LAYERS];
+    int width[UMNN_MADE_MAX_LAYERS + 1];               // [K0, N1, ..., NL]
+    int n_layers;
+    const float* x;                                     // [B, K0]
+    void* out;                                          // [B, NL] fp32 or bf16
+    int out_bf16;
+    long long B;
+};
+
+__device__ __forceinline__ int kfeat(int s, int g, int j) { return 32 * s + 16 * (j >> 2) + 4 * g + (j & 3); }
+
+template <int RT>
+__global__ __launch_bounds__(64 * MF_WAVES, 1) void made_fused_kernel(const MadeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short act[];       // [RT][MF_SMAX][2][64][8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, p = lane & 15;
+    const long long row0 = (long long)blockIdx.x * (16 * RT);
+    auto act_at = [&](int rt, int s, int piece) { return act + (((rt * MF_SMAX + s) * 2 + piece) * 64 + lane) * 8; };
+
+    // ---- layer-0 operands straight from x: every wave stages its share of the (row tile, K-step) pairs
+    {
+        const int K0 = a.width[0], S0 = (K0 + 31) / 32;
+        for (int it = wid; it < RT * S0; it += MF_WAVES) {
+            const int rt = it / S0, s = it - rt * S0;
+            const long long row = row0 + 16 * rt + p;
+            const float* xr = a.x + (row < a.B ? row : a.B - 1) * K0;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = kfeat(s, g, j);
+                v[j] = (k < K0 && row < a.B) ? xr[k] : 0.f;
+            }
+            unsigned q0[2], q1[2], q2[2], q3[2];
+            split_pair<2>(v[0], v[1], q0); split_pair<2>(v[2], v[3], q1); split_pair<2>(v[4], v[5], q2); split_pair<2>(v[6], v[7], q3);
+#pragma unroll
+            for (int piece = 0; piece < 2; ++piece)
+                *reinterpret_cast<u32x4*>(act_at(rt, s, piece)) = u32x4{q0[piece], q1[piece], q2[piece], q3[piece]};
+        }
+    }
+    __syncthreads();
+
+    for (int l = 0; l < a.n_layers; ++l) {
+        const int K = a.width[l], N = a.width[l + 1];
+        const int S = (K + 31) / 32, T = (N + 15) / 16;
+        const bool last = l + 1 == a.n_layers;
+        const unsigned short* __restrict__ Wl = a.W[l];
+        const float* __restrict__ bl = a.b[l];
+        // hidden layers have at most 4 * MF_TPC tiles (one pass per wave); the output layer may take several passes, whose
+        // results go to global memory, so no barrier is needed between them
+        const int npass = (T + MF_WAVES * MF_TPC - 1) / (MF_WAVES * MF_TPC);     // (uniform: every wave runs every pass and barrier)
+        for (int pass = 0; pass < npass; ++pass) {
+            const int t0 = wid + pass * MF_WAVES * MF_TPC;
+            const int nc = t0 < T ? (T - t0 + MF_WAVES - 1) / MF_WAVES : 0;      // valid tiles of this wave in this pass (<= MF_TPC)
+            f32x4 acc[MF_TPC][RT];
+#pragma unroll
+            for (int c = 0; c < MF_TPC; ++c)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // fragments of K-step s for this wave's tiles t0 + 4c: [tile][K-step][piece]; one K-step is fetched ahead
+            u32x4 fr[2][MF_TPC][2];
+            auto fetch = [&](int buf, int s) __attribute__((always_inline)) {
+#pragma unroll
+                for (int c = 0; c < MF_TPC; ++c) {
+                    if (c < nc) {
+                        const int t = t0 + MF_WAVES * c;
+#pragma unroll
+                        for (int piece = 0; piece < 2; ++piece)
+                            fr[buf][c][piece] = *reinterpret_cast<const u32x4*>(Wl + ((size_t)(t * S + s) * 2 + piece) * MF_FRAG + lane * 8);
+                    }
+                }
+            };
+            if (nc > 0) fetch(0, 0);
+            if (nc > 0)
+            for (int s = 0; s < S; s += 2) {
+                // two K-steps per trip so that the fragment buffers are statically indexed
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int ss = s + half;
+                    if (ss < S) {
+                        if (ss + 1 < S) fetch(half ^ 1, ss + 1);
+                        u32x4 bh[RT], bo[RT];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            bh[rt] = *reinterpret_cast<const u32x4*>(act_at(rt, ss, 0));
+                            bo[rt] = *reinterpret_cast<const u32x4*>(act_at(rt, ss, 1));
+                        }
+                        // (term outermost: consecutive MFMAs write different accumulators)
+#pragma unroll
+                        for (int term = 0; term < 3; ++term)
+#pragma unroll
+                            for (int c = 0; c < MF_TPC; ++c)
+                                if (c < nc) {
+#pragma unroll
+                                    for (int rt = 0; rt < RT; ++rt)
+                                        acc[c][rt] = mfma_bf16(fr[half][c][term == 2 ? 1 : 0], term == 1 ? bo[rt] : bh[rt], acc[c][rt]);   // Wh xh, Wh xl, Wl xh
+                                }
+                    }
+                }
+            }
+            if (!last) __syncthreads();          // every wave has read the current activations (hidden layers: one pass each)
+            // ---- epilogue of the pass: bias (+ ReLU, split, next layer's operand) or the store of h
+#pragma unroll
+            for (int c = 0; c < MF_TPC; ++c) {
+                if (c >= nc) continue;
+                const int t = t0 + MF_WAVES * c;
+                const int f0 = 16 * t + 4 * g;                        // this lane's four features
+                float bv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[r] = f0 + r < N ? bl[f0 + r] : 0.f;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[c][rt][r] + bv[r];
+                    if (!last) {
+                        // features 16t + 4g + r = k-slots j = 4 (t & 1) + r of K-step t >> 1: half of this lane's operand quad
+                        unsigned q0[2], q1[2];
+                        split_pair<2>(f0 + 0 < N ? fmaxf(v[0], 0.f) : 0.f, f0 + 1 < N ? fmaxf(v[1], 0.f) : 0.f, q0);
+                        split_pair<2>(f0 + 2 < N ? fmaxf(v[2], 0.f) : 0.f, f0 + 3 < N ? fmaxf(v[3], 0.f) : 0.f, q1);
+#pragma unroll
+                        for (int piece = 0; piece < 2; ++piece)
+                            *reinterpret_cast<u32x2*>(act_at(rt, t >> 1, piece) + 4 * (t & 1)) = u32x2{q0[piece], q1[piece]};
+                    } else {
+                        const long long row = row0 + 16 * rt + p;
+                        if (row < a.B) {
+                            if (a.out_bf16) {
+                                unsigned short* o = reinterpret_cast<unsigned short*>(a.out) + row * N + f0;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) if (f0 + r < N) o[r] = f32_to_bf16_rn(v[r]);
+                            } else {
+                                float* o = reinterpret_cast<float*>(a.out) + row * N + f0;
+                                if (f0 + 3 < N && (N & 3) == 0) *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                                else
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) if (f0 + r < N) o[r] = v[r];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!last) {
+            // zero the operand halves of an odd tile count / of K-steps the next layer reads but this layer did not write
+            const int Tn = T, Sn = (N + 31) / 32;
+            if ((Tn & 1) && wid == 0) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int piece = 0; piece < 2; ++piece)
+                        *reinterpret_cast<u32x2*>(act_at(rt, Sn - 1, piece) + 4) = u32x2{0u, 0u};
+            }
+            __syncthreads();                     // next layer's operands complete
+        }
+    }
+}
+}  // namespace
+
+extern "C" int umnn_made_mlp_forward(const umnn_made_net* net, const float* x, long long B, void* h_out, int out_bf16,
+                                     void* stream_) {
+    if (!net) return umnn_fail(UMNN_EINVAL, "made_mlp: net is null");
+    const int L = net->n_layers;
+    if (L < 1 || L > UMNN_MADE_MAX_LAYERS) return umnn_fail(UMNN_EUNSUPPORTED, "made_mlp: 1..UMNN_MADE_MAX_LAYERS linear layers");
+    if (B < 0) return umnn_fail(UMNN_EINVAL, "made_mlp: B < 0");
+    MadeArgs a;
+    for (int l = 0; l <= L; ++l) {
+        a.width[l] = net->widths[l];
+        if (a.width[l] < 1) return umnn_fail(UMNN_EINVAL, "made_mlp: widths must be >= 1");
+        if (l < L && a.width[l] > 32 * MF_SMAX)
+            return umnn_fail(UMNN_EUNSUPPORTED, "made_mlp: input / hidden widths up to 512 (wider conditioners keep the library GEMMs)");
+    }
+    if (B == 0) return 0;
+    if (!x || !h_out) return umnn_fail(UMNN_EINVAL, "made_mlp: null pointer");
+    for (int l = 0; l < L; ++l) {
+        if (!net->W[l] || !net->b[l]) return umnn_fail(UMNN_EINVAL, "made_mlp: null weight / bias pointer");
+        a.W[l] = reinterpret_cast<const unsigned short*>(net->W[l]);
+        a.b[l] = net->b[l];
+    }
+    a.n_layers = L; a.x = x; a.out = h_out; a.out_bf16 = out_bf16 != 0; a.B = B;
+    hipStream_t stream = (hipStream_t)stream_;
+    // row tiles per workgroup: 4 (a fragment serves 64 rows) once that still gives every CU a workgroup, else 1
+    const int cus = umnn_num_cus();
+    const int RT = (B + 63) / 64 >= cus / 2 ? 4 : 1;
+    const size_t lds = (size_t)RT * MF_SMAX * 2 * 64 * 8 * sizeof(unsigned short);
+    const unsigned grid = (unsigned)((B + 16 * RT - 1) / (16 * RT));
+    if (RT == 4) {
+        if (int rc = umnn_allow_lds((const void*)made_fused_kernel<4>, lds)) return rc;
+        hipLaunchKernelGGL(made_fused_kernel<4>, dim3(grid), dim3(64 * MF_WAVES), lds, stream, a);
+        umnn_note_launch("made_fused<RT=4>");
+    } else {
+        if (int rc = umnn_allow_lds((const void*)made_fused_kernel<1>, lds)) return rc;
+        hipLaunchKernelGGL(made_fused_kernel<1>, dim3(grid), dim3(64 * MF_WAVES), lds, stream, a);
+        umnn_note_launch("made_fused<RT=1>");
+    }
+    return umnn_check(hipGetLastError(), "made_fused launch");
+}

@@ -92,8 +92,9 @@ class GraphedTrainStep:
     PyTorch constraint worth knowing (it cost a segfault at ``capture_end`` here): autograd binds a parameter's AccumulateGrad
     node to the stream that was current when the node was created.  If an autograd graph built on the DEFAULT stream over
     these parameters is still alive (e.g. the loss tensor of an earlier eager step kept in a variable), the captured backward
-    accumulates on the legacy stream, which a capture cannot wait on.  Build the step before any eager training step, or
-    drop every reference to earlier graphs first."""
+    accumulates on the legacy stream, which a capture cannot wait on.  The constructor drops the graphs the model itself
+    holds (the blocks' cached ``m_embeding``); references held by the caller (a kept ``ll`` / ``z`` of an earlier eager step)
+    must be dropped by the caller, or the step built before any eager training step."""
 
     def __init__(self, model, optimizer, x_example, context=None, warmup=3, clip_value=None, grad_hook=None):
         assert x_example.is_cuda, "hipGraph capture needs device tensors"
@@ -105,6 +106,13 @@ class GraphedTrainStep:
         self.x = x_example.clone()
         self.context = context.clone() if context is not None else None
         params = [p for g in optimizer.param_groups for p in g["params"]]
+        # The blocks cache their last embedding (``m_embeding``, reference attribute) -- with its autograd graph when it was
+        # computed in training mode.  That graph keeps the parameters' AccumulateGrad nodes alive, bound to whatever stream
+        # the first training forward ran on; drop it so that the warm-up below re-creates them on the side stream (see the
+        # class docstring: on the default stream they make capture_end crash).
+        for mod in model.modules():
+            if hasattr(mod, "m_embeding"):
+                mod.m_embeding = None
 
         def one_step():
             optimizer.zero_grad(set_to_none=True)

@@ -48,12 +48,14 @@ class MaskedLinear(nn.Linear):
         self.register_buffer('mask', torch.ones(out_features, in_features))
         self._cache = None      # (weight version, weight data_ptr, masked weight)
         self._packed = None     # (key, bf16 [Wh|Wh|Wl|bh|bl] operand)
+        self._frags = None      # (key, (bf16 MFMA fragments, fp32 bias)) for the fused conditioner kernel
 
     def set_mask(self, mask):
         # mask arrives [in, out] (numpy, bool); stored [out, in] like the weight
         self.mask.data.copy_(torch.from_numpy(np.ascontiguousarray(mask.T).astype(np.float32)))
         self._cache = None
         self._packed = None
+        self._frags = None
 
     def invalidate_caches(self):
         """Drop the cached masked / packed weights.  The caches are keyed on tensor versions; writes through ``.data``
@@ -61,6 +63,7 @@ class MaskedLinear(nn.Linear):
         call this (``umnn_amd.invalidate_caches(model)`` does it for a whole model)."""
         self._cache = None
         self._packed = None
+        self._frags = None
 
     @staticmethod
     def _capturing(t):
@@ -101,8 +104,57 @@ class MaskedLinear(nn.Linear):
             self._packed = (key, packed)
         return self._packed[1]
 
+    def packed_fragments(self, rows=None):
+        """(fragments, bias) for ``umnn_made_mlp_forward``: the masked weight as bf16 MFMA fragments
+        [tile][K-step][piece hi/lo][lane][8] in the K order of include/umnn_cc.h, and the fp32 bias (cached while weight, mask
+        and bias are unchanged).  ``rows``: optional output-row selection (ConditionnalMADE)."""
+        key = (self.weight._version, self.weight.data_ptr(), self.mask._version, self.mask.data_ptr(),
+               self.bias._version, self.bias.data_ptr(), None if rows is None else rows.data_ptr())
+        capturing = self._capturing(self.weight)        # see masked_weight: recompute inside the graph, never cache
+        if capturing or self._frags is None or self._frags[0] != key:
+            with torch.no_grad():
+                W, b = self.mask * self.weight, self.bias
+                if rows is not None:
+                    W, b = W.index_select(0, rows), b.index_select(0, rows)
+                packed = (pack_fragments(W.float()), b.float().contiguous())
+            if capturing:
+                return packed
+            self._frags = (key, packed)
+        return self._frags[1]
+
     def forward(self, input):
         return F.linear(input, self.masked_weight(), self.bias)
+
+
+_FRAG_INDEX = {}      # (N, K, device) -> gather indices of pack_fragments
+
+
+def pack_fragments(W):
+    """[N, K] fp32 -> bf16 [T, S, 2, 64, 8]: A-operand fragments of v_mfma_f32_16x16x32_bf16 for D[out][row] = W[out][k] act[k][row].
+    Lane (g = lane >> 4, rho = lane & 15) of fragment (tile t, K-step s) holds, in slot j, W[16t + rho][32s + 16(j>>2) + 4g + (j&3)]
+    (zero outside the matrix) -- the K order in which the fused kernel's accumulators are the next layer's operand; piece 0 is
+    the value rounded to bf16, piece 1 the rounded remainder."""
+    N, K = W.shape
+    T, S = (N + 15) // 16, (K + 31) // 32
+    key = (N, K, W.device)
+    idx = _FRAG_INDEX.get(key)
+    if idx is None:
+        lane = torch.arange(64, device=W.device)
+        g, rho = lane >> 4, lane & 15
+        j = torch.arange(8, device=W.device)
+        n = 16 * torch.arange(T, device=W.device).view(T, 1, 1, 1) + rho.view(1, 1, 64, 1)                       # [T,1,64,1]
+        k = 32 * torch.arange(S, device=W.device).view(1, S, 1, 1) + (16 * (j >> 2) + (j & 3)).view(1, 1, 1, 8) \
+            + 4 * g.view(1, 1, 64, 1)                                                                            # [1,S,64,8]
+        idx = (n.expand(T, S, 64, 8) * (32 * S) + k.expand(T, S, 64, 8)).reshape(-1)
+        if len(_FRAG_INDEX) > 64:
+            _FRAG_INDEX.clear()
+        _FRAG_INDEX[key] = idx
+    Wp = torch.zeros(16 * T, 32 * S, dtype=torch.float32, device=W.device)
+    Wp[:N, :K] = W
+    frag = Wp.reshape(-1).index_select(0, idx).view(T, S, 64, 8)
+    hi = frag.bfloat16()
+    lo = (frag - hi.float()).bfloat16()
+    return torch.stack((hi, lo), 2).contiguous()
 
 
 def invalidate_caches(module):
@@ -167,6 +219,55 @@ def _fast_chain(a, layers, last_rows=None, out_dtype=None):
     return raw
 
 
+_FUSED = {"enabled": os.environ.get("UMNN_MADE_FUSED", "1") != "0", "max_rows": int(os.environ.get("UMNN_MADE_FUSED_MAX_ROWS", "32768")),
+          "wide_out": os.environ.get("UMNN_MADE_FUSED_WIDE_OUT", "0") == "1"}
+
+
+def set_made_fused(enabled, max_rows=None, wide_out=None):
+    """The whole conditioner of a block as ONE launch (``umnn_made_mlp_forward``) on the inference path when every width is
+    <= 512 (see ``_fused_ok``) and the batch has at most ``max_rows`` rows (default 32768).  ``False``: always the per-layer
+    path.  ``wide_out=True`` lifts the limit on the OUTPUT width (tests / measurements)."""
+    _FUSED["enabled"] = bool(enabled)
+    if max_rows is not None:
+        _FUSED["max_rows"] = int(max_rows)
+    if wide_out is not None:
+        _FUSED["wide_out"] = bool(wide_out)
+
+
+def _fused_ok(a, layers, n_out=None):
+    """One launch for the whole conditioner where that wins (measured, bench.py workloads with UMNN_MADE_FUSED=0/1: toy 0.202
+    -> 0.162 ms per step, POWER 2.16 -> 1.94 ms): every layer at most 512 wide INCLUDING the output.  Wide output layers
+    (BSDS300's 1890, the VAE flow's 1920 columns: several passes of a kernel that streams its weights at one wave per SIMD)
+    keep the per-layer library GEMMs (BSDS300 12.92 vs 13.11 ms, VAE 1.02 vs 1.34 ms)."""
+    if not _FUSED["enabled"] or a.shape[0] > _FUSED["max_rows"] or len(layers) > 8:
+        return False
+    n_out = layers[-1].out_features if n_out is None else n_out
+    return all(l.in_features <= 512 for l in layers) and (n_out <= 512 or _FUSED.get("wide_out", False))
+
+
+def _fused_chain(a, layers, last_rows=None, out_dtype=None):
+    """a [B, K0] fp32 -> conditioner output through the single fused kernel (csrc/made_fused.hip)."""
+    from . import _lib
+    lib = _lib.lib()
+    a = a.contiguous()
+    net = _lib.MadeNet()
+    net.n_layers = len(layers)
+    net.widths[0] = layers[0].in_features
+    keep = []
+    for i, layer in enumerate(layers):
+        frags, bias = layer.packed_fragments(last_rows if i == len(layers) - 1 else None)
+        keep += [frags, bias]
+        net.widths[i + 1] = bias.shape[0]
+        net.W[i], net.b[i] = frags.data_ptr(), bias.data_ptr()
+    bf16 = out_dtype == torch.bfloat16
+    out = torch.empty(a.shape[0], net.widths[len(layers)], device=a.device, dtype=torch.bfloat16 if bf16 else torch.float32)
+    with torch.cuda.device(a.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        _lib.check(lib.umnn_made_mlp_forward(ctypes.byref(net), a.data_ptr(), a.shape[0], out.data_ptr(), 1 if bf16 else 0, stream),
+                   "umnn_made_mlp_forward")
+    return out
+
+
 def _to_weight_dtype(x, layer):
     """bf16 / fp16 activations handed to fp32 weights outside autocast: widen (exact) instead of failing in F.linear."""
     if x.dtype != layer.weight.dtype and not torch.is_autocast_enabled():
@@ -225,7 +326,10 @@ class MADE(nn.Module):
         """The masked MLP itself (what the flow's EmbeddingNetwork needs, whatever nout is)."""
         x = _to_weight_dtype(x, self.net[0])
         if _fast_path_ok(x):
-            return _fast_chain(x, [l for l in self.net if isinstance(l, MaskedLinear)], out_dtype=out_dtype)
+            layers = [l for l in self.net if isinstance(l, MaskedLinear)]
+            if _fused_ok(x, layers):
+                return _fused_chain(x, layers, out_dtype=out_dtype)
+            return _fast_chain(x, layers, out_dtype=out_dtype)
         out = self.net(x)
         return out.to(out_dtype) if out_dtype is not None and out.dtype != out_dtype else out
 
@@ -276,7 +380,10 @@ class ConditionnalMADE(MADE):
             context = context.to(x.dtype)
         a = _to_weight_dtype(torch.cat((context, x), 1), self.net[0])
         if _fast_path_ok(a):
-            return _fast_chain(a, [l for l in self.net if isinstance(l, MaskedLinear)], self._kept_rows(a.device), out_dtype)
+            layers = [l for l in self.net if isinstance(l, MaskedLinear)]
+            if _fused_ok(a, layers, self.nin_non_cond * (self.nout // self.nin)):
+                return _fused_chain(a, layers, self._kept_rows(a.device), out_dtype)
+            return _fast_chain(a, layers, self._kept_rows(a.device), out_dtype)
         layers = list(self.net)
         for layer in layers[:-1]:
             a = layer(a)
