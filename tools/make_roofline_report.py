@@ -113,7 +113,9 @@ for tag, title in (("bsds300", "C3 BSDS300-shaped eval (8192 x 63 integrals per 
                 rows = table(ttl, dict(e, algorithmic_flops_per_launch=0.0, algorithmic_tflops=0.0, frac_of_bf16_peak=0.0))
                 lines += [r for r in rows if "algorithmic FLOPs" not in r]
         else:
-            e = kernel_entry(stats, pmc, "cc_bwd_bf16_kernel", 3 * fl)
+            # (round 3: the software-pipelined loop is its own kernel symbol; older profiles have cc_bwd_bf16_kernel)
+            name = "cc_bwd_swp_kernel" if any("cc_bwd_swp_kernel" in r["Name"] for r in stats) else "cc_bwd_bf16_kernel"
+            e = kernel_entry(stats, pmc, name, 3 * fl)
             report[tag]["backward"] = e
             lines += table("backward quadrature kernel (algorithmic FLOPs = 3 x forward: two gradient GEMMs per forward GEMM + the recompute)", e)
         lines += ["Top kernels of the training step (kernel-trace):", "", "| kernel | calls | avg | % |", "|---|---|---|---|"]
