@@ -449,11 +449,24 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
         auto loadW = [&](auto layerc, auto kc, auto tc) __attribute__((always_inline)) {        // W set k = 3 s + piece, tile t
             constexpr int li = decltype(layerc)::value, kk = decltype(kc)::value, t = decltype(tc)::value;
             constexpr int s = kk / 3, piece = kk % 3;
+#ifdef UMNN_SWP_EXP_NOFRAG
+            return;
+#endif
+#ifdef UMNN_SWP_EXP_NOP2                 // timing experiment only (wrong results): no LDS read for the third piece
+            if constexpr (piece == 2) { bufW[kk & 1][t] = bufW[(kk + 1) & 1][t]; return; }
+#endif
             bufW[kk & 1][t] = *reinterpret_cast<const u32x4*>(fragF + (li - 1) * IMG + ((t * BKS + s) * NPF + piece) * FRAG);
         };
         auto loadT = [&](auto layerc, auto kc, auto tc) __attribute__((always_inline)) {        // W^T set k = 2 s + piece, tile t
             constexpr int li = decltype(layerc)::value, kk = decltype(kc)::value, t = decltype(tc)::value;
             constexpr int s = kk / 2, piece = kk % 2;
+#ifdef UMNN_SWP_EXP_NOFRAG
+            return;
+#endif
+#ifdef UMNN_SWP_EXP_TB128                // timing experiment only (wrong results): W^T fragments as one conflict-free b128 read
+            bufT[t] = *reinterpret_cast<const u32x4*>(fragF + (li - 1) * IMG + ((t * BKS + s) * NPF + piece) * FRAG);
+            return;
+#endif
             const unsigned short* lo = fragT + (li - 1) * IMG + (((2 * s + 0) * BKS + (t >> 1)) * NPF + piece) * FRAG + 4 * (t & 1);
             const unsigned short* hi = fragT + (li - 1) * IMG + (((2 * s + 1) * BKS + (t >> 1)) * NPF + piece) * FRAG + 4 * (t & 1);
             const u32x2 x0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4v __attribute__((address_space(3)))*)(lo)));
@@ -537,7 +550,9 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
                     if constexpr (nn >= 48 && nn < 52) loadW(ic, std::integral_constant<int, 5>{}, std::integral_constant<int, nn - 48>{});   // used 68..71
                     if constexpr (nn >= 56 && nn < 60) loadT(lc, std::integral_constant<int, 3>{}, std::integral_constant<int, nn - 56>{});   // used 64..67
                     // K-step 1 of this stage's operands: pairs 4..7, then delta's K-step 1 to LDS
+#ifndef UMNN_SWP_EXP_NOGVALU            // (timing experiments only: wrong results)
                     if constexpr (nn < 16) pair_op(std::integral_constant<int, 4 + nn / 4>{}, std::integral_constant<int, nn % 4>{});
+#endif
                     if constexpr (nn == 16) commit(curc, std::integral_constant<int, 1>{});
                     // operands of region D: a_l^T and its sign piece out of X, THEN a_i(k+1) into X; delta^T out of the delta slot
                     if constexpr (nn >= 60 && nn < 64) read_aT(std::integral_constant<int, nn - 60>{}, X);
