@@ -258,6 +258,10 @@ typedef struct umnn_made_net {
     const float* b[UMNN_MADE_MAX_LAYERS];
 } umnn_made_net;
 int umnn_made_mlp_forward(const umnn_made_net* net, const float* x, long long B, void* h_out, int out_bf16, void* stream);
+/* The same kernel with the output format spelt out: out_mode 0 fp32 h, 1 bf16 h, 2 = the masked MLP's HIDDEN stack only -- the last
+ * layer given here is followed by ReLU and written as umnn_made_split3's operand [hi | lo | hi | 1 | 1 | 0...] (out_ld bf16 per row)
+ * for a wide output layer that stays a library GEMM (BSDS300's 1890, the VAE flow's 1920 columns). */
+int umnn_made_mlp_forward_ex(const umnn_made_net* net, const float* x, long long B, void* out, int out_mode, int out_ld, void* stream);
 
 #ifdef __cplusplus
 }

@@ -173,3 +173,42 @@ def test_fused_conditioner_falls_back_beyond_512_and_sees_weight_updates(dev):
         finally:
             umnn_amd.set_made_fast_path(True)
         assert (b - exact).abs().max().item() <= 2e-5 * exact.abs().max().item()
+
+
+@pytest.mark.parametrize("cond", [0, 40])
+def test_hidden_stack_kernel_feeding_the_library_gemm_of_a_wide_output_layer(dev, cond):
+    """Conditioners with a wide output (BSDS300: 1890 columns, the VAE prior flow: 1920 after dropping the context columns) run
+    their hidden stack in the fused kernel, which writes relu(h_last) straight as the bf16 operand [hi | lo | hi | 1 | 1] of the
+    output layer's library GEMM (umnn_made_mlp_forward_ex, out_mode 2): two launches per block, same numbers as the per-layer path."""
+    import umnn_amd
+    from umnn_amd import MADE, ConditionnalMADE, _lib
+    from umnn_amd.made import MaskedLinear, _fused_ok
+    torch.manual_seed(4 + cond)
+    nin, E, B = 63, 30, 777
+    if cond:
+        made = ConditionnalMADE(nin, cond, [512, 512], (nin + cond) * E, num_masks=1, natural_ordering=True).to(dev)
+        args = (torch.randn(B, nin, device=dev), torch.randn(B, cond, device=dev))
+    else:
+        made = MADE(nin, [512, 512], nin * E, num_masks=1, natural_ordering=True).to(dev)
+        args = (torch.randn(B, nin, device=dev),)
+    with torch.no_grad():
+        n0 = _lib.lib().umnn_launch_count()
+        made.raw(*args)
+        assert _lib.lib().umnn_launch_count() == n0, "wide outputs default to the per-layer path (measured: no gain from the kernel)"
+        umnn_amd.set_made_fused(True, hybrid=True)
+        fused = made.raw(*args)
+        assert _lib.lib().umnn_launch_count() == n0 + 1 and "made_fused" in _lib.lib().umnn_last_kernel_name().decode()
+        fused16 = made.raw(*args, out_dtype=torch.bfloat16)
+        umnn_amd.set_made_fused(False, hybrid=False)
+        try:
+            per_layer = made.raw(*args)
+            umnn_amd.set_made_fast_path(False)
+            exact = made.raw(*args)
+        finally:
+            umnn_amd.set_made_fused(True)
+            umnn_amd.set_made_fast_path(True)
+    assert fused.shape == exact.shape == (B, nin * E)
+    scale = exact.abs().max().item()
+    assert (fused - exact).abs().max().item() <= 2e-5 * scale
+    assert (fused - per_layer).abs().max().item() <= 1e-5 * scale
+    assert fused16.dtype == torch.bfloat16 and (fused16.float() - exact).abs().max().item() <= 6e-3 * scale

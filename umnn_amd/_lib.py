@@ -88,6 +88,7 @@ SIGNATURES = {
     "umnn_last_kernel_name_of": (ctypes.c_char_p, [ctypes.c_int]),
     "umnn_made_split3": (ctypes.c_int, [_fp, _ll, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]),
     "umnn_made_mlp_forward": (ctypes.c_int, [ctypes.c_void_p, _fp, _ll, _fp, ctypes.c_int, _fp]),
+    "umnn_made_mlp_forward_ex": (ctypes.c_int, [ctypes.c_void_p, _fp, _ll, _fp, ctypes.c_int, ctypes.c_int, _fp]),
 }
 
 MADE_MAX_LAYERS = 8

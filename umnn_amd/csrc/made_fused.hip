@@ -35,7 +35,8 @@ struct MadeArgs {
     int n_layers;
     const float* x;                                     // [B, K0]
     void* out;                                          // [B, NL] fp32 or bf16
-    int out_bf16;
+    int out_bf16;                                       // 0 fp32 h, 1 bf16 h, 2 split3 operand of relu(h) for a following library GEMM
+    int out_ld;                                         // (mode 2) bf16 elements per operand row
     long long B;
 };
 
@@ -156,7 +157,23 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void made_fused_kernel(const Made
                     } else {
                         const long long row = row0 + 16 * rt + p;
                         if (row < a.B) {
-                            if (a.out_bf16) {
+                            if (a.out_bf16 == 2) {
+                                // the next layer is a LIBRARY GEMM: write its left operand [hi | lo | hi | 1 | 1 | 0..] of
+                                // a = relu(v) (umnn_made_split3's format, ld = a.out_ld bf16 per row)
+                                unsigned short* o = reinterpret_cast<unsigned short*>(a.out) + row * a.out_ld;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if (f0 + r < N) {
+                                        const float av = fmaxf(v[r], 0.f);
+                                        const unsigned short hb = bf16_rn_bits(av);
+                                        const unsigned short lb = bf16_rn_bits(av - bf16_bits_to_f32(hb));
+                                        o[f0 + r] = hb; o[N + f0 + r] = lb; o[2 * N + f0 + r] = hb;
+                                    }
+                                if (t == 0 && g == 0) {
+                                    o[3 * N] = 0x3f80; o[3 * N + 1] = 0x3f80;
+                                    for (int k = 3 * N + 2; k < a.out_ld; ++k) o[k] = 0;
+                                }
+                            } else if (a.out_bf16) {
                                 unsigned short* o = reinterpret_cast<unsigned short*>(a.out) + row * N + f0;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) if (f0 + r < N) o[r] = f32_to_bf16_rn(v[r]);
@@ -190,6 +207,11 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void made_fused_kernel(const Made
 
 extern "C" int umnn_made_mlp_forward(const umnn_made_net* net, const float* x, long long B, void* h_out, int out_bf16,
                                      void* stream_) {
+    return umnn_made_mlp_forward_ex(net, x, B, h_out, out_bf16 != 0 ? 1 : 0, 0, stream_);
+}
+
+extern "C" int umnn_made_mlp_forward_ex(const umnn_made_net* net, const float* x, long long B, void* h_out, int out_mode,
+                                        int out_ld, void* stream_) {
     if (!net) return umnn_fail(UMNN_EINVAL, "made_mlp: net is null");
     const int L = net->n_layers;
     if (L < 1 || L > UMNN_MADE_MAX_LAYERS) return umnn_fail(UMNN_EUNSUPPORTED, "made_mlp: 1..UMNN_MADE_MAX_LAYERS linear layers");
@@ -208,7 +230,10 @@ extern "C" int umnn_made_mlp_forward(const umnn_made_net* net, const float* x, l
         a.W[l] = reinterpret_cast<const unsigned short*>(net->W[l]);
         a.b[l] = net->b[l];
     }
-    a.n_layers = L; a.x = x; a.out = h_out; a.out_bf16 = out_bf16 != 0; a.B = B;
+    if (out_mode < 0 || out_mode > 2) return umnn_fail(UMNN_EINVAL, "made_mlp: out_mode is 0 (fp32), 1 (bf16) or 2 (split3 operand)");
+    if (out_mode == 2 && (out_ld < 3 * net->widths[L] + 2 || net->widths[L] > 32 * MF_SMAX))
+        return umnn_fail(UMNN_EINVAL, "made_mlp: operand output needs ld >= 3 * width + 2 and width <= 512");
+    a.n_layers = L; a.x = x; a.out = h_out; a.out_bf16 = out_mode; a.out_ld = out_ld; a.B = B;
     hipStream_t stream = (hipStream_t)stream_;
     // row tiles per workgroup: 4 (a fragment serves 64 rows) once that still gives every CU a workgroup, else 1
     const int cus = umnn_num_cus();

@@ -220,10 +220,11 @@ def _fast_chain(a, layers, last_rows=None, out_dtype=None):
 
 
 _FUSED = {"enabled": os.environ.get("UMNN_MADE_FUSED", "1") != "0", "max_rows": int(os.environ.get("UMNN_MADE_FUSED_MAX_ROWS", "32768")),
-          "wide_out": os.environ.get("UMNN_MADE_FUSED_WIDE_OUT", "0") == "1"}
+          "wide_out": os.environ.get("UMNN_MADE_FUSED_WIDE_OUT", "0") == "1",
+          "hybrid": os.environ.get("UMNN_MADE_FUSED_HYBRID", "0") == "1"}
 
 
-def set_made_fused(enabled, max_rows=None, wide_out=None):
+def set_made_fused(enabled, max_rows=None, wide_out=None, hybrid=None):
     """The whole conditioner of a block as ONE launch (``umnn_made_mlp_forward``) on the inference path when every width is
     <= 512 (see ``_fused_ok``) and the batch has at most ``max_rows`` rows (default 32768).  ``False``: always the per-layer
     path.  ``wide_out=True`` lifts the limit on the OUTPUT width (tests / measurements)."""
@@ -232,40 +233,59 @@ def set_made_fused(enabled, max_rows=None, wide_out=None):
         _FUSED["max_rows"] = int(max_rows)
     if wide_out is not None:
         _FUSED["wide_out"] = bool(wide_out)
+    if hybrid is not None:           # wide outputs: hidden stack in the kernel, output layer as one library GEMM (measured: no gain)
+        _FUSED["hybrid"] = bool(hybrid)
 
 
 def _fused_ok(a, layers, n_out=None):
-    """One launch for the whole conditioner where that wins (measured, bench.py workloads with UMNN_MADE_FUSED=0/1: toy 0.202
-    -> 0.162 ms per step, POWER 2.16 -> 1.94 ms): every layer at most 512 wide INCLUDING the output.  Wide output layers
-    (BSDS300's 1890, the VAE flow's 1920 columns: several passes of a kernel that streams its weights at one wave per SIMD)
-    keep the per-layer library GEMMs (BSDS300 12.92 vs 13.11 ms, VAE 1.02 vs 1.34 ms)."""
+    """-> 0 (per-layer path), 1 (whole conditioner in one launch) or 2 (hidden stack in one launch + the output layer as ONE
+    library GEMM).  Every input / hidden width must be <= 512.  Measured with bench.py's workloads (tools/bench_fused.sh):
+    narrow outputs (toy 20, POWER 180 columns) win with the whole MLP in the kernel (0.203 -> 0.162 ms, 2.21 -> 2.00 ms per step);
+    wide output layers (BSDS300's 1890, the VAE flow's 1920 columns) lose there (several passes of a kernel that streams its
+    weights at one wave per SIMD: 12.92 vs 13.11 ms, 1.02 vs 1.34 ms), and feeding hipBLASLt's output GEMM from the kernel's
+    hidden stack (mode 2) does not beat four short launches either (VAE 1.03 vs 1.11 ms, BSDS300 13.55 vs 13.58 ms): wide outputs
+    keep the per-layer path unless ``set_made_fused(hybrid=True)`` / ``wide_out=True`` ask otherwise."""
     if not _FUSED["enabled"] or a.shape[0] > _FUSED["max_rows"] or len(layers) > 8:
-        return False
+        return 0
+    if not all(l.in_features <= 512 for l in layers):
+        return 0
     n_out = layers[-1].out_features if n_out is None else n_out
-    return all(l.in_features <= 512 for l in layers) and (n_out <= 512 or _FUSED.get("wide_out", False))
+    if n_out <= 512 or _FUSED.get("wide_out", False):
+        return 1
+    return 2 if (len(layers) >= 2 and _FUSED.get("hybrid", False)) else 0
 
 
-def _fused_chain(a, layers, last_rows=None, out_dtype=None):
-    """a [B, K0] fp32 -> conditioner output through the single fused kernel (csrc/made_fused.hip)."""
+def _fused_chain(a, layers, last_rows=None, out_dtype=None, mode=1):
+    """a [B, K0] fp32 -> conditioner output through the fused kernel (csrc/made_fused.hip): the whole MLP (mode 1) or its
+    hidden stack, whose last ReLU output leaves as the bf16 operand of the output layer's library GEMM (mode 2)."""
     from . import _lib
     lib = _lib.lib()
     a = a.contiguous()
+    inner = layers if mode == 1 else layers[:-1]
     net = _lib.MadeNet()
-    net.n_layers = len(layers)
-    net.widths[0] = layers[0].in_features
+    net.n_layers = len(inner)
+    net.widths[0] = inner[0].in_features
     keep = []
-    for i, layer in enumerate(layers):
-        frags, bias = layer.packed_fragments(last_rows if i == len(layers) - 1 else None)
+    for i, layer in enumerate(inner):
+        frags, bias = layer.packed_fragments(last_rows if (mode == 1 and i == len(inner) - 1) else None)
         keep += [frags, bias]
         net.widths[i + 1] = bias.shape[0]
         net.W[i], net.b[i] = frags.data_ptr(), bias.data_ptr()
     bf16 = out_dtype == torch.bfloat16
-    out = torch.empty(a.shape[0], net.widths[len(layers)], device=a.device, dtype=torch.bfloat16 if bf16 else torch.float32)
     with torch.cuda.device(a.device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
-        _lib.check(lib.umnn_made_mlp_forward(ctypes.byref(net), a.data_ptr(), a.shape[0], out.data_ptr(), 1 if bf16 else 0, stream),
+        if mode == 1:
+            out = torch.empty(a.shape[0], net.widths[len(inner)], device=a.device, dtype=torch.bfloat16 if bf16 else torch.float32)
+            _lib.check(lib.umnn_made_mlp_forward_ex(ctypes.byref(net), a.data_ptr(), a.shape[0], out.data_ptr(), 1 if bf16 else 0, 0,
+                                                    stream), "umnn_made_mlp_forward")
+            return out
+        packed = layers[-1].packed_bf16(last_rows)                      # [N, pad8(3K+2)]: the per-layer path's weight operand
+        op = torch.empty(a.shape[0], packed.shape[1], dtype=torch.bfloat16, device=a.device)
+        _lib.check(lib.umnn_made_mlp_forward_ex(ctypes.byref(net), a.data_ptr(), a.shape[0], op.data_ptr(), 2, op.shape[1], stream),
                    "umnn_made_mlp_forward")
-    return out
+    if bf16:
+        return torch.mm(op, packed.t())                                  # bf16 out, fp32 accumulate inside the GEMM
+    return torch.mm(op, packed.t(), out_dtype=torch.float32)
 
 
 def _to_weight_dtype(x, layer):
@@ -327,8 +347,9 @@ class MADE(nn.Module):
         x = _to_weight_dtype(x, self.net[0])
         if _fast_path_ok(x):
             layers = [l for l in self.net if isinstance(l, MaskedLinear)]
-            if _fused_ok(x, layers):
-                return _fused_chain(x, layers, out_dtype=out_dtype)
+            mode = _fused_ok(x, layers)
+            if mode:
+                return _fused_chain(x, layers, out_dtype=out_dtype, mode=mode)
             return _fast_chain(x, layers, out_dtype=out_dtype)
         out = self.net(x)
         return out.to(out_dtype) if out_dtype is not None and out.dtype != out_dtype else out
@@ -381,8 +402,9 @@ class ConditionnalMADE(MADE):
         a = _to_weight_dtype(torch.cat((context, x), 1), self.net[0])
         if _fast_path_ok(a):
             layers = [l for l in self.net if isinstance(l, MaskedLinear)]
-            if _fused_ok(a, layers, self.nin_non_cond * (self.nout // self.nin)):
-                return _fused_chain(a, layers, self._kept_rows(a.device), out_dtype)
+            mode = _fused_ok(a, layers, self.nin_non_cond * (self.nout // self.nin))
+            if mode:
+                return _fused_chain(a, layers, self._kept_rows(a.device), out_dtype, mode=mode)
             return _fast_chain(a, layers, self._kept_rows(a.device), out_dtype)
         layers = list(self.net)
         for layer in layers[:-1]:
