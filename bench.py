@@ -70,7 +70,7 @@ def make_inputs(cfg, rows, device, seed):
     return x, ctx
 
 
-def cpu_baseline(cfg, model, budget_s=45.0):
+def cpu_baseline(cfg, model, budget_s=52.0):
     """Time the torch port of the reference's compute_ll with BOTH of its quadrature solvers -- the materialised
     ``ParallelNeuralIntegral`` (ParallelNeuralIntegral.py:37-65) and the node-by-node ``NeuralIntegral``
     (NeuralIntegral.py:37-66) -- on the host cores, on a bounded sample of the same workload (row chunks; the un-chunked

@@ -174,7 +174,9 @@ double umnn_cc_forward_flops_per_integral(const umnn_mlp* net, int nb_steps);
 /* Introspection used by tests, the smoke test and the bench. */
 const char* umnn_last_error(void);
 int umnn_version(void);
-long long umnn_launch_count(void);          /* HIP kernels launched by this process so far */
+long long umnn_launch_count(void);          /* quadrature kernels (forward / backward / finishing) launched by this process so far */
+long long umnn_made_launch_count(void);     /* launches of the fused conditioner kernel (umnn_made_mlp_forward) so far */
+const char* umnn_last_made_kernel_name(void);
 const char* umnn_last_kernel_name(void);    /* variant picked by the last forward/backward */
 /* Times `reps` back-to-back umnn_cc_forward launches with hipEvents recorded on `stream`
  * (the stream the kernels run on) and returns the average milliseconds per launch in *ms. */

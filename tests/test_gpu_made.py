@@ -126,12 +126,11 @@ def test_fused_conditioner_kernel_matches_per_layer_path_and_oracle(dev, nin, hi
         with torch.no_grad():
             for fused in (True, False):
                 umnn_amd.set_made_fused(fused, wide_out=True)       # (wide outputs too: the kernel's multi-pass output layer)
-                launches = _lib.lib().umnn_launch_count()
+                launches = _lib.lib().umnn_made_launch_count()
                 outs[fused] = made.raw(x, out_dtype=out_dtype)
-                # (the per-layer path's operand builder + library GEMMs are not counted launches of the library)
-                assert _lib.lib().umnn_launch_count() - launches == (1 if fused else 0)
+                assert _lib.lib().umnn_made_launch_count() - launches == (1 if fused else 0)
                 if fused:
-                    assert "made_fused" in _lib.lib().umnn_last_kernel_name().decode()
+                    assert "made_fused" in _lib.lib().umnn_last_made_kernel_name().decode()
             umnn_amd.set_made_fast_path(False)
             exact = made.raw(x)
     finally:
@@ -158,12 +157,12 @@ def test_fused_conditioner_falls_back_beyond_512_and_sees_weight_updates(dev):
     wide = MADE(8, [1024, 1024], 16, num_masks=1, natural_ordering=True).to(dev)
     x = torch.randn(40, 8, device=dev)
     with torch.no_grad():
-        n0 = _lib.lib().umnn_launch_count()
+        n0 = _lib.lib().umnn_made_launch_count()
         wide.raw(x)
-        assert _lib.lib().umnn_launch_count() == n0, "widths beyond 512 keep the per-layer path"
+        assert _lib.lib().umnn_made_launch_count() == n0, "widths beyond 512 keep the per-layer path"
         made = MADE(8, [64, 64], 16, num_masks=1, natural_ordering=True).to(dev)
         a = made.raw(x).clone()
-        assert _lib.lib().umnn_launch_count() == n0 + 1 and "made_fused" in _lib.lib().umnn_last_kernel_name().decode()
+        assert _lib.lib().umnn_made_launch_count() == n0 + 1 and "made_fused" in _lib.lib().umnn_last_made_kernel_name().decode()
         made.net[0].weight.mul_(1.5)                      # in place: the version counter moves, the fragments are re-packed
         b = made.raw(x)
         assert not torch.equal(a, b)
@@ -192,12 +191,12 @@ def test_hidden_stack_kernel_feeding_the_library_gemm_of_a_wide_output_layer(dev
         made = MADE(nin, [512, 512], nin * E, num_masks=1, natural_ordering=True).to(dev)
         args = (torch.randn(B, nin, device=dev),)
     with torch.no_grad():
-        n0 = _lib.lib().umnn_launch_count()
+        n0 = _lib.lib().umnn_made_launch_count()
         made.raw(*args)
-        assert _lib.lib().umnn_launch_count() == n0, "wide outputs default to the per-layer path (measured: no gain from the kernel)"
+        assert _lib.lib().umnn_made_launch_count() == n0, "wide outputs default to the per-layer path (measured: no gain from the kernel)"
         umnn_amd.set_made_fused(True, hybrid=True)
         fused = made.raw(*args)
-        assert _lib.lib().umnn_launch_count() == n0 + 1 and "made_fused" in _lib.lib().umnn_last_kernel_name().decode()
+        assert _lib.lib().umnn_made_launch_count() == n0 + 1 and "made_fused" in _lib.lib().umnn_last_made_kernel_name().decode()
         fused16 = made.raw(*args, out_dtype=torch.bfloat16)
         umnn_amd.set_made_fused(False, hybrid=False)
         try:

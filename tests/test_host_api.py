@@ -353,3 +353,27 @@ def test_mlp_spec_recognition():
     assert mlp_spec(umnn_amd.IntegrandNetwork(4, 3, [200], 1)) is None        # wider than the kernels cover
     with pytest.raises(KeyError):
         umnn_amd.IntegrandNetwork(4, 3, [8], 1, act_func="Tanh")
+
+
+def test_pack_fragments_layout_matches_the_documented_k_order():
+    """made.pack_fragments (host side of umnn_made_mlp_forward): fragment (t, s), lane (g, rho), slot j holds
+    W[16t + rho][32s + 16(j>>2) + 4g + (j&3)] split into two bf16 pieces, zeros outside the matrix (include/umnn_cc.h)."""
+    from umnn_amd.made import pack_fragments
+    torch.manual_seed(0)
+    for N, K in ((37, 70), (16, 32), (1, 1), (100, 6)):
+        W = torch.randn(N, K)
+        P = pack_fragments(W)
+        T, S = (N + 15) // 16, (K + 31) // 32
+        assert P.shape == (T, S, 2, 64, 8) and P.dtype == torch.bfloat16
+        lane = torch.arange(64)
+        g, rho = lane >> 4, lane & 15
+        j = torch.arange(8)
+        for t in range(T):
+            for s in range(S):
+                n = (16 * t + rho).view(64, 1).expand(64, 8)
+                k = (32 * s + 16 * (j >> 2) + (j & 3)).view(1, 8) + 4 * g.view(64, 1)
+                ok = (n < N) & (k < K)
+                want = torch.where(ok, W[n.clamp(max=N - 1), k.clamp(max=K - 1)], torch.zeros(()))
+                hi = want.bfloat16()
+                lo = (want - hi.float()).bfloat16()
+                assert torch.equal(P[t, s, 0], hi) and torch.equal(P[t, s, 1], lo), (N, K, t, s)

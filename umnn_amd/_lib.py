@@ -87,6 +87,8 @@ SIGNATURES = {
                                              ctypes.POINTER(ctypes.c_double)]),
     "umnn_last_kernel_name_of": (ctypes.c_char_p, [ctypes.c_int]),
     "umnn_made_split3": (ctypes.c_int, [_fp, _ll, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]),
+    "umnn_made_launch_count": (ctypes.c_longlong, []),
+    "umnn_last_made_kernel_name": (ctypes.c_char_p, []),
     "umnn_made_mlp_forward": (ctypes.c_int, [ctypes.c_void_p, _fp, _ll, _fp, ctypes.c_int, _fp]),
     "umnn_made_mlp_forward_ex": (ctypes.c_int, [ctypes.c_void_p, _fp, _ll, _fp, ctypes.c_int, ctypes.c_int, _fp]),
 }

@@ -34,6 +34,16 @@ void umnn_note_launch(const char* kernel_name) {
     g_last_of[tag].store(kernel_name, std::memory_order_relaxed);
     g_launches.fetch_add(1, std::memory_order_relaxed);
 }
+// the conditioner's fused kernel keeps its own books: umnn_launch_count() counts QUADRATURE launches (tests assert
+// "compute_ll = nb_flow launches", "invert = d launches per block" with it)
+static std::atomic<long long> g_made_launches{0};
+static std::atomic<const char*> g_last_made{""};
+void umnn_note_made_launch(const char* kernel_name) {
+    g_last_made.store(kernel_name, std::memory_order_relaxed);
+    g_made_launches.fetch_add(1, std::memory_order_relaxed);
+}
+extern "C" long long umnn_made_launch_count(void) { return g_made_launches.load(std::memory_order_relaxed); }
+extern "C" const char* umnn_last_made_kernel_name(void) { return g_last_made.load(std::memory_order_relaxed); }
 extern "C" const char* umnn_last_kernel_name_of(int tag) {
     return tag >= 0 && tag <= 2 ? g_last_of[tag].load(std::memory_order_relaxed) : "";
 }

@@ -31,6 +31,7 @@ struct UmnnOptions {
 UmnnOptions& umnn_options();
 int umnn_allow_lds(const void* fn, size_t bytes);         // hipFuncSetAttribute(MaxDynamicSharedMemorySize)
 void umnn_note_launch(const char* kernel_name);
+void umnn_note_made_launch(const char* kernel_name);      // conditioner kernels: separate counter / name
 long long umnn_param_count(const umnn_mlp* net);
 
 // Optional per-launch timing (umnn_profile_enable): hipEvents recorded on the launch stream around each kernel.

@@ -243,11 +243,11 @@ extern "C" int umnn_made_mlp_forward_ex(const umnn_made_net* net, const float* x
     if (RT == 4) {
         if (int rc = umnn_allow_lds((const void*)made_fused_kernel<4>, lds)) return rc;
         hipLaunchKernelGGL(made_fused_kernel<4>, dim3(grid), dim3(64 * MF_WAVES), lds, stream, a);
-        umnn_note_launch("made_fused<RT=4>");
+        umnn_note_made_launch("made_fused<RT=4>");
     } else {
         if (int rc = umnn_allow_lds((const void*)made_fused_kernel<1>, lds)) return rc;
         hipLaunchKernelGGL(made_fused_kernel<1>, dim3(grid), dim3(64 * MF_WAVES), lds, stream, a);
-        umnn_note_launch("made_fused<RT=1>");
+        umnn_note_made_launch("made_fused<RT=1>");
     }
     return umnn_check(hipGetLastError(), "made_fused launch");
 }
