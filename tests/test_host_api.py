@@ -377,3 +377,18 @@ def test_pack_fragments_layout_matches_the_documented_k_order():
                 hi = want.bfloat16()
                 lo = (want - hi.float()).bfloat16()
                 assert torch.equal(P[t, s, 0], hi) and torch.equal(P[t, s, 1], lo), (N, K, t, s)
+
+
+def test_bench_cpu_baseline_protocol_runs_on_a_small_workload():
+    """bench.cpu_baseline (the `cpu_baseline` record of the bench line): both reference solvers, thread sweep, warm-up, median
+    over two chunks, budget flag, the all-cores probe in a child process with a time limit."""
+    import bench
+    cfg = dict(bench.WORKLOADS["toy"], rows=64)
+    model = bench.build_model(cfg, "cpu")
+    rec = bench.cpu_baseline(cfg, model, budget_s=6.0)
+    assert rec["kind"] == "port" and rec["unit"] == "evals/s" and rec["value"] > 0 and rec["cores"] >= 1
+    assert set(rec["solvers"]) == {"sequential", "parallel"} and rec["solver"] in rec["solvers"]
+    for s in rec["solvers"].values():
+        assert s["reps"] >= 3 and s["warmup"] >= 1 and s["chunks"] == 2 and isinstance(s["budget_limited"], bool)
+        assert s["min_ms"] <= s["median_ms"] <= s["max_ms"]
+    assert rec["value"] == max(s["evals_per_s"] for s in rec["solvers"].values())
