@@ -97,6 +97,7 @@ static void load_env(UmnnOptions& o) {
     o.fwd_pad_min = env_int("UMNN_FWD_PAD_MIN", 1);
     v = env_int("UMNN_BWD_NS", -1); o.bwd_ns = v >= 1 && v <= 32 ? v : -1;
     o.bwd_swp = env_int("UMNN_BWD_SWP", 1) != 0;
+    o.bwd_ws = env_int("UMNN_BWD_WS", 1) != 0;
 }
 UmnnOptions& umnn_options() {
     static UmnnOptions opts;
@@ -119,6 +120,7 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "fwd_pad_min")) return &o.fwd_pad_min;
     if (!strcmp(name, "bwd_ns")) return &o.bwd_ns;
     if (!strcmp(name, "bwd_swp")) return &o.bwd_swp;
+    if (!strcmp(name, "bwd_ws")) return &o.bwd_ws;
     return nullptr;
 }
 // the same per-option ranges load_env accepts (anything else would reach the launchers as "no such variant")
@@ -133,6 +135,7 @@ static bool option_value_ok(const char* name, int v) {
     if (!strcmp(name, "fwd_pad_min")) return v >= 0 && v <= 127;
     if (!strcmp(name, "bwd_ns")) return v == -1 || (v >= 1 && v <= 32);
     if (!strcmp(name, "bwd_swp")) return v == 0 || v == 1;
+    if (!strcmp(name, "bwd_ws")) return v == 0 || v == 1;
     return true;
 }
 extern "C" int umnn_set_option(const char* name, int value) {

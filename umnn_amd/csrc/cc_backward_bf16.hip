@@ -3,6 +3,7 @@
 // cc_backward_front.hip).
 #include "cc_bwd_bf16_kernel.h"
 #include "cc_bwd_swp_kernel.h"
+#include "cc_bwd_ws_kernel.h"
 
 // ------------------------------------------------------------------------------------------
 typedef void (*bwd_bf16_kernel_t)(const BwdBf16Args);
@@ -22,6 +23,13 @@ struct BwdSwpVariant { int lh, nrl; bwd_bf16_kernel_t fn; const char* name; };
 static const BwdSwpVariant kBwdSwpVariants[] = {
     BWD_SWP_VARIANT(4, 13), BWD_SWP_VARIANT(3, 13), BWD_SWP_VARIANT(2, 13),
     BWD_SWP_VARIANT(4, 0), BWD_SWP_VARIANT(3, 0), BWD_SWP_VARIANT(2, 0),
+};
+
+// weight-stationary workgroup pipeline (cc_bwd_ws_kernel.h): four hidden layers, enough tiles to keep every workgroup's pipeline full
+struct BwdWsVariant { int nrl; bwd_bf16_kernel_t fn; const char* name; };
+static const BwdWsVariant kBwdWsVariants[] = {
+    { 13, cc_bwd_ws_kernel<13>, "cc_bwd_bf16<L=4,LIVE=13,WS>" },
+    { 0, cc_bwd_ws_kernel<0>, "cc_bwd_bf16<L=4,LIVE=0,WS>" },
 };
 
 // Plans and launches the main backward pass with the bf16 kernels.  Returns UMNN_EUNSUPPORTED when the shape is
@@ -44,6 +52,46 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
     if (nrl != 13) nrl = 0;
     a.ngroups = (unsigned)((a.NI + 15) / 16);
     if (a.ns > a.n + 1) a.ns = a.n + 1;
+    if (umnn_options().bwd_ws && L == 4) {
+        const long long items = (long long)a.ngroups * (a.ns > 1 ? a.ns : 1);
+        const BwdWsVariant* wv = nullptr;
+        for (const BwdWsVariant& c : kBwdWsVariants)
+            if (c.nrl == nrl) { wv = &c; break; }
+        if (wv && a.ns <= 1 && items >= 4LL * nblocks_max) {
+            const size_t lds_ws = (size_t)WS_LDS_USHORTS * sizeof(unsigned short);
+            const int nblocks = nblocks_max;
+            *nwaves_out = nblocks * UMNN_WAVES_PER_BLOCK;
+            a.l_lo = 1;
+            if (int rc = umnn_allow_lds((const void*)wv->fn, lds_ws)) return rc;
+#ifdef UMNN_WS_TIMING
+            static double* tbuf = nullptr;
+            const int nw = nblocks * UMNN_WAVES_PER_BLOCK;
+            if (!tbuf) hipMalloc(&tbuf, sizeof(double) * 6 * 4096);
+            hipMemsetAsync(tbuf, 0, sizeof(double) * 6 * nw, stream);
+            args.tz2 = reinterpret_cast<const float*>(tbuf);
+#endif
+            umnn_prof_begin(stream);
+            hipLaunchKernelGGL(wv->fn, dim3(nblocks), dim3(UMNN_BLOCK), lds_ws, stream, args);
+            umnn_prof_end(stream, 3.0 * umnn_cc_forward_flops_per_integral(net, a.n) * (double)a.NI, UMNN_PROF_BACKWARD);
+#ifdef UMNN_WS_TIMING
+            {
+                hipStreamSynchronize(stream);
+                static double host[6 * 4096];
+                hipMemcpy(host, tbuf, sizeof(double) * 6 * nw, hipMemcpyDeviceToHost);
+                const char* role[4] = {"C ", "G1", "G2", "G3"};
+                for (int r = 0; r < 4; ++r) {
+                    double sm[6] = {0};
+                    for (int w = r; w < nw; w += 4) for (int j = 0; j < 6; ++j) sm[j] += host[6 * w + j];
+                    const double st = sm[4] > 0 ? sm[4] : 1;
+                    fprintf(stderr, "WS_TIMING %s per step (s_memtime ticks): prep %.0f | region1 %.0f | region2 %.0f | barrier wait %.0f   (steps per wave %.0f)\n",
+                            role[r], sm[0] / st, sm[1] / st, sm[2] / st, sm[3] / st, sm[4] / (nw / 4));
+                }
+            }
+#endif
+            umnn_note_launch(wv->name);
+            return umnn_check(hipGetLastError(), "cc_bwd_bf16 (ws) launch");
+        }
+    }
     if (umnn_options().bwd_swp) {
         const BwdSwpVariant* sv = nullptr;
         for (const BwdSwpVariant& c : kBwdSwpVariants)
