@@ -376,7 +376,7 @@ def test_software_pipelined_backward_agrees_with_the_round2_loop(shape, with_gfx
     gf = torch.randn(B, d, device=dev) if with_gfx else None
     outs = {}
     for swp in (0, 1):
-        with _lib.options(bwd_swp=swp):
+        with _lib.options(bwd_swp=swp, bwd_ws=0):
             outs[swp] = I.hip_backward(spec, x0, x, h, gg, gf, n)
             name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
             assert ("SWP" in name) == bool(swp), name
@@ -387,3 +387,72 @@ def test_software_pipelined_backward_agrees_with_the_round2_loop(shape, with_gfx
     assert torch.equal(outs[0][3][-n_last:], outs[1][3][-n_last:])
     for a_, b_ in zip(outs[0][2:], outs[1][2:]):
         assert U.scaled_err(b_.cpu().numpy(), a_.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("case", [
+    # B, d, E, hidden, n, g_fx, out_act, x dtype, h dtype, inv_f
+    (300, 63, 30, [50] * 4, 20, True, "ELU", torch.float32, torch.float32, False),
+    (301, 63, 30, [48, 60, 36, 50], 12, True, "ELU", torch.float32, torch.float32, False),      # LIVE = 0 variant, ragged last tile
+    (2100, 8, 10, [50] * 4, 15, False, "Sigmoid", torch.float32, torch.float32, False),
+    (1100, 16, 6, [50] * 4, 7, True, "ELU", torch.bfloat16, torch.bfloat16, False),
+    (1030, 16, 5, [50] * 4, 9, True, "ELU", torch.float32, torch.float32, True),
+])
+def test_weight_stationary_backward_agrees_with_the_pipelined_loop_and_fp32(case, dev):
+    """cc_bwd_ws_kernel (eight role waves per workgroup: the weights of one layer resident in each GEMM wave's registers,
+    tile-nodes passed from wave to wave through LDS tiles, dW on 32x32x16 MFMAs) against cc_bwd_swp_kernel and the exact
+    fp32 kernels.  Same six-term recompute, three-term delta chain and three-term dW; the order of a few additions differs
+    (four partial sums in the output layer's dot product, dW summed per 32x32 tile), so outputs are compared to 5e-6 of their
+    largest entry against the pipelined loop and within the bf16x3 path tolerance against fp32.  Covers both register
+    variants, a ragged last tile, the tangent element (g_fx), sigmoid outputs, bf16 storage and the 1/f operator."""
+    import umnn_amd
+    from umnn_amd import _lib
+    from umnn_amd import integral as I
+    from umnn_amd.nets import mlp_spec
+    B, d, E, hid, n, with_gfx, out_act, xdt, hdt, inv_f = case
+    torch.manual_seed(B * 7 + d)
+    net = umnn_amd.IntegrandNetwork(d, 1 + E, hid, 1, act_func=out_act).to(dev)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.mul_(1.7)
+    spec = mlp_spec(net)
+    x, x0 = (torch.randn(B, d, device=dev) * 2).to(xdt), (torch.randn(B, d, device=dev) * 0.3).to(xdt)
+    h, gg = torch.randn(B, E * d, device=dev).to(hdt), torch.randn(B, d, device=dev).to(xdt)
+    gf = torch.randn(B, d, device=dev).to(xdt) if with_gfx else None
+    outs = {}
+    for key, ws, prec in (("swp", 0, "bf16x3"), ("ws", 1, "bf16x3"), ("fp32", 0, "fp32")):
+        _lib.set_backward_precision(prec)
+        try:
+            with _lib.options(bwd_ws=ws):
+                outs[key] = I.hip_backward(spec, x0, x, h, gg, gf, n, inv_f=inv_f)
+                name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+                if key == "ws":
+                    assert ",WS>" in name, name
+                    again = I.hip_backward(spec, x0, x, h, gg, gf, n, inv_f=inv_f)
+                    assert all(torch.equal(u, v) for u, v in zip(outs[key], again)), "bit-reproducible (no atomics)"
+                else:
+                    assert ",WS>" not in name, name
+        finally:
+            _lib.set_backward_precision("bf16x3")
+    storage = 2e-2 if xdt == torch.bfloat16 else 0.0        # outputs stored as bf16: one rounding of the last bit
+    for i, nm in enumerate(("dx0", "dx", "dh", "dtheta")):
+        a_, b_, r_ = (outs[k][i].float().cpu().numpy() for k in ("swp", "ws", "fp32"))
+        assert np.isfinite(b_).all(), nm
+        assert U.scaled_err(b_, a_) < max(5e-6, storage), (nm, U.scaled_err(b_, a_))
+        assert U.scaled_err(b_, r_) < max(1e-3 if nm == "dh" else 2e-4, storage), (nm, U.scaled_err(b_, r_))
+
+
+def test_weight_stationary_backward_is_only_taken_for_large_unsplit_batches(dev):
+    """The workgroup pipeline needs a long element stream per workgroup: small batches (fewer than four tiles per workgroup, or a
+    node range split over several work items) stay on the software-pipelined loop, as do nets that are not four hidden layers."""
+    import umnn_amd
+    from umnn_amd import _lib
+    from umnn_amd import integral as I
+    from umnn_amd.nets import mlp_spec
+    for B, d, hid in ((64, 63, [50] * 4), (300, 63, [50] * 3)):
+        net = umnn_amd.IntegrandNetwork(d, 31, hid, 1).to(dev)
+        spec = mlp_spec(net)
+        x, h, gg = torch.randn(B, d, device=dev), torch.randn(B, 30 * d, device=dev), torch.randn(B, d, device=dev)
+        with _lib.options(bwd_ws=1):
+            I.hip_backward(spec, None, x, h, gg, None, 20)
+            name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+        assert "SWP" in name, name

@@ -97,7 +97,7 @@ static void load_env(UmnnOptions& o) {
     o.fwd_pad_min = env_int("UMNN_FWD_PAD_MIN", 1);
     v = env_int("UMNN_BWD_NS", -1); o.bwd_ns = v >= 1 && v <= 32 ? v : -1;
     o.bwd_swp = env_int("UMNN_BWD_SWP", 1) != 0;
-    o.bwd_ws = env_int("UMNN_BWD_WS", 0) != 0;
+    o.bwd_ws = env_int("UMNN_BWD_WS", 1) != 0;
 }
 UmnnOptions& umnn_options() {
     static UmnnOptions opts;

@@ -65,26 +65,26 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
             if (int rc = umnn_allow_lds((const void*)wv->fn, lds_ws)) return rc;
 #ifdef UMNN_WS_TIMING
             static double* tbuf = nullptr;
-            const int nw = nblocks * UMNN_WAVES_PER_BLOCK;
-            if (!tbuf) hipMalloc(&tbuf, sizeof(double) * 6 * 4096);
-            hipMemsetAsync(tbuf, 0, sizeof(double) * 6 * nw, stream);
+            const int nw = nblocks * WS_WAVES;
+            if (!tbuf) hipMalloc(&tbuf, sizeof(double) * 4 * 8192);
+            hipMemsetAsync(tbuf, 0, sizeof(double) * 4 * nw, stream);
             args.tz2 = reinterpret_cast<const float*>(tbuf);
 #endif
             umnn_prof_begin(stream);
-            hipLaunchKernelGGL(wv->fn, dim3(nblocks), dim3(UMNN_BLOCK), lds_ws, stream, args);
+            hipLaunchKernelGGL(wv->fn, dim3(nblocks), dim3(64 * WS_WAVES), lds_ws, stream, args);
             umnn_prof_end(stream, 3.0 * umnn_cc_forward_flops_per_integral(net, a.n) * (double)a.NI, UMNN_PROF_BACKWARD);
 #ifdef UMNN_WS_TIMING
             {
                 hipStreamSynchronize(stream);
-                static double host[6 * 4096];
-                hipMemcpy(host, tbuf, sizeof(double) * 6 * nw, hipMemcpyDeviceToHost);
-                const char* role[4] = {"C ", "G1", "G2", "G3"};
-                for (int r = 0; r < 4; ++r) {
-                    double sm[6] = {0};
-                    for (int w = r; w < nw; w += 4) for (int j = 0; j < 6; ++j) sm[j] += host[6 * w + j];
-                    const double st = sm[4] > 0 ? sm[4] : 1;
-                    fprintf(stderr, "WS_TIMING %s per step (s_memtime ticks): prep %.0f | region1 %.0f | region2 %.0f | barrier wait %.0f   (steps per wave %.0f)\n",
-                            role[r], sm[0] / st, sm[1] / st, sm[2] / st, sm[3] / st, sm[4] / (nw / 4));
+                static double host[4 * 8192];
+                hipMemcpy(host, tbuf, sizeof(double) * 4 * nw, hipMemcpyDeviceToHost);
+                const char* role[8] = {"Ca", "F1", "F2", "F3", UMNN_WS_PAIRING ? "B3" : "Cb", "B1", "B2", UMNN_WS_PAIRING ? "Cb" : "B3"};
+                for (int r = 0; r < WS_WAVES; ++r) {
+                    double sm[4] = {0};
+                    for (int w = r; w < nw; w += WS_WAVES) for (int j = 0; j < 4; ++j) sm[j] += host[4 * w + j];
+                    const double st = sm[3] > 0 ? sm[3] : 1;
+                    fprintf(stderr, "WS_TIMING %s per step (s_memtime ticks): prep %.0f | work %.0f | barrier wait %.0f   (steps per wave %.0f)\n",
+                            role[r], sm[0] / st, sm[1] / st, sm[2] / st, sm[3] / (nw / WS_WAVES));
                 }
             }
 #endif
