@@ -69,7 +69,10 @@ __device__ __forceinline__ WsCursor ws_next(const WsShape& sh, WsCursor c) {
 }
 // ring of LDS tiles: ushort offset of the current tile, advanced once per step (no division in the step loop)
 template <int NS, int STRIDE>
-__device__ __forceinline__ void ws_adv(int& off) { off += STRIDE; if (off == NS * STRIDE) off = 0; }
+__device__ __forceinline__ void ws_adv(int& off) {
+    if constexpr (NS == 2) off ^= STRIDE;               // (two-tile rings: one scalar instruction)
+    else { off += STRIDE; if (off == NS * STRIDE) off = 0; }
+}
 template <int NS, int STRIDE>
 __host__ __device__ constexpr int ws_ring0(int delay) { return ((WS_BIAS - delay) % NS) * STRIDE; }
 
@@ -88,6 +91,12 @@ __device__ __forceinline__ u32x2 ws_tr_read(const unsigned short* src) {
 
 #ifndef UMNN_WS_PAIRING
 #define UMNN_WS_PAIRING 0
+#endif
+#ifndef UMNN_WS_DW1_IN_B1
+#define UMNN_WS_DW1_IN_B1 0         // dW_1 accumulated by wave B1 (1) or Cb (0): balances the instruction count of the SIMDs
+#endif
+#ifndef UMNN_WS_D4_IN_CA
+#define UMNN_WS_D4_IN_CA 0          // delta_4 = dout w_out act'(a_4) formed by wave Ca (1) or Cb (0)
 #endif
 #ifdef UMNN_WS_TIMING
 #define WS_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -166,6 +175,14 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
     const int trb = (8 * (g >> 1) + (p >> 2)) * TRS + 16 * (g & 1) + 4 * (p & 3);
     const int nit = sh.nit;
     ws_clear_tiles(lds16);
+    float wout[BT][4];                                  // (delta_4 is formed here: see the step loop)
+#pragma unroll
+    for (int t = 0; t < BT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = feat_of(t, r, g);
+            wout[t][r] = f < m.width[4] ? m.W[4][f] : 0.f;       // (no cotangent through the constant feature's slot)
+        }
 
     float w1x[BT][4];
     {
@@ -237,6 +254,7 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
 
     WS_TIMING_DECL;
     int rA3 = ws_ring0<WS_NS3, WS_TILE>(8), rD4 = ws_ring0<2, WS_TILE>(8);
+    int rS4 = ws_ring0<2, WS_P3>(7), rD4w = ws_ring0<2, WS_TILE>(7);
     int rO1 = ws_ring0<WS_NS1, WS_TILE>(0), rO3 = ws_ring0<2, WS_P3>(0);
     // node position of the current element (the table value of the NEXT element is fetched a step ahead)
     bool live = cu.j < nit;
@@ -256,6 +274,14 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         const unsigned short* D4 = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + trb;
         unsigned short* const O1 = lds16 + WS_OFF_A1 + rO1 + own;
         unsigned short* const O1p3 = lds16 + WS_OFF_P3 + rO3 + own;
+#if UMNN_WS_D4_IN_CA
+        // what F3 left a step ago for element s - 7: the leading piece of a_4 (its sign) and dout
+        const unsigned short* S4 = lds16 + WS_OFF_S4 + rS4;
+        u32x4 sg4[BKS];
+#pragma unroll
+        for (int s2 = 0; s2 < BKS; ++s2) sg4[s2] = *reinterpret_cast<const u32x4*>(S4 + own + s2 * 8);
+        const float dout4 = *reinterpret_cast<const float*>(S4 + p * TRS + 64);
+#endif
         WsOps ops;
         // operands of dW_3 (A hi, B hi, B lo, A lo); then the layer-1 activations (registers only) while those fetches fly
         ws_load_op<0>(ops, D4, A3); ws_load_op<2>(ops, D4, A3); ws_load_op<4>(ops, D4, A3); ws_load_op<6>(ops, D4, A3);
@@ -300,6 +326,24 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
             if constexpr (nn >= 8 && nn < 11) store_a(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 8>{});
             __builtin_amdgcn_sched_barrier(0);
         });
+#if UMNN_WS_D4_IN_CA
+        // delta_4 of element s - 7: delta_L = dout w_out act'(a_L), split, stored for B3 and for this wave's dW_3 of the next step
+        {
+            f32x4 d4[BT];
+#pragma unroll
+            for (int t = 0; t < BT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    d4[t][r] = 4 * t + r < NLIVE ? (dout4 * wout[t][r]) * act_grad_q(sg4, t, r, slope) : 0.f;
+            BFrag<NPB> q;
+            split_regs<NRL, NPB>(d4, q);
+            unsigned short* const D4o = lds16 + WS_OFF_D + 4 * WS_TILE + rD4w + own;
+#pragma unroll
+            for (int s2 = 0; s2 < BKS; ++s2)
+#pragma unroll
+                for (int k2 = 0; k2 < NPB; ++k2) *reinterpret_cast<u32x4*>(D4o + k2 * 16 * TRS + s2 * 8) = q.v[s2][k2];
+        }
+#endif
         // next element: its item data if it opens a new tile, its node position from the table value fetched above
         if (live) {
             const bool crossed = nx.j != cu.j;
@@ -312,6 +356,7 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         }
         ws_adv<WS_NS3, WS_TILE>(rA3); ws_adv<2, WS_TILE>(rD4);
         ws_adv<WS_NS1, WS_TILE>(rO1); ws_adv<2, WS_P3>(rO3);
+        ws_adv<2, WS_P3>(rS4); ws_adv<2, WS_TILE>(rD4w);
         WS_T(t2);
         __syncthreads();
         WS_T(t3);
@@ -367,9 +412,12 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
         const unsigned short* S4 = lds16 + WS_OFF_S4 + rS4;
         unsigned short* const D4o = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + own;
         u32x4 sg4[BKS];
+        float dout = 0.f;
+#if !UMNN_WS_D4_IN_CA
 #pragma unroll
         for (int s2 = 0; s2 < BKS; ++s2) sg4[s2] = *reinterpret_cast<const u32x4*>(S4 + own + s2 * 8);
-        const float dout = *reinterpret_cast<const float*>(S4 + p * TRS + 64);
+        dout = *reinterpret_cast<const float*>(S4 + p * TRS + 64);
+#endif
         const unsigned short* A2 = lds16 + WS_OFF_A2 + rA2 + trb;
         const unsigned short* A1 = lds16 + WS_OFF_A1 + rA1 + trb;
         const unsigned short* D3 = lds16 + WS_OFF_D + 2 * WS_TILE + rD3 + trb;
@@ -395,17 +443,19 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
             *reinterpret_cast<u32x4*>(D4o + k2 * 16 * TRS + ks * 8) = u32x4{q4[4 * ks][k2], q4[4 * ks + 1][k2], q4[4 * ks + 2][k2], q4[4 * ks + 3][k2]};
         };
         WS_T(t1);
-        swp_static_for<24>([&](auto nc) {
+        swp_static_for<UMNN_WS_DW1_IN_B1 ? 12 : 24>([&](auto nc) {
             constexpr int nn = decltype(nc)::value;
             if constexpr (nn < 12) ws_dw_mfma<nn>(dW2, o2);
             else ws_dw_mfma<nn - 12>(dW1, o1);
-            if constexpr (nn < 8) ws_load_op<nn>(o1, D2, A1);
+            if constexpr (nn < 8 && !UMNN_WS_DW1_IN_B1) ws_load_op<nn>(o1, D2, A1);
             // delta_4: two registers per slot, pair j split at slots j + 1 / j + 2, K-steps stored at 6, 7 / 10, 11
+#if !UMNN_WS_D4_IN_CA
             if constexpr (nn < 8) { d4_reg(std::integral_constant<int, 2 * nn>{}); d4_reg(std::integral_constant<int, 2 * nn + 1>{}); }
             if constexpr (nn >= 1 && nn < 9) pair4(std::integral_constant<int, nn - 1>{}, std::integral_constant<int, 0>{});
             if constexpr (nn >= 2 && nn < 10) pair4(std::integral_constant<int, nn - 2>{}, std::integral_constant<int, 1>{});
             if constexpr (nn == 6 || nn == 7) store_d4(std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 6>{});
             if constexpr (nn == 10 || nn == 11) store_d4(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 10>{});
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
         ws_adv<WS_NS2, WS_TILE>(rA2); ws_adv<WS_NS1, WS_TILE>(rA1);
@@ -418,7 +468,7 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
     }
     WS_TIMING_OUT(S);
     ws_write_dw(a, part, 2, dW2, lane);
-    ws_write_dw(a, part, 1, dW1, lane);
+    if constexpr (!UMNN_WS_DW1_IN_B1) ws_write_dw(a, part, 1, dW1, lane);
 }
 
 // ============================================================================================================ waves F1..F3
@@ -483,11 +533,15 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
     };
     if (nit > 0) new_item_P();
 
-    f32x4 acc[BT];
+#ifndef UMNN_WS_ACC8
+#define UMNN_WS_ACC8 0          // 1: the two K-steps of the forward GEMM accumulate separately (eight independent MFMA chains), summed before the activation
+#endif
+    f32x4 acc[BT], acc1[BT];
     float actF[BT][4], delta[BT][4];                   // (delta: the tangent values of a tangent element)
 #pragma unroll
     for (int t = 0; t < BT; ++t) {
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) { actF[t][r] = 0.f; delta[t][r] = 0.f; }
     }
@@ -539,6 +593,9 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
             constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4, j = e / 2;
             constexpr bool TAN = decltype(tanc)::value;
             if constexpr (e < NLIVE) {
+#if UMNN_WS_ACC8
+                acc[t][r] += acc1[t][r];
+#endif
                 if constexpr (!IS_OUT) {
                     if constexpr (TAN) {
                         // tangent element: times act'(a_{l+1}) of the element before (node 0), read off its leading bf16 piece
@@ -639,17 +696,32 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
         {
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             swp_static_for<48>([&](auto nc) {
-                constexpr int nn = decltype(nc)::value, s2 = nn / 24, idx = nn % 24;
+                constexpr int nn = decltype(nc)::value;
+#if UMNN_WS_ACC8
+                // (groups of four tiles alternate between the K-steps: a chain's next link is eight instructions away)
+                constexpr int s2 = (nn / 4) & 1, idx = 4 * (nn / 8) + (nn % 4);
+                f32x4 (&ac)[BT] = s2 ? acc1 : acc;
+                constexpr bool first = idx < 4;
+#else
+                constexpr int s2 = nn / 24, idx = nn % 24;
+                f32x4 (&ac)[BT] = acc;
+                constexpr bool first = s2 == 0 && idx < 4;
+#endif
+#ifndef UMNN_WS_EXP_NOMFMA_F            // (timing experiments only: wrong results)
                 if constexpr (idx < 12) {
                     constexpr int t = idx % 4, ba = idx / 4;
-                    acc[t] = mfma_bf16(Wf[t][s2][0], bf.v[s2][ba], (s2 == 0 && idx < 4) ? zero : acc[t]);
+                    ac[t] = mfma_bf16(Wf[t][s2][0], bf.v[s2][ba], first ? zero : ac[t]);
                 } else if constexpr (idx < 20) {
                     constexpr int t = (idx - 12) % 4, ba = (idx - 12) / 4;
-                    acc[t] = mfma_bf16(Wf[t][s2][1], bf.v[s2][ba], acc[t]);
+                    ac[t] = mfma_bf16(Wf[t][s2][1], bf.v[s2][ba], ac[t]);
                 } else {
                     constexpr int t = idx - 20;
-                    acc[t] = mfma_bf16(Wf[t][s2][2], bf.v[s2][0], acc[t]);
+                    ac[t] = mfma_bf16(Wf[t][s2][2], bf.v[s2][0], ac[t]);
                 }
+#else
+                (void)first; (void)zero;
+#endif
+#ifndef UMNN_WS_EXP_NOVALU_F
                 if constexpr (!IS_OUT) {
                     // pair j: rounding stages at slots 3j, 3j + 1, 3j + 2; K-step 0 stored at 12..14, K-step 1 at 24..26
                     if constexpr (nn < 24 && (nn % 3) == 0) pairF(std::integral_constant<int, nn / 3>{}, std::integral_constant<int, 0>{});
@@ -665,6 +737,7 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
                     if constexpr (nn == 9) *reinterpret_cast<float*>(S4out + p * TRS + 64) = doutN;
                     if constexpr (nn >= 10 && nn < 18) { out_reg(std::integral_constant<int, 2 * (nn - 10)>{}); out_reg(std::integral_constant<int, 2 * (nn - 10) + 1>{}); }
                 }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -733,6 +806,15 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
     f32x4 dW1x[BT], dcs[BT];
 #pragma unroll
     for (int t = 0; t < BT; ++t) { dW1x[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    constexpr bool HAS_DW = IS_TAIL && UMNN_WS_DW1_IN_B1;   // B1 also accumulates dW_1 += delta_2 (x) a_1 (same element as its GEMM)
+    const int trb = (8 * (g >> 1) + (p >> 2)) * TRS + 16 * (g & 1) + 4 * (p & 3);
+    ws_f32x16 dWb[2][2];
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) dWb[to][ti][v] = 0.f;
     WsCursor cb{0, 0};
     float xvB = 0.f, x0vB = 0.f, dxvB = 0.f;
     auto new_item_B = [&]() __attribute__((always_inline)) {
@@ -776,6 +858,12 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
             for (int k2 = 0; k2 < NPB; ++k2) bd.v[s2][k2] = *reinterpret_cast<const u32x4*>(Din + k2 * 16 * TRS + s2 * 8);
 #pragma unroll
         for (int s2 = 0; s2 < BKS; ++s2) sg[s2] = *reinterpret_cast<const u32x4*>(Asg + s2 * 8);
+        WsOps ob;
+        if constexpr (HAS_DW) {
+            const unsigned short* Dt = Din - own + trb, *At = Asg - own + trb;      // the same two tiles, transposing reads
+            ws_load_op<0>(ob, Dt, At); ws_load_op<2>(ob, Dt, At); ws_load_op<4>(ob, Dt, At); ws_load_op<6>(ob, Dt, At);
+            ws_load_op<5>(ob, Dt, At); ws_load_op<7>(ob, Dt, At); ws_load_op<1>(ob, Dt, At); ws_load_op<3>(ob, Dt, At);
+        }
         WS_T(t1);
         // ---- W_l^T GEMM (24 MFMAs, A operands = this wave's registers)
         f32x4 nd[BT];
@@ -791,6 +879,7 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
                 for (int t = 0; t < BT; ++t) nd[t] = mfma_bf16(WT[t][s2][1], bd.v[s2][0], nd[t]);
             }
         }
+        if constexpr (HAS_DW) swp_static_for<12>([&](auto nc) { ws_dw_mfma<decltype(nc)::value>(dWb, ob); });
         // ---- delta_l = (W_l^T delta_{l+1}) . act'(a_l); B1: the tail of the node; B2, B3: split and store for the wave below
         f32x4 dl[BT];
 #pragma unroll
@@ -845,6 +934,7 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
     WS_TIMING_OUT(S);
+    if constexpr (HAS_DW) ws_write_dw(a, part, 1, dWb, lane);
     if constexpr (IS_TAIL) {
 #pragma unroll
         for (int t = 0; t < BT; ++t)
@@ -894,11 +984,21 @@ __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws_kernel(const BwdBf
         else if (role == 1) ws_role_B<NRL, 1>(args, lds16, S, sh, part);
         else if (role == 2) ws_role_B<NRL, 2>(args, lds16, S, sh, part);
         else ws_role_B<NRL, 3>(args, lds16, S, sh, part);
-#else
+#elif UMNN_WS_PAIRING == 1
         if (role == 0) ws_role_B<NRL, 3>(args, lds16, S, sh, part);
         else if (role == 1) ws_role_B<NRL, 1>(args, lds16, S, sh, part);
         else if (role == 2) ws_role_B<NRL, 2>(args, lds16, S, sh, part);
         else ws_role_Cb<NRL>(args, lds16, S, sh, part);
+#elif UMNN_WS_PAIRING == 2
+        if (role == 0) ws_role_B<NRL, 1>(args, lds16, S, sh, part);
+        else if (role == 1) ws_role_B<NRL, 3>(args, lds16, S, sh, part);
+        else if (role == 2) ws_role_B<NRL, 2>(args, lds16, S, sh, part);
+        else ws_role_Cb<NRL>(args, lds16, S, sh, part);
+#else
+        if (role == 0) ws_role_B<NRL, 2>(args, lds16, S, sh, part);
+        else if (role == 1) ws_role_B<NRL, 1>(args, lds16, S, sh, part);
+        else if (role == 2) ws_role_Cb<NRL>(args, lds16, S, sh, part);
+        else ws_role_B<NRL, 3>(args, lds16, S, sh, part);
 #endif
     }
 }
