@@ -1,35 +1,44 @@
 // Weight-stationary one-pass backward on the bf16 matrix cores (round 3, second kernel): the waves of a workgroup stop being
 // copies of the same program.  Same arithmetic as cc_bwd_swp_kernel.h / cc_bwd_bf16_kernel.h (reference lines
-// ParallelNeuralIntegral.py:66-94,110-123): six-term recompute, three-term delta chain, dW on the matrix core -- but in those
-// kernels every wave needs the whole register file (192 dW accumulators), so ONE wave per SIMD issues a serial stream of
-// ~1400 instructions per tile-node at ~7 cycles each (nothing fills its dependency stalls), and every GEMM MFMA pulls a
-// fresh 1 KB weight fragment out of LDS.  Here the weights never move and no wave holds more than a quarter
-// of the state: EIGHT waves per workgroup, two per SIMD, each <= 256 registers:
+// ParallelNeuralIntegral.py:66-94,110-123): six-term recompute, three-term delta chain, three-term dW on the matrix core.  In
+// those kernels every wave needs the whole register file (192 dW accumulators), so ONE wave per SIMD issues a serial stream
+// of ~1430 instructions per tile-node (nothing fills its dependency stalls), and every GEMM MFMA pulls a fresh 1 KB weight
+// fragment out of LDS.  Here the weights never move and no wave holds more than a quarter of the state: EIGHT
+// waves per workgroup, two per SIMD, each <= 256 registers:
 //
 //   F1, F2, F3   forward GEMM of hidden layer l -> l+1: W_l (3 bf16 pieces, 96 registers) lives in the wave's registers for
 //                the whole launch; per step 48 MFMAs on one tile-node (B operands: 6 LDS reads) with the activation / split
-//                of the tile-node before behind them.  F3 ends in the output layer: f, dout, delta_L, d w_out.
+//                of the tile-node before behind them.  F3 ends in the output layer: f, dout, d w_out; it leaves dout and the
+//                leading piece of a_4 (the sign is all delta_4 needs).
 //   B1, B2, B3   W_l^T (2 pieces, 64 registers): per step 24 MFMAs, then delta_l = (W_l^T delta_{l+1}) . act'(a_l), split,
 //                stored for the next wave down.  B1 ends in the tail (dc, dW1[:,0]).
-//   Ca           layer 1 (a_1 of a new tile-node per step) and dW_3;   Cb   dW_2 and dW_1.  dW_l += delta_{l+1} (x) a_l as
-//                2 x 2 tiles of 32 x 32 on v_mfma_f32_32x32x16_bf16 (K = the 16 points; 12 MFMAs per layer and tile-node),
-//                operands by transposing LDS reads.
+//   Ca           layer 1 (a_1 of a new tile-node per step) and dW_3;
+//   Cb           delta_4 = dout w_out act'(a_4) (split, stored), dW_2 and dW_1.
+//                dW_l += delta_{l+1} (x) a_l as 2 x 2 tiles of 32 x 32 on v_mfma_f32_32x32x16_bf16 (K = the 16 points; 12 MFMAs
+//                per layer and tile-node), operands by transposing LDS reads.
 //
 // Tile-nodes flow through the workgroup as a systolic pipeline over LDS tiles (the [piece][point][slot] tile of the other
 // kernels: own-lane b128 reads give B operands back, ds_read_b64_tr_b16 gives the transposed dW operands), one s_barrier per
 // step.  Element u of the stream (a node of a tile; node order 0, [tangent of node 0], 1, .., n per tile, tiles one after the
 // other) is at:
-//   step u      Ca  : a_1[u]                      -> tile A1[u % 10]
-//   step u+1/2  F1  : GEMM / activation, a_2[u]   -> tile A2[u % 7]          (GEMM in one step, its vector work in the next:
-//   step u+3/4  F2  : a_3[u]                      -> tile A3[u % 4]           the wave always has TWO independent jobs)
-//   step u+5/6  F3  : a_4[u], f, delta_4[u]       -> tile D4[u % 2]
-//   step u+7    B3  : delta_3[u] = W_3^T delta_4 . act'(a_3) -> D3[u % 2];   Ca: dW_3 += delta_4[u] (x) a_3[u]
-//   step u+8    B2  : delta_2[u] -> D2[u % 2];                                Cb: dW_2 += delta_3[u] (x) a_2[u]
-//   step u+9    B1  : delta_1[u] -> dc, dW1[:,0];                             Cb: dW_1 += delta_2[u] (x) a_1[u]
-// LDS: 21 activation tiles + 6 cotangent tiles of 4.5 KB, 6 third-piece tiles of 2.25 KB = 135 KB; no weight images.
+//   step u      Ca  : a_1[u]                      -> tile A1[u % 11]
+//   step u+1/2  F1  : GEMM / activation, a_2[u]   -> tile A2[u % 8]          (GEMM in one step, its vector work in the next:
+//   step u+3/4  F2  : a_3[u]                      -> tile A3[u % 5]           the wave always has TWO independent jobs)
+//   step u+5/6  F3  : a_4[u], f, dout[u]          -> tile S4[u % 2]
+//   step u+7    Cb  : delta_4[u]                  -> tile D4[u % 2]
+//   step u+8    B3  : delta_3[u] = W_3^T delta_4 . act'(a_3) -> D3[u % 2];   Ca: dW_3 += delta_4[u] (x) a_3[u]
+//   step u+9    B2  : delta_2[u] -> D2[u % 2];                                Cb: dW_2 += delta_3[u] (x) a_2[u]
+//   step u+10   B1  : delta_1[u] -> dc, dW1[:,0];                             Cb: dW_1 += delta_2[u] (x) a_1[u]
+// LDS: 24 activation tiles + 6 cotangent tiles of 4.5 KB, 8 single-piece tiles of 2.25 KB = 153 KB; no weight images.
 // The tangent pass of the g_fx term (d f / d x at node 0) is one extra stream element per tile: Ca sends w1 . act'(z_1), the F
 // waves multiply by act'(a_{l+1}(node 0)) -- the signs of the element before -- instead of applying the activation, F3 turns
 // it into dfdt and a zero cotangent.  Un-split node ranges only (BwdArgs::ns <= 1: large batches).
+//
+// Measured at C3 (8192 x 63, n = 100): 12.9-13.0 ms per launch against 13.4-13.6 for the software-pipelined loop.  Per tile-node
+// both kernels execute ~1420 instructions (here 764 vector + 251 matrix + 120 LDS + 277 scalar; there 792 + 359 + 245 + 33) and
+// their SIMDs issue for the same ~65 % of the time: the gain is the 20 % of matrix work the 32x32 dW tiles save, most of which
+// the scalar bookkeeping of eight cursors and two dozen tile rings gives back.  -DUMNN_WS_TIMING times every role per step;
+// the SIMD that hosts Ca + Cb (377 instructions per step) is the critical one (DESIGN 4.2 has the numbers and the variants).
 #pragma once
 #include "cc_bwd_swp_kernel.h"
 
@@ -949,8 +958,9 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
     }
 }
 
-// wave -> role.  Waves w and w + 4 share a SIMD; the pairs are chosen so that the four SIMDs issue about the same number of
-// instructions per step: Ca + B3, F1 + B1, F2 + B2, F3 + Cb.
+// wave -> role.  Waves w and w + 4 share a SIMD.  Default pairing: Ca + Cb, F1 + B1, F2 + B2, F3 + B3 -- every SIMD gets the same
+// matrix-pipe time (1152 cycles per step); the other pairings measured (UMNN_WS_PAIRING = 1..3) balance instruction counts better
+// and lose 1-2 ms to matrix-pipe contention.
 template <int NRL>
 __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws_kernel(const BwdBf16Args args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
