@@ -114,7 +114,7 @@ for tag, title in (("bsds300", "C3 BSDS300-shaped eval (8192 x 63 integrals per 
                 lines += [r for r in rows if "algorithmic FLOPs" not in r]
         else:
             # (round 3: the software-pipelined loop is its own kernel symbol; older profiles have cc_bwd_bf16_kernel)
-            name = "cc_bwd_swp_kernel" if any("cc_bwd_swp_kernel" in r["Name"] for r in stats) else "cc_bwd_bf16_kernel"
+            name = next((k for k in ("cc_bwd_ws_kernel", "cc_bwd_swp_kernel") if any(k in r["Name"] for r in stats)), "cc_bwd_bf16_kernel")
             e = kernel_entry(stats, pmc, name, 3 * fl)
             report[tag]["backward"] = e
             lines += table("backward quadrature kernel (algorithmic FLOPs = 3 x forward: two gradient GEMMs per forward GEMM + the recompute)", e)
