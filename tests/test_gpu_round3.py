@@ -456,3 +456,31 @@ def test_weight_stationary_backward_is_only_taken_for_large_unsplit_batches(dev)
             I.hip_backward(spec, None, x, h, gg, None, 20)
             name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
         assert "SWP" in name, name
+
+
+def test_weight_stationary_backward_at_the_benchmarked_size(dev):
+    """The configuration ``bench.py --mode train`` times (8192 x 63 integrals per block, n = 100, 50-wide net): every workgroup of
+    the pipeline streams ~126 tiles x 102 elements.  Against the software-pipelined loop on the same inputs, and bit-reproducible."""
+    import umnn_amd
+    from umnn_amd import _lib
+    from umnn_amd import integral as I
+    from umnn_amd.nets import mlp_spec
+    B, d, E, n = 8192, 63, 30, 100
+    torch.manual_seed(3)
+    net = umnn_amd.IntegrandNetwork(d, 1 + E, [50] * 4, 1).to(dev)
+    spec = mlp_spec(net)
+    x, h = torch.randn(B, d, device=dev), torch.randn(B, E * d, device=dev)
+    gg, gf = torch.randn(B, d, device=dev), torch.randn(B, d, device=dev)
+    outs = {}
+    for ws in (0, 1):
+        with _lib.options(bwd_ws=ws):
+            outs[ws] = I.hip_backward(spec, None, x, h, gg, gf, n)
+            name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+            assert (",WS>" in name) == bool(ws), name
+    again = I.hip_backward(spec, None, x, h, gg, gf, n)
+    assert all(torch.equal(u, v) for u, v in zip(outs[1][1:], again[1:]))
+    for i, nm in ((1, "dx"), (2, "dh"), (3, "dtheta")):
+        a_, b_ = outs[0][i].cpu().numpy(), outs[1][i].cpu().numpy()
+        assert np.isfinite(b_).all(), nm
+        # (at this size a handful of the 3e8 kink decisions differ between any two summation orders: dh is compared at 2e-5)
+        assert U.scaled_err(b_, a_) < (2e-5 if nm == "dh" else 5e-6), (nm, U.scaled_err(b_, a_))

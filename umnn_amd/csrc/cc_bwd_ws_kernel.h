@@ -454,11 +454,13 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
         WS_T(t1);
         swp_static_for<UMNN_WS_DW1_IN_B1 ? 12 : 24>([&](auto nc) {
             constexpr int nn = decltype(nc)::value;
+#ifndef UMNN_WS_EXP_NOMFMA_CB           // (timing experiments only: wrong results)
             if constexpr (nn < 12) ws_dw_mfma<nn>(dW2, o2);
             else ws_dw_mfma<nn - 12>(dW1, o1);
+#endif
             if constexpr (nn < 8 && !UMNN_WS_DW1_IN_B1) ws_load_op<nn>(o1, D2, A1);
             // delta_4: two registers per slot, pair j split at slots j + 1 / j + 2, K-steps stored at 6, 7 / 10, 11
-#if !UMNN_WS_D4_IN_CA
+#if !UMNN_WS_D4_IN_CA && !defined(UMNN_WS_EXP_NOD4_CB)
             if constexpr (nn < 8) { d4_reg(std::integral_constant<int, 2 * nn>{}); d4_reg(std::integral_constant<int, 2 * nn + 1>{}); }
             if constexpr (nn >= 1 && nn < 9) pair4(std::integral_constant<int, nn - 1>{}, std::integral_constant<int, 0>{});
             if constexpr (nn >= 2 && nn < 10) pair4(std::integral_constant<int, nn - 2>{}, std::integral_constant<int, 1>{});
