@@ -484,3 +484,47 @@ def test_weight_stationary_backward_at_the_benchmarked_size(dev):
         assert np.isfinite(b_).all(), nm
         # (at this size a handful of the 3e8 kink decisions differ between any two summation orders: dh is compared at 2e-5)
         assert U.scaled_err(b_, a_) < (2e-5 if nm == "dh" else 5e-6), (nm, U.scaled_err(b_, a_))
+
+
+@pytest.mark.parametrize("hid, with_gfx", [([100, 50, 50, 50, 50], True), ([112, 48, 60, 36, 50], False)])
+def test_weight_stationary_middle_stage_of_the_three_stage_backward(hid, with_gfx, dev):
+    """Nets with a wide first hidden layer (MNISTExperiment's 31-100-50-50-50-50-1): the middle stage of the three-stage backward
+    (cc_backward_front.hip) runs as the workgroup pipeline too -- z_2 fetched from HBM by wave Ca one element ahead, delta_2
+    written back by wave B1 -- when a chunk has at least four tiles per workgroup.  Against the one-pass middle kernel of round
+    2 on the same inputs and against the exact-fp32 kernels."""
+    import umnn_amd
+    from umnn_amd import _lib
+    from umnn_amd import integral as I
+    from umnn_amd.nets import mlp_spec
+    B, d, E, n = 40, 784, 30, 12
+    torch.manual_seed(11)
+    net = umnn_amd.IntegrandNetwork(d, 1 + E, hid, 1).to(dev)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.mul_(1.5)
+    spec = mlp_spec(net)
+    x, x0 = torch.randn(B, d, device=dev) * 2, torch.randn(B, d, device=dev) * 0.3
+    h, gg = torch.randn(B, E * d, device=dev), torch.randn(B, d, device=dev)
+    gf = torch.randn(B, d, device=dev) if with_gfx else None
+    outs = {}
+    for key, ws, prec in (("mid", 0, "bf16x3"), ("ws", 1, "bf16x3"), ("fp32", 0, "fp32")):
+        _lib.set_backward_precision(prec)
+        try:
+            with _lib.options(bwd_ws=ws):
+                outs[key] = I.hip_backward(spec, x0, x, h, gg, gf, n)
+                name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+                if key == "ws":
+                    assert "WS,FRONT" in name, name
+                    again = I.hip_backward(spec, x0, x, h, gg, gf, n)
+                    assert all(torch.equal(u, v) for u, v in zip(outs[key], again))
+                elif key == "mid":
+                    assert "FRONT" in name and "WS" not in name, name
+        finally:
+            _lib.set_backward_precision("bf16x3")
+    for i, nm in enumerate(("dx0", "dx", "dh", "dtheta")):
+        a_, b_, r_ = (outs[k][i].cpu().numpy() for k in ("mid", "ws", "fp32"))
+        assert np.isfinite(b_).all(), nm
+        assert U.scaled_err(b_, a_) < 5e-6, (nm, U.scaled_err(b_, a_))
+        # (dh against fp32: the 100-wide first layer at 1.5x weights flips a few more LeakyReLU kinks than the 50-wide nets do, for
+        # either bf16x3 kernel alike: 1.1e-3 measured)
+        assert U.scaled_err(b_, r_) < (3e-3 if nm == "dh" else 2e-4), (nm, U.scaled_err(b_, r_))

@@ -23,6 +23,7 @@
 // scratch the workspace provides (2 GiB), every wave's d_theta slice accumulating across chunks.  HBM traffic per
 // tile-node 4 x 3.3 KB against ~5 us of matrix work: three orders of magnitude below the bandwidth roof.
 #include "cc_bwd_bf16_kernel.h"
+#include "cc_bwd_ws_kernel.h"
 
 struct FrontArgs {
     BwdArgs b;              // the FULL net
@@ -473,6 +474,12 @@ struct MidVariant { int lh, nrl; mid_kernel_t fn; const char* name; };
 #define MID_VARIANT(LHH, NR) { LHH, NR, cc_bwd_bf16_kernel<LHH, true, NR, true>, "cc_bwd_bf16<L=" #LHH ",EDGE=1,LIVE=" #NR ",FRONT>" }
 static const MidVariant kMidVariants[] = { MID_VARIANT(4, 13), MID_VARIANT(3, 13), MID_VARIANT(2, 13),
                                            MID_VARIANT(4, 0), MID_VARIANT(3, 0), MID_VARIANT(2, 0) };
+// the middle stage as a weight-stationary workgroup pipeline (cc_bwd_ws_kernel.h): four hidden layers after the cut, chunks
+// of at least four tiles per workgroup
+static const MidVariant kMidWsVariants[] = {
+    { 4, 13, cc_bwd_ws_kernel<13, true>, "cc_bwd_bf16<L=4,LIVE=13,WS,FRONT>" },
+    { 4, 0, cc_bwd_ws_kernel<0, true>, "cc_bwd_bf16<L=4,LIVE=0,WS,FRONT>" },
+};
 
 // Does this net belong to the family?  hidden layer 1: 5..8 tiles; hidden layers 2..L: three or four tiles at most (zero-padded
 // to four), 2..4 of them.
@@ -548,6 +555,12 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
     if (int rc = umnn_allow_lds((const void*)fv->fwd, lds_a)) return rc;
     if (int rc = umnn_allow_lds((const void*)mv->fn, lds_mid)) return rc;
     if (int rc = umnn_allow_lds((const void*)fv->bwd, lds_c)) return rc;
+    const MidVariant* wv = nullptr;
+    if (umnn_options().bwd_ws && LH == 4)
+        for (const MidVariant& v : kMidWsVariants) if (v.nrl == nrl) { wv = &v; break; }
+    const size_t lds_ws = (size_t)WS_LDS_USHORTS * sizeof(unsigned short);
+    if (wv) { if (int rc = umnn_allow_lds((const void*)wv->fn, lds_ws)) return rc; }
+    bool used_ws = false;
 
     FrontArgs fa;
     fa.b = base;
@@ -567,10 +580,15 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
         fa.z2 = z2; fa.d2 = d2; fa.tz2 = tz2; fa.grp0 = (unsigned)t0; fa.b.ngroups = (unsigned)nt; fa.accumulate = t0 > 0;
         mid.z2 = z2; mid.d2 = d2; mid.tz2 = tz2; mid.grp0 = (unsigned)t0; mid.b.ngroups = (unsigned)nt; mid.accumulate = t0 > 0;
         hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
-        hipLaunchKernelGGL(mv->fn, dim3(nblocks), dim3(UMNN_BLOCK), lds_mid, stream, mid);
+        if (wv && nt >= 4LL * nblocks_max) {
+            hipLaunchKernelGGL(wv->fn, dim3(nblocks_max), dim3(64 * WS_WAVES), lds_ws, stream, mid);
+            used_ws = true;
+        } else {
+            hipLaunchKernelGGL(mv->fn, dim3(nblocks), dim3(UMNN_BLOCK), lds_mid, stream, mid);
+        }
         hipLaunchKernelGGL(fv->bwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_c, stream, fa);
     }
     umnn_prof_end(stream, 3.0 * umnn_cc_forward_flops_per_integral(net, n) * (double)base.NI, UMNN_PROF_BACKWARD);
-    umnn_note_launch(mv->name);
+    umnn_note_launch(used_ws ? wv->name : mv->name);
     return umnn_check(hipGetLastError(), "cc_bwd front launch");
 }

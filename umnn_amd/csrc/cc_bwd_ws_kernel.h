@@ -151,7 +151,7 @@ __device__ __forceinline__ void ws_dw_mfma(ws_f32x16 (&dW)[2][2], const WsOps& o
 }
 // this workgroup's d_theta slice: rows / columns of the dW tiles run over register slots (slot_feature); 32 x 32 result
 // layout: column lane & 31, register v = 4 i + r <-> row 8 i + 4 (lane >> 5) + r
-__device__ __forceinline__ void ws_write_dw(const BwdArgs& a, float* part, int l, const ws_f32x16 (&dW)[2][2], int lane) {
+__device__ __forceinline__ void ws_write_dw(const BwdArgs& a, float* part, int l, const ws_f32x16 (&dW)[2][2], int lane, bool accumulate) {
     const MlpDev& m = a.m;
     const int Hin = m.width[l], Hout = m.width[l + 1];
 #pragma unroll
@@ -164,12 +164,12 @@ __device__ __forceinline__ void ws_write_dw(const BwdArgs& a, float* part, int l
                 const int fi = slot_feature(32 * ti + (lane & 31));
                 if (fo < Hout) {
                     const int idx = fi < Hin ? a.poffW[l] + fo * Hin + fi : (fi == Hin ? a.poffb[l] + fo : -1);
-                    if (idx >= 0) part[idx] = dW[to][ti][v];
+                    if (idx >= 0) part[idx] = (accumulate ? part[idx] : 0.f) + dW[to][ti][v];
                 }
             }
 }
 
-template <int NRL>
+template <int NRL, bool FRONT>
 __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
     constexpr int NPAIR = (NLIVE + 1) / 2;
@@ -201,7 +201,7 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int f = feat_of(t, r, g);
-                w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
+                w1x[t][r] = (!FRONT && f < H1) ? W0[f * (1 + E)] : 0.f;
             }
     }
     ws_f32x16 dW[2][2];
@@ -217,8 +217,31 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
     f32x4 c[BT];
 #pragma unroll
     for (int t = 0; t < BT; ++t) c[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // FRONT (middle stage of the three-stage backward, cc_backward_front.hip): "layer 1" is the front kernel's z_2 out of HBM,
+    // [tile][node][register][lane]; fetched one element ahead.  zc = the current element's values (the tangent element: d z_2 / d t
+    // at node 0), zn = the next element's, z0 = z_2 of node 0 of the current tile (the tangent element needs its signs).
+    const int nl2 = NRL > 0 ? NRL : args.nl2;
+    float zc[BT][4], zn[BT][4], z0[BT][4];
+#pragma unroll
+    for (int t = 0; t < BT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { zc[t][r] = 0.f; zn[t][r] = 0.f; z0[t][r] = 0.f; }
+    auto fetch_z = [&](const WsCursor& c2, float (&dst)[BT][4]) __attribute__((always_inline)) {
+        const size_t tile0 = (size_t)ws_grp(c2) * (size_t)(a.n + 1) * nl2 * 64 + lane;
+        const bool tan = ws_is_tan(sh, c2);
+        const size_t base = tan ? (size_t)ws_grp(c2) * nl2 * 64 + lane : tile0 + (size_t)ws_node(sh, c2) * nl2 * 64;
+        const float* __restrict__ src = tan ? args.tz2 : args.z2;
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 4 * t + r, jj = j < nl2 ? j : nl2 - 1;       // (unconditional loads: index clamped, value masked)
+                if (j < NLIVE) { const float v = src[base + (size_t)jj * 64]; dst[t][r] = j < nl2 ? v : 0.f; }
+            }
+    };
     auto new_item = [&]() __attribute__((always_inline)) {
-        const long long q = (long long)ws_grp(cu) * 16 + p;
+        if constexpr (FRONT) return;
+        const long long q = (long long)(args.grp0 + ws_grp(cu)) * 16 + p;
         const long long qq = q < a.NI ? q : a.NI - 1;
         xv = io_ld(a.x, qq, a.x_bf16);
         x0v = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
@@ -246,6 +269,7 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         }
     };
     if (nit > 0) new_item();
+    if constexpr (FRONT) { if (nit > 0) fetch_z(cu, zc); }
 
     float actF[BT][4];
     unsigned qF[8][NPF];
@@ -268,8 +292,8 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
     // node position of the current element (the table value of the NEXT element is fetched a step ahead)
     bool live = cu.j < nit;
     bool is_tan = live && ws_is_tan(sh, cu);
-    float tk;
-    {
+    float tk = 0.f;
+    if constexpr (!FRONT) {
         const int k = ws_node(sh, cu);
         const float uu = a.ccs[k] + 1.f;
         tk = (k == 0) ? xv : __fadd_rn(x0v, __fmul_rn(dxv, uu) * 0.5f);
@@ -278,7 +302,17 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         WS_T(t0);
         const WsCursor nx = live ? ws_next(sh, cu) : cu;
         const int kn = ws_node(sh, nx);
-        const float ccs_n = a.ccs[kn];
+        float ccs_n = 0.f;
+        if constexpr (!FRONT) ccs_n = a.ccs[kn];
+        if constexpr (FRONT) {
+            if (live && cu.e == 0) {
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z0[t][r] = zc[t][r];
+            }
+            if (live && nx.j < nit) fetch_z(nx, zn);
+        }
         const unsigned short* A3 = lds16 + WS_OFF_A3 + rA3 + trb;
         const unsigned short* D4 = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + trb;
         unsigned short* const O1 = lds16 + WS_OFF_A1 + rO1 + own;
@@ -300,9 +334,14 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
             constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
             constexpr bool TAN = decltype(tanc)::value;
             if constexpr (e < NLIVE) {
-                const float z = fmaf(w1x[t][r], tk, c[t][r]);
-                if constexpr (TAN) actF[t][r] = w1x[t][r] * (z > 0.f ? 1.f : slope);
-                else actF[t][r] = hidden_act_f(z, slope);
+                if constexpr (FRONT) {
+                    if constexpr (TAN) actF[t][r] = zc[t][r] * (z0[t][r] > 0.f ? 1.f : slope);
+                    else actF[t][r] = hidden_act_f(zc[t][r], slope);
+                } else {
+                    const float z = fmaf(w1x[t][r], tk, c[t][r]);
+                    if constexpr (TAN) actF[t][r] = w1x[t][r] * (z > 0.f ? 1.f : slope);
+                    else actF[t][r] = hidden_act_f(z, slope);
+                }
             }
         };
         auto pairF = [&](auto jc, auto stc) __attribute__((always_inline)) {
@@ -360,8 +399,15 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
             live = cu.j < nit;
             if (crossed && live) new_item();
             is_tan = live && ws_is_tan(sh, cu);
-            const float uu = ccs_n + 1.f;
-            tk = (kn == 0) ? xv : __fadd_rn(x0v, __fmul_rn(dxv, uu) * 0.5f);
+            if constexpr (FRONT) {
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zc[t][r] = zn[t][r];
+            } else {
+                const float uu = ccs_n + 1.f;
+                tk = (kn == 0) ? xv : __fadd_rn(x0v, __fmul_rn(dxv, uu) * 0.5f);
+            }
         }
         ws_adv<WS_NS3, WS_TILE>(rA3); ws_adv<2, WS_TILE>(rD4);
         ws_adv<WS_NS1, WS_TILE>(rO1); ws_adv<2, WS_P3>(rO3);
@@ -372,10 +418,10 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
     WS_TIMING_OUT(S);
-    ws_write_dw(a, part, 3, dW, lane);
+    ws_write_dw(a, part, 3, dW, lane, FRONT && args.accumulate);
 }
 
-template <int NRL>
+template <int NRL, bool FRONT>
 __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
     constexpr int L = 4;
@@ -478,12 +524,12 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
     WS_TIMING_OUT(S);
-    ws_write_dw(a, part, 2, dW2, lane);
-    if constexpr (!UMNN_WS_DW1_IN_B1) ws_write_dw(a, part, 1, dW1, lane);
+    ws_write_dw(a, part, 2, dW2, lane, FRONT && args.accumulate);
+    if constexpr (!UMNN_WS_DW1_IN_B1) ws_write_dw(a, part, 1, dW1, lane, FRONT && args.accumulate);
 }
 
 // ============================================================================================================ waves F1..F3
-template <int NRL, int LAYER>
+template <int NRL, int LAYER, bool FRONT>
 __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
     constexpr int NPAIR = (NLIVE + 1) / 2;
@@ -531,7 +577,7 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
     float fxv = 0.f, fx0v = 0.f, dfdt = 0.f, fp0 = 0.f;
     auto new_item_P = [&]() __attribute__((always_inline)) {
         if constexpr (IS_OUT) {
-            const long long q = (long long)ws_grp(cp) * 16 + p;
+            const long long q = (long long)(args.grp0 + ws_grp(cp)) * 16 + p;
             const bool ok = q < a.NI;
             const long long qq = ok ? q : a.NI - 1;
             xvP = io_ld(a.x, qq, a.x_bf16);
@@ -755,7 +801,7 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
         // ---- item boundary (outside the scheduled region: uniform branch)
         if constexpr (IS_OUT) {
             if (liveP && cp.e == sh.ne - 1) {
-                const long long q = (long long)ws_grp(cp) * 16 + p;
+                const long long q = (long long)(args.grp0 + ws_grp(cp)) * 16 + p;
                 if (q < a.NI && g == 0) {
                     if (a.dx) io_st(a.dx, q, fmaf(gfxvP, dfdt, fxv * gvP), a.x_bf16);
                     if (a.dx0) io_st(a.dx0, q, -fx0v * gvP, a.x_bf16);
@@ -783,14 +829,14 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
                 const int f = feat_of(t, r, g);
                 if (p == 0) {
                     const int idx = f < HL ? a.poffW[L] + f : (f == HL ? a.poffb[L] : -1);
-                    if (idx >= 0) part[idx] = v;
+                    if (idx >= 0) part[idx] = (FRONT && args.accumulate ? part[idx] : 0.f) + v;
                 }
             }
     }
 }
 
 // ============================================================================================================ waves B1..B3
-template <int NRL, int LAYER>
+template <int NRL, int LAYER, bool FRONT>
 __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
     constexpr int DB = 11 - LAYER;                     // element s - DB: W_l^T GEMM, then its vector work, in the same step
@@ -829,8 +875,8 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
     WsCursor cb{0, 0};
     float xvB = 0.f, x0vB = 0.f, dxvB = 0.f;
     auto new_item_B = [&]() __attribute__((always_inline)) {
-        if constexpr (IS_TAIL) {
-            const long long q = (long long)ws_grp(cb) * 16 + p;
+        if constexpr (IS_TAIL && !FRONT) {
+            const long long q = (long long)(args.grp0 + ws_grp(cb)) * 16 + p;
             const long long qq = q < a.NI ? q : a.NI - 1;
             xvB = io_ld(a.x, qq, a.x_bf16);
             x0vB = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
@@ -842,7 +888,7 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
     WS_TIMING_DECL;
     int rAsg = ws_ring0<ws_a_ns(LAYER), WS_TILE>(DB), rDin = ws_ring0<2, WS_TILE>(DB), rDout = ws_ring0<2, WS_TILE>(DB);
     float tkB = 0.f;
-    if constexpr (IS_TAIL) {
+    if constexpr (IS_TAIL && !FRONT) {
         const int kB = ws_node(sh, cb);
         const float uu = a.ccs[kB] + 1.f;
         tkB = (kB == 0) ? xvB : __fadd_rn(x0vB, __fmul_rn(dxvB, uu) * 0.5f);
@@ -856,7 +902,7 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
         if constexpr (IS_TAIL) {
             if (liveB) nxB = ws_next(sh, cb);
             kBn = ws_node(sh, nxB);
-            ccs_n = a.ccs[kBn];
+            if constexpr (!FRONT) ccs_n = a.ccs[kBn];
         }
         const unsigned short* Asg = lds16 + ws_a_off(LAYER) + rAsg + own;                                  // a_l[s - DB]
         const unsigned short* Din = lds16 + WS_OFF_D + (LAYER + 1 - 2) * 2 * WS_TILE + rDin + own;         // delta_{l+1}[s - DB]
@@ -899,7 +945,7 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
             for (int r = 0; r < 4; ++r) {
                 if (4 * t + r < NLIVE) {
                     dl[t][r] = nd[t][r] * act_grad_q(sg, t, r, slope);
-                    if constexpr (IS_TAIL) {
+                    if constexpr (IS_TAIL && !FRONT) {
                         dcs[t][r] += dl[t][r];
                         dW1x[t][r] = fmaf(dl[t][r], tkB, dW1x[t][r]);
                     }
@@ -915,9 +961,22 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
 #pragma unroll
                 for (int k2 = 0; k2 < NPB; ++k2) *reinterpret_cast<u32x4*>(Dout + k2 * 16 * TRS + s2 * 8) = q.v[s2][k2];
         }
-        if constexpr (IS_TAIL) {
+        if constexpr (IS_TAIL && FRONT) {
+            // middle stage: delta_2 = dL/dz_2 of this node goes back to HBM for the front-backward kernel (not for the tangent element)
+            if (liveB && !ws_is_tan(sh, cb)) {
+                const int nl2 = NRL > 0 ? NRL : args.nl2;
+                const size_t base = ((size_t)ws_grp(cb) * (size_t)(a.n + 1) + (size_t)ws_node(sh, cb)) * nl2 * 64 + lane;
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * t + r < NLIVE && 4 * t + r < nl2) args.d2[base + (size_t)(4 * t + r) * 64] = dl[t][r];
+            }
+            if (liveB) cb = nxB;
+        }
+        if constexpr (IS_TAIL && !FRONT) {
             if (liveB && cb.e == sh.ne - 1) {
-                const long long q = (long long)ws_grp(cb) * 16 + p;
+                const long long q = (long long)(args.grp0 + ws_grp(cb)) * 16 + p;
                 if (q < a.NI) {
 #pragma unroll
                     for (int t = 0; t < BT; ++t)
@@ -945,8 +1004,8 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
     WS_TIMING_OUT(S);
-    if constexpr (HAS_DW) ws_write_dw(a, part, 1, dWb, lane);
-    if constexpr (IS_TAIL) {
+    if constexpr (HAS_DW) ws_write_dw(a, part, 1, dWb, lane, FRONT && args.accumulate);
+    if constexpr (IS_TAIL && !FRONT) {
 #pragma unroll
         for (int t = 0; t < BT; ++t)
 #pragma unroll
@@ -963,7 +1022,7 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
 // wave -> role.  Waves w and w + 4 share a SIMD.  Default pairing: Ca + Cb, F1 + B1, F2 + B2, F3 + B3 -- every SIMD gets the same
 // matrix-pipe time (1152 cycles per step); the other pairings measured (UMNN_WS_PAIRING = 1..3) balance instruction counts better
 // and lose 1-2 ms to matrix-pipe contention.
-template <int NRL>
+template <int NRL, bool FRONT = false>
 __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws_kernel(const BwdBf16Args args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
@@ -986,31 +1045,31 @@ __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws_kernel(const BwdBf
     // one d_theta slice per workgroup: every parameter is owned by exactly one of its waves
     float* part = a.partials + (size_t)blockIdx.x * UMNN_WAVES_PER_BLOCK * a.n_params;
     if (!upper) {
-        if (role == 0) ws_role_Ca<NRL>(args, lds16, S, sh, part);
-        else if (role == 1) ws_role_F<NRL, 1>(args, lds16, S, sh, part);
-        else if (role == 2) ws_role_F<NRL, 2>(args, lds16, S, sh, part);
-        else ws_role_F<NRL, 3>(args, lds16, S, sh, part);
+        if (role == 0) ws_role_Ca<NRL, FRONT>(args, lds16, S, sh, part);
+        else if (role == 1) ws_role_F<NRL, 1, FRONT>(args, lds16, S, sh, part);
+        else if (role == 2) ws_role_F<NRL, 2, FRONT>(args, lds16, S, sh, part);
+        else ws_role_F<NRL, 3, FRONT>(args, lds16, S, sh, part);
     } else {
 #if UMNN_WS_PAIRING == 0
-        if (role == 0) ws_role_Cb<NRL>(args, lds16, S, sh, part);
-        else if (role == 1) ws_role_B<NRL, 1>(args, lds16, S, sh, part);
-        else if (role == 2) ws_role_B<NRL, 2>(args, lds16, S, sh, part);
-        else ws_role_B<NRL, 3>(args, lds16, S, sh, part);
+        if (role == 0) ws_role_Cb<NRL, FRONT>(args, lds16, S, sh, part);
+        else if (role == 1) ws_role_B<NRL, 1, FRONT>(args, lds16, S, sh, part);
+        else if (role == 2) ws_role_B<NRL, 2, FRONT>(args, lds16, S, sh, part);
+        else ws_role_B<NRL, 3, FRONT>(args, lds16, S, sh, part);
 #elif UMNN_WS_PAIRING == 1
-        if (role == 0) ws_role_B<NRL, 3>(args, lds16, S, sh, part);
-        else if (role == 1) ws_role_B<NRL, 1>(args, lds16, S, sh, part);
-        else if (role == 2) ws_role_B<NRL, 2>(args, lds16, S, sh, part);
-        else ws_role_Cb<NRL>(args, lds16, S, sh, part);
+        if (role == 0) ws_role_B<NRL, 3, FRONT>(args, lds16, S, sh, part);
+        else if (role == 1) ws_role_B<NRL, 1, FRONT>(args, lds16, S, sh, part);
+        else if (role == 2) ws_role_B<NRL, 2, FRONT>(args, lds16, S, sh, part);
+        else ws_role_Cb<NRL, FRONT>(args, lds16, S, sh, part);
 #elif UMNN_WS_PAIRING == 2
-        if (role == 0) ws_role_B<NRL, 1>(args, lds16, S, sh, part);
-        else if (role == 1) ws_role_B<NRL, 3>(args, lds16, S, sh, part);
-        else if (role == 2) ws_role_B<NRL, 2>(args, lds16, S, sh, part);
-        else ws_role_Cb<NRL>(args, lds16, S, sh, part);
+        if (role == 0) ws_role_B<NRL, 1, FRONT>(args, lds16, S, sh, part);
+        else if (role == 1) ws_role_B<NRL, 3, FRONT>(args, lds16, S, sh, part);
+        else if (role == 2) ws_role_B<NRL, 2, FRONT>(args, lds16, S, sh, part);
+        else ws_role_Cb<NRL, FRONT>(args, lds16, S, sh, part);
 #else
-        if (role == 0) ws_role_B<NRL, 2>(args, lds16, S, sh, part);
-        else if (role == 1) ws_role_B<NRL, 1>(args, lds16, S, sh, part);
-        else if (role == 2) ws_role_Cb<NRL>(args, lds16, S, sh, part);
-        else ws_role_B<NRL, 3>(args, lds16, S, sh, part);
+        if (role == 0) ws_role_B<NRL, 2, FRONT>(args, lds16, S, sh, part);
+        else if (role == 1) ws_role_B<NRL, 1, FRONT>(args, lds16, S, sh, part);
+        else if (role == 2) ws_role_Cb<NRL, FRONT>(args, lds16, S, sh, part);
+        else ws_role_B<NRL, 3, FRONT>(args, lds16, S, sh, part);
 #endif
     }
 }
