@@ -34,11 +34,12 @@
 // waves multiply by act'(a_{l+1}(node 0)) -- the signs of the element before -- instead of applying the activation, F3 turns
 // it into dfdt and a zero cotangent.  Un-split node ranges only (BwdArgs::ns <= 1: large batches).
 //
-// Measured at C3 (8192 x 63, n = 100): 12.9-13.0 ms per launch against 13.4-13.6 for the software-pipelined loop.  Per tile-node
-// both kernels execute ~1420 instructions (here 764 vector + 251 matrix + 120 LDS + 277 scalar; there 792 + 359 + 245 + 33) and
-// their SIMDs issue for the same ~65 % of the time: the gain is the 20 % of matrix work the 32x32 dW tiles save, most of which
-// the scalar bookkeeping of eight cursors and two dozen tile rings gives back.  -DUMNN_WS_TIMING times every role per step;
-// the SIMD that hosts Ca + Cb (377 instructions per step) is the critical one (DESIGN 4.2 has the numbers and the variants).
+// Measured at C3 (8192 x 63, n = 100): 12.9-13.1 ms per launch against 13.4-13.6 for the software-pipelined loop.  Per tile-node
+// 1135 vector + matrix + LDS instructions (there 1396) and 20 % fewer matrix cycles; what that saves is mostly lost to
+// synchronisation: a role wave waits at the step barrier for 28 % of a step on average, and the four long roles (F1, F2, F3, Cb:
+// one per SIMD) sit on the pair's 1152 matrix-pipe cycles plus their un-overlapped vector phases.  The scalar bookkeeping
+// (277 instructions per tile-node) is nearly free (-DUMNN_WS_EXP_NORINGS: 0.9 %).  -DUMNN_WS_TIMING times every role per step;
+// DESIGN 4.2 has the numbers and the fourteen variants that were measured.
 #pragma once
 #include "cc_bwd_swp_kernel.h"
 
@@ -79,6 +80,9 @@ __device__ __forceinline__ WsCursor ws_next(const WsShape& sh, WsCursor c) {
 // ring of LDS tiles: ushort offset of the current tile, advanced once per step (no division in the step loop)
 template <int NS, int STRIDE>
 __device__ __forceinline__ void ws_adv(int& off) {
+#ifdef UMNN_WS_EXP_NORINGS                 // (timing experiment only: every ring stays on its first tile, results wrong)
+    return;
+#endif
     if constexpr (NS == 2) off ^= STRIDE;               // (two-tile rings: one scalar instruction)
     else { off += STRIDE; if (off == NS * STRIDE) off = 0; }
 }
