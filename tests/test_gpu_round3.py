@@ -528,3 +528,39 @@ def test_weight_stationary_middle_stage_of_the_three_stage_backward(hid, with_gf
         # (dh against fp32: the 100-wide first layer at 1.5x weights flips a few more LeakyReLU kinks than the 50-wide nets do, for
         # either bf16x3 kernel alike: 1.1e-3 measured)
         assert U.scaled_err(b_, r_) < (3e-3 if nm == "dh" else 2e-4), (nm, U.scaled_err(b_, r_))
+
+
+def test_weight_stationary_backward_with_relu_hidden_layers(dev):
+    """ReLU hidden layers (slope 0: MonotonicNN's activation) through the workgroup pipeline: the activation derivative is read off
+    the sign of the leading bf16 piece (a clamped negative is -0: not positive), the tangent element multiplies by it."""
+    from umnn_amd import _lib
+    from umnn_amd import integral as I
+    from umnn_amd.nets import MlpSpec
+    rng = np.random.RandomState(5)
+    B, d, E, n = 2100, 8, 6, 11
+    sizes = [1 + E] + [50, 50, 50, 50] + [1]
+    lin = []
+    for i in range(len(sizes) - 1):
+        m = torch.nn.Linear(sizes[i], sizes[i + 1])
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy((rng.randn(sizes[i + 1], sizes[i]) * (1.6 / np.sqrt(sizes[i]))).astype(np.float32)))
+            m.bias.copy_(torch.from_numpy((rng.randn(sizes[i + 1]) * 0.3).astype(np.float32)))
+        lin.append(m.to(dev))
+    spec = MlpSpec(lin, _lib.ACT_RELU, _lib.OUT_ELU_PLUS_ONE)
+    x, x0 = torch.randn(B, d, device=dev) * 2, torch.randn(B, d, device=dev) * 0.3
+    h, gg, gf = torch.randn(B, E * d, device=dev), torch.randn(B, d, device=dev), torch.randn(B, d, device=dev)
+    outs = {}
+    for key, ws, prec in (("swp", 0, "bf16x3"), ("ws", 1, "bf16x3"), ("fp32", 0, "fp32")):
+        _lib.set_backward_precision(prec)
+        try:
+            with _lib.options(bwd_ws=ws):
+                outs[key] = I.hip_backward(spec, x0, x, h, gg, gf, n)
+                name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+                assert (",WS>" in name) == (key == "ws"), name
+        finally:
+            _lib.set_backward_precision("bf16x3")
+    for i, nm in enumerate(("dx0", "dx", "dh", "dtheta")):
+        a_, b_, r_ = (outs[k][i].cpu().numpy() for k in ("swp", "ws", "fp32"))
+        assert np.isfinite(b_).all(), nm
+        assert U.scaled_err(b_, a_) < 5e-6, (nm, U.scaled_err(b_, a_))
+        assert U.scaled_err(b_, r_) < (2e-3 if nm == "dh" else 2e-4), (nm, U.scaled_err(b_, r_))
