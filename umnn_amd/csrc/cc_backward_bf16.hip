@@ -66,8 +66,8 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
 #ifdef UMNN_WS_TIMING
             static double* tbuf = nullptr;
             const int nw = nblocks * WS_WAVES;
-            if (!tbuf) hipMalloc(&tbuf, sizeof(double) * 4 * 8192);
-            hipMemsetAsync(tbuf, 0, sizeof(double) * 4 * nw, stream);
+            if (!tbuf) hipMalloc(&tbuf, sizeof(double) * 6 * 8192);
+            hipMemsetAsync(tbuf, 0, sizeof(double) * 6 * nw, stream);
             args.tz2 = reinterpret_cast<const float*>(tbuf);
 #endif
             umnn_prof_begin(stream);
@@ -76,15 +76,15 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
 #ifdef UMNN_WS_TIMING
             {
                 hipStreamSynchronize(stream);
-                static double host[4 * 8192];
-                hipMemcpy(host, tbuf, sizeof(double) * 4 * nw, hipMemcpyDeviceToHost);
+                static double host[6 * 8192];
+                hipMemcpy(host, tbuf, sizeof(double) * 6 * nw, hipMemcpyDeviceToHost);
                 const char* role[8] = {"Ca", "F1", "F2", "F3", UMNN_WS_PAIRING ? "B3" : "Cb", "B1", "B2", UMNN_WS_PAIRING ? "Cb" : "B3"};
                 for (int r = 0; r < WS_WAVES; ++r) {
-                    double sm[4] = {0};
-                    for (int w = r; w < nw; w += WS_WAVES) for (int j = 0; j < 4; ++j) sm[j] += host[4 * w + j];
-                    const double st = sm[3] > 0 ? sm[3] : 1;
-                    fprintf(stderr, "WS_TIMING %s per step (s_memtime ticks): prep %.0f | work %.0f | barrier wait %.0f   (steps per wave %.0f)\n",
-                            role[r], sm[0] / st, sm[1] / st, sm[2] / st, sm[3] / (nw / WS_WAVES));
+                    double sm[6] = {0};
+                    for (int w = r; w < nw; w += WS_WAVES) for (int j = 0; j < 6; ++j) sm[j] += host[6 * w + j];
+                    const double st = sm[4] > 0 ? sm[4] : 1;
+                    fprintf(stderr, "WS_TIMING %s per step (s_memtime ticks): prep %.0f | work to the %d %% mark %.0f | rest of the work %.0f | barrier wait %.0f   (steps per wave %.0f)\n",
+                            role[r], sm[0] / st, UMNN_WS_TRACE_FRAC, sm[1] / st, sm[2] / st, sm[3] / st, sm[4] / (nw / WS_WAVES));
                 }
             }
 #endif

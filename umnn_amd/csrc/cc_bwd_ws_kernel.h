@@ -94,6 +94,8 @@ __host__ __device__ constexpr int ws_ring0(int delay) { return ((WS_BIAS - delay
 #else
 #define WS_VGPR_HINT(x) (void)0
 #endif
+// companion work spread over a matrix loop: micro-operation i rides behind slot (3 i) / 2 (two of every three slots carry one)
+__host__ __device__ constexpr int ws_op_of_slot(int nn) { return ((((2 * nn + 2) / 3) * 3) / 2 == nn) ? (2 * nn + 2) / 3 : -1; }
 typedef float ws_f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ ws_f32x16 ws_mfma32(u32x4 a, u32x4 b, ws_f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -105,6 +107,9 @@ __device__ __forceinline__ u32x2 ws_tr_read(const unsigned short* src) {
 #ifndef UMNN_WS_PAIRING
 #define UMNN_WS_PAIRING 0
 #endif
+#ifndef UMNN_WS_SPREAD
+#define UMNN_WS_SPREAD 1             // companion vector work spread evenly over the matrix loops (0: front-loaded, the first schedule)
+#endif
 #ifndef UMNN_WS_DW1_IN_B1
 #define UMNN_WS_DW1_IN_B1 0         // dW_1 accumulated by wave B1 (1) or Cb (0): balances the instruction count of the SIMDs
 #endif
@@ -112,15 +117,25 @@ __device__ __forceinline__ u32x2 ws_tr_read(const unsigned short* src) {
 #define UMNN_WS_D4_IN_CA 0          // delta_4 = dout w_out act'(a_4) formed by wave Ca (1) or Cb (0)
 #endif
 #ifdef UMNN_WS_TIMING
+// per-role cycle sums (s_memtime): prep = operand fetches issued and waited for, work = the role's step (cut in two at slot
+// UMNN_WS_TRACE_FRAC percent of its matrix loop when that is defined: one more sample per step, a different build per cut), wait =
+// the step barrier
+#ifndef UMNN_WS_TRACE_FRAC
+#define UMNN_WS_TRACE_FRAC 50
+#endif
 #define WS_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define WS_TIMING_DECL unsigned long long tt[3] = {0, 0, 0}
-#define WS_TIMING_ACC(t0, t1, t2, t3) do { tt[0] += (t1) - (t0); tt[1] += (t2) - (t1); tt[2] += (t3) - (t2); } while (0)
+#define WS_TIMING_DECL unsigned long long tt[4] = {0, 0, 0, 0}, tmark = 0
+#define WS_MARK(nn, nslots) do { if constexpr ((nn) == ((nslots) * UMNN_WS_TRACE_FRAC) / 100) tmark = __builtin_amdgcn_s_memtime(); } while (0)
+#define WS_MARK_HERE() do { tmark = __builtin_amdgcn_s_memtime(); } while (0)
+#define WS_TIMING_ACC(t0, t1, t2, t3) do { tt[0] += (t1) - (t0); tt[1] += tmark - (t1); tt[2] += (t2) - tmark; tt[3] += (t3) - (t2); } while (0)
 #define WS_TIMING_OUT(S) do { if (args.tz2 && (threadIdx.x & 63) == 0) { \
-        double* o = reinterpret_cast<double*>(const_cast<float*>(args.tz2)) + ((size_t)blockIdx.x * WS_WAVES + (threadIdx.x >> 6)) * 4; \
-        o[0] = (double)tt[0]; o[1] = (double)tt[1]; o[2] = (double)tt[2]; o[3] = (double)(S); } } while (0)
+        double* o = reinterpret_cast<double*>(const_cast<float*>(args.tz2)) + ((size_t)blockIdx.x * WS_WAVES + (threadIdx.x >> 6)) * 6; \
+        o[0] = (double)tt[0]; o[1] = (double)tt[1]; o[2] = (double)tt[2]; o[3] = (double)tt[3]; o[4] = (double)(S); o[5] = 0.0; } } while (0)
 #else
 #define WS_T(var) (void)0
 #define WS_TIMING_DECL (void)0
+#define WS_MARK(nn, nslots) (void)0
+#define WS_MARK_HERE() (void)0
 #define WS_TIMING_ACC(t0, t1, t2, t3) (void)0
 #define WS_TIMING_OUT(S) (void)0
 #endif
@@ -369,6 +384,7 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         __builtin_amdgcn_sched_barrier(0);
         swp_static_for<12>([&](auto nc) {
             constexpr int nn = decltype(nc)::value;
+            WS_MARK(nn, 12);
             ws_dw_mfma<nn>(dW, ops);
             // the split of a_1: two pairs per slot, stage by stage; then the stores
             if constexpr (nn < 4) { pairF(std::integral_constant<int, 2 * nn>{}, std::integral_constant<int, 0>{}); pairF(std::integral_constant<int, 2 * nn + 1>{}, std::integral_constant<int, 0>{}); }
@@ -504,6 +520,7 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
         WS_T(t1);
         swp_static_for<UMNN_WS_DW1_IN_B1 ? 12 : 24>([&](auto nc) {
             constexpr int nn = decltype(nc)::value;
+            WS_MARK(nn, (UMNN_WS_DW1_IN_B1 ? 12 : 24));
 #ifndef UMNN_WS_EXP_NOMFMA_CB           // (timing experiments only: wrong results)
             if constexpr (nn < 12) ws_dw_mfma<nn>(dW2, o2);
             else ws_dw_mfma<nn - 12>(dW1, o1);
@@ -511,11 +528,20 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
             if constexpr (nn < 8 && !UMNN_WS_DW1_IN_B1) ws_load_op<nn>(o1, D2, A1);
             // delta_4: two registers per slot, pair j split at slots j + 1 / j + 2, K-steps stored at 6, 7 / 10, 11
 #if !UMNN_WS_D4_IN_CA && !defined(UMNN_WS_EXP_NOD4_CB)
+#if UMNN_WS_SPREAD && !UMNN_WS_DW1_IN_B1
+            // one register per slot, pair j split at slots 2j + 2 / 2j + 3, K-steps stored at 10, 11 / 18, 19 (spread over the 24 slots)
+            if constexpr (nn < 16) d4_reg(std::integral_constant<int, nn>{});
+            if constexpr (nn >= 2 && nn < 18 && (nn % 2) == 0) pair4(std::integral_constant<int, (nn - 2) / 2>{}, std::integral_constant<int, 0>{});
+            if constexpr (nn >= 3 && nn < 19 && (nn % 2) == 1) pair4(std::integral_constant<int, (nn - 3) / 2>{}, std::integral_constant<int, 1>{});
+            if constexpr (nn == 10 || nn == 11) store_d4(std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 10>{});
+            if constexpr (nn == 18 || nn == 19) store_d4(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 18>{});
+#else
             if constexpr (nn < 8) { d4_reg(std::integral_constant<int, 2 * nn>{}); d4_reg(std::integral_constant<int, 2 * nn + 1>{}); }
             if constexpr (nn >= 1 && nn < 9) pair4(std::integral_constant<int, nn - 1>{}, std::integral_constant<int, 0>{});
             if constexpr (nn >= 2 && nn < 10) pair4(std::integral_constant<int, nn - 2>{}, std::integral_constant<int, 1>{});
             if constexpr (nn == 6 || nn == 7) store_d4(std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 6>{});
             if constexpr (nn == 10 || nn == 11) store_d4(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 10>{});
+#endif
 #endif
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -758,6 +784,7 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             swp_static_for<48>([&](auto nc) {
                 constexpr int nn = decltype(nc)::value;
+                WS_MARK(nn, 48);
 #if UMNN_WS_ACC8
                 // (groups of four tiles alternate between the K-steps: a chain's next link is eight instructions away)
                 constexpr int s2 = (nn / 4) & 1, idx = 4 * (nn / 8) + (nn % 4);
@@ -784,12 +811,24 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
 #endif
 #ifndef UMNN_WS_EXP_NOVALU_F
                 if constexpr (!IS_OUT) {
+#if UMNN_WS_SPREAD
+                    // the split of a_{l+1} spread over the whole loop (measured: front-loaded companions made the first twelve
+                    // slots take 56 cycles each, the bare ones at the end 17): 30 micro-operations, one behind two of every three
+                    // slots -- per K-step the four pairs stage by stage, then its three stores
+                    constexpr int op = ws_op_of_slot(nn);
+                    if constexpr (op >= 0 && op < 30) {
+                        constexpr int ks = op / 15, w = op % 15;
+                        if constexpr (w < 12) pairF(std::integral_constant<int, 4 * ks + w % 4>{}, std::integral_constant<int, w / 4>{});
+                        else store_a(std::integral_constant<int, ks>{}, std::integral_constant<int, w - 12>{});
+                    }
+#else
                     // pair j: rounding stages at slots 3j, 3j + 1, 3j + 2; K-step 0 stored at 12..14, K-step 1 at 24..26
                     if constexpr (nn < 24 && (nn % 3) == 0) pairF(std::integral_constant<int, nn / 3>{}, std::integral_constant<int, 0>{});
                     if constexpr (nn < 24 && (nn % 3) == 1) pairF(std::integral_constant<int, nn / 3>{}, std::integral_constant<int, 1>{});
                     if constexpr (nn < 24 && (nn % 3) == 2) pairF(std::integral_constant<int, nn / 3>{}, std::integral_constant<int, 2>{});
                     if constexpr (nn >= 12 && nn < 15) store_a(std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 12>{});
                     if constexpr (nn >= 24 && nn < 27) store_a(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 24>{});
+#endif
                 } else {
                     // the leading piece of a_L does not wait for the scalar chain; dout and d w_out follow it
                     if constexpr (nn < 8) out_scalar(std::integral_constant<int, nn>{});
@@ -940,6 +979,7 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
                 for (int t = 0; t < BT; ++t) nd[t] = mfma_bf16(WT[t][s2][1], bd.v[s2][0], nd[t]);
             }
         }
+        WS_MARK_HERE();                                   // (B waves: the cut is always after the GEMM)
         if constexpr (HAS_DW) swp_static_for<12>([&](auto nc) { ws_dw_mfma<decltype(nc)::value>(dWb, ob); });
         // ---- delta_l = (W_l^T delta_{l+1}) . act'(a_l); B1: the tail of the node; B2, B3: split and store for the wave below
         f32x4 dl[BT];
