@@ -39,7 +39,7 @@
 // synchronisation: a role wave waits at the step barrier for 28 % of a step on average, and the four long roles (F1, F2, F3, Cb:
 // one per SIMD) sit on the pair's 1152 matrix-pipe cycles plus their un-overlapped vector phases.  The scalar bookkeeping
 // (277 instructions per tile-node) is nearly free (-DUMNN_WS_EXP_NORINGS: 0.9 %).  -DUMNN_WS_TIMING times every role per step;
-// DESIGN 4.2 has the numbers and the fourteen variants that were measured.
+// DESIGN 4.2 has the numbers and the variants that were measured.
 #pragma once
 #include "cc_bwd_swp_kernel.h"
 
@@ -112,6 +112,9 @@ __device__ __forceinline__ u32x2 ws_tr_read(const unsigned short* src) {
 #endif
 #ifndef UMNN_WS_DW1_IN_B1
 #define UMNN_WS_DW1_IN_B1 0         // dW_1 accumulated by wave B1 (1) or Cb (0): balances the instruction count of the SIMDs
+#endif
+#ifndef UMNN_WS_C_SPLIT
+#define UMNN_WS_C_SPLIT 0            // 1: Ca = all the vector work of the C roles (layer 1, delta_4), Cb = all three dW products (needs UMNN_WS_D4_IN_CA = 1)
 #endif
 #ifndef UMNN_WS_D4_IN_CA
 #define UMNN_WS_D4_IN_CA 0          // delta_4 = dout w_out act'(a_4) formed by wave Ca (1) or Cb (0)
@@ -345,9 +348,13 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         const float dout4 = *reinterpret_cast<const float*>(S4 + p * TRS + 64);
 #endif
         WsOps ops;
+#if !UMNN_WS_C_SPLIT
         // operands of dW_3 (A hi, B hi, B lo, A lo); then the layer-1 activations (registers only) while those fetches fly
         ws_load_op<0>(ops, D4, A3); ws_load_op<2>(ops, D4, A3); ws_load_op<4>(ops, D4, A3); ws_load_op<6>(ops, D4, A3);
         ws_load_op<5>(ops, D4, A3); ws_load_op<7>(ops, D4, A3); ws_load_op<1>(ops, D4, A3); ws_load_op<3>(ops, D4, A3);
+#else
+        (void)ops; (void)D4; (void)A3;
+#endif
         // layer 1 of element s (tangent element: w1 . act'(z_1) of node 0)
         auto layer1_reg = [&](auto ec, auto tanc) __attribute__((always_inline)) {
             constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
@@ -385,7 +392,9 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         swp_static_for<12>([&](auto nc) {
             constexpr int nn = decltype(nc)::value;
             WS_MARK(nn, 12);
+#if !UMNN_WS_C_SPLIT
             ws_dw_mfma<nn>(dW, ops);
+#endif
             // the split of a_1: two pairs per slot, stage by stage; then the stores
             if constexpr (nn < 4) { pairF(std::integral_constant<int, 2 * nn>{}, std::integral_constant<int, 0>{}); pairF(std::integral_constant<int, 2 * nn + 1>{}, std::integral_constant<int, 0>{}); }
             if constexpr (nn >= 1 && nn < 5) { pairF(std::integral_constant<int, 2 * (nn - 1)>{}, std::integral_constant<int, 1>{}); pairF(std::integral_constant<int, 2 * (nn - 1) + 1>{}, std::integral_constant<int, 1>{}); }
@@ -438,7 +447,9 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
     WS_TIMING_OUT(S);
+#if !UMNN_WS_C_SPLIT
     ws_write_dw(a, part, 3, dW, lane, FRONT && args.accumulate);
+#endif
 }
 
 template <int NRL, bool FRONT>
@@ -480,6 +491,14 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
     int rA2 = ws_ring0<WS_NS2, WS_TILE>(9), rA1 = ws_ring0<WS_NS1, WS_TILE>(10);
     int rD3 = ws_ring0<2, WS_TILE>(9), rD2 = ws_ring0<2, WS_TILE>(10);
     int rS4 = ws_ring0<2, WS_P3>(7), rD4 = ws_ring0<2, WS_TILE>(7);
+    int rA3c = ws_ring0<WS_NS3, WS_TILE>(8), rD4c = ws_ring0<2, WS_TILE>(8);
+    ws_f32x16 dW3[2][2];
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) dW3[to][ti][v] = 0.f;
     for (int s = 0; s < S; ++s) {
         WS_T(t0);
         // delta_4 of element s - 7 from what F3 left a step ago: delta_L = dout w_out act'(a_L), split, stored for B3 and Ca --
@@ -498,8 +517,22 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
         const unsigned short* D3 = lds16 + WS_OFF_D + 2 * WS_TILE + rD3 + trb;
         const unsigned short* D2 = lds16 + WS_OFF_D + 0 * WS_TILE + rD2 + trb;
         WsOps o2, o1;
+#if UMNN_WS_C_SPLIT
+        // all three dW products here: operands of dW_3 first (o1's registers: dW_1's operands replace them during dW_2)
+        const unsigned short* A3c = lds16 + WS_OFF_A3 + rA3c + trb;
+        const unsigned short* D4c = lds16 + WS_OFF_D + 4 * WS_TILE + rD4c + trb;
+        ws_load_op<0>(o1, D4c, A3c); ws_load_op<2>(o1, D4c, A3c); ws_load_op<4>(o1, D4c, A3c); ws_load_op<6>(o1, D4c, A3c);
+        ws_load_op<5>(o1, D4c, A3c); ws_load_op<7>(o1, D4c, A3c); ws_load_op<1>(o1, D4c, A3c); ws_load_op<3>(o1, D4c, A3c);
+        swp_static_for<12>([&](auto nc) {
+            constexpr int nn = decltype(nc)::value;
+            ws_dw_mfma<nn>(dW3, o1);
+            if constexpr (nn < 8) ws_load_op<nn>(o2, D3, A2);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#else
         ws_load_op<0>(o2, D3, A2); ws_load_op<2>(o2, D3, A2); ws_load_op<4>(o2, D3, A2); ws_load_op<6>(o2, D3, A2);
         ws_load_op<5>(o2, D3, A2); ws_load_op<7>(o2, D3, A2); ws_load_op<1>(o2, D3, A2); ws_load_op<3>(o2, D3, A2);
+#endif
         float d4[BT][4];
         auto d4_reg = [&](auto ec) __attribute__((always_inline)) {
             constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
@@ -548,12 +581,16 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
         ws_adv<WS_NS2, WS_TILE>(rA2); ws_adv<WS_NS1, WS_TILE>(rA1);
         ws_adv<2, WS_TILE>(rD3); ws_adv<2, WS_TILE>(rD2);
         ws_adv<2, WS_P3>(rS4); ws_adv<2, WS_TILE>(rD4);
+        ws_adv<WS_NS3, WS_TILE>(rA3c); ws_adv<2, WS_TILE>(rD4c);
         WS_T(t2);
         __syncthreads();
         WS_T(t3);
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
     WS_TIMING_OUT(S);
+#if UMNN_WS_C_SPLIT
+    ws_write_dw(a, part, 3, dW3, lane, FRONT && args.accumulate);
+#endif
     ws_write_dw(a, part, 2, dW2, lane, FRONT && args.accumulate);
     if constexpr (!UMNN_WS_DW1_IN_B1) ws_write_dw(a, part, 1, dW1, lane, FRONT && args.accumulate);
 }
