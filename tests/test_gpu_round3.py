@@ -547,6 +547,10 @@ def test_weight_stationary_backward_with_relu_hidden_layers(dev):
             m.bias.copy_(torch.from_numpy((rng.randn(sizes[i + 1]) * 0.3).astype(np.float32)))
         lin.append(m.to(dev))
     spec = MlpSpec(lin, _lib.ACT_RELU, _lib.OUT_ELU_PLUS_ONE)
+    # (seeded: with slope 0 a pre-activation within rounding of zero switches a whole path on or off, so ANY two arithmetics --
+    # the bf16x3 kernels against fp32 included -- can differ by 1e-3..1e-2 on single entries for an unlucky draw; tools/_relu_loop.py
+    # sweeps 40 seeds: the two bf16x3 kernels agree to 3e-6 on every one of them, and differ from fp32 identically)
+    torch.manual_seed(1)
     x, x0 = torch.randn(B, d, device=dev) * 2, torch.randn(B, d, device=dev) * 0.3
     h, gg, gf = torch.randn(B, E * d, device=dev), torch.randn(B, d, device=dev), torch.randn(B, d, device=dev)
     outs = {}
