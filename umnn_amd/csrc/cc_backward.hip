@@ -400,6 +400,57 @@ __global__ __launch_bounds__(256) void cc_bwd_dh_kernel(const float* __restrict_
     }
 }
 
+// The same product on the fp32 matrix cores (large batches): d_h^T[e][q] = sum_f W1[f][1+e] dc[q][f] as D[e][q] += A[e][f] B[f][q]
+// with v_mfma_f32_16x16x4_f32.  A wave owns 16 integrals at a time: B operands are its dc rows straight from HBM (lane (g, p):
+// integral q0 + p, feature 4 ks + g -- the four lane groups of a row read 16 contiguous bytes), A operands come from a [ks][te][lane]
+// image of W1[:, 1:]^T in LDS (one conflict-free ds_read_b32 per MFMA), the result tile (lane (g, p): integral p, embedding columns
+// 16 te + 4 g + r) is stored with 64-byte runs along the integrals.  The first version above reads two LDS words per FMA and sat
+// at 1.6 TB/s of dc + d_h traffic (101 us per C3 call against 165 MB); this one is bound by that stream.
+__global__ __launch_bounds__(256) void cc_bwd_dh_mfma_kernel(const float* __restrict__ dc, const float* __restrict__ W0,
+                                                             float* __restrict__ dh, long long NI, int d, int E, int H1, int h_bf16) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int KS = (H1 + 3) / 4, TE = (E + 15) / 16;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, p = lane & 15;
+    for (int i = tid; i < KS * TE * 64; i += 256) {
+        const int ln = i & 63, te = (i >> 6) % TE, ks = (i >> 6) / TE;
+        const int e = 16 * te + (ln & 15), f = 4 * ks + (ln >> 4);
+        sm[i] = (e < E && f < H1) ? W0[f * (1 + E) + 1 + e] : 0.f;
+    }
+    __syncthreads();
+    const long long ngroups = (NI + 15) / 16;
+    const long long wave = (long long)blockIdx.x * 4 + (tid >> 6), nwaves = (long long)gridDim.x * 4;
+    for (long long grp = wave; grp < ngroups; grp += nwaves) {
+        const long long q = grp * 16 + p;
+        const bool ok = q < NI;
+        const float* __restrict__ row = dc + (ok ? q : NI - 1) * H1;
+        f32x4 acc[5];
+#pragma unroll
+        for (int te = 0; te < 5; ++te) acc[te] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float bnext = g < H1 ? row[g] : 0.f;
+        for (int ks = 0; ks < KS; ++ks) {
+            const float bv = bnext;
+            const int fn = 4 * (ks + 1) + g;
+            bnext = (ks + 1 < KS && fn < H1) ? row[fn] : 0.f;
+#pragma unroll
+            for (int te = 0; te < 5; ++te)
+                if (te < TE) acc[te] = mfma16(sm[(ks * TE + te) * 64 + lane], bv, acc[te]);
+        }
+        if (ok) {
+            const long long bi = q / d;
+            const long long base = bi * ((long long)E * d) + (q - bi * d);
+#pragma unroll
+            for (int te = 0; te < 5; ++te)
+                if (te < TE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = 16 * te + 4 * g + r;
+                        if (e < E) io_st(dh, base + (long long)e * d, acc[te][r], h_bf16);
+                    }
+                }
+        }
+    }
+}
+
 // node-split runs: dc[0][i] += dc[1][i] + ... + dc[ns-1][i], in that order (deterministic)
 __global__ __launch_bounds__(256) void cc_bwd_dcsum_kernel(float* __restrict__ dc, long long count, int ns) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -798,12 +849,22 @@ extern "C" int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const
         hipLaunchKernelGGL(cc_bwd_dcsum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, a.dc, count, ns_used);
     }
     if (dh) {
+        const long long groups = (a.NI + 15) / 16;
+        if (E <= 80 && groups >= 8LL * umnn_num_cus()) {              // large batches: the matrix-core version (persistent waves)
+            const size_t sm = (size_t)((H1 + 3) / 4) * ((E + 15) / 16) * 64 * sizeof(float);
+            const long long want = (groups + 3) / 4, cap = 8LL * umnn_num_cus();
+            const unsigned nb = (unsigned)(want < cap ? want : cap);
+            if (int rc = umnn_allow_lds((const void*)cc_bwd_dh_mfma_kernel, sm)) return rc;
+            hipLaunchKernelGGL(cc_bwd_dh_mfma_kernel, dim3(nb), dim3(256), sm, stream, a.dc, net->W[0], dh, a.NI, d, E, H1, a.h_bf16);
+            umnn_note_launch("cc_bwd_dh<mfma>");
+        } else {
         const int qpb = a.NI / 64 < 2LL * umnn_num_cus() ? 16 : 64;      // integrals per workgroup
         const size_t sm = ((size_t)H1 * E + qpb * (H1 + 1)) * sizeof(float);
         const unsigned nb = (unsigned)((a.NI + qpb - 1) / qpb);
         if (int rc = umnn_allow_lds((const void*)cc_bwd_dh_kernel, sm)) return rc;
         hipLaunchKernelGGL(cc_bwd_dh_kernel, dim3(nb), dim3(256), sm, stream, a.dc, net->W[0], dh, a.NI, d, E, H1, qpb, a.h_bf16);
         umnn_note_launch("cc_bwd_dh");
+        }
     }
     if (dtheta) {
         const size_t sm = dw0_lds_floats(pl.chunk0, H1, E) * sizeof(float);
