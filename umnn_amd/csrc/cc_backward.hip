@@ -814,10 +814,11 @@ extern "C" int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const
         else if (rc != UMNN_EUNSUPPORTED) return rc;
         else a.ns = ns_used;
     }
+    int nslices = pl.nwaves;              // d_theta slices the main pass wrote (the reduction reads no more than that)
     if (!done && umnn_options().bwd_precision == UMNN_PRECISION_BF16X3) {
         int nw = 0;
         const int rc = umnn_launch_backward_bf16(a, net, pl.nblocks, &nw, stream);
-        if (rc == 0) done = true;
+        if (rc == 0) { done = true; if (nw > 0 && nw < nslices) nslices = nw; }
         else if (rc != UMNN_EUNSUPPORTED) return rc;
     }
     // ---- passes: the EDGE pass (with as many dW layers as its variant holds), then the remaining layers
@@ -875,7 +876,7 @@ extern "C" int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const
         for (int tb = 0; tb < 4 * tiles_per_wave; tb += per_launch)
             hipLaunchKernelGGL(dw0, dim3(pl.nparts0), dim3(256), sm, stream, a.dc, h, p0, a.NI, d, E, H1, pl.chunk0, a.h_bf16, tb);
         hipLaunchKernelGGL(cc_bwd_reduce_kernel, dim3((a.n_params + 31) / 32), dim3(256), 0, stream,
-                           a.partials, pl.nwaves, a.n_params, p0, pl.nparts0, E, H1, a.poffW[0], a.poffb[0], dtheta);
+                           a.partials, nslices, a.n_params, p0, pl.nparts0, E, H1, a.poffW[0], a.poffb[0], dtheta);
         umnn_note_launch("cc_bwd_reduce");
     }
     umnn_prof_end(stream, 0.0, UMNN_PROF_FINISH);

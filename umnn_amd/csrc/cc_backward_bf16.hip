@@ -60,7 +60,7 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
         if (wv && a.ns <= 1 && items >= 4LL * nblocks_max) {
             const size_t lds_ws = (size_t)WS_LDS_USHORTS * sizeof(unsigned short);
             const int nblocks = nblocks_max;
-            *nwaves_out = nblocks * UMNN_WAVES_PER_BLOCK;
+            *nwaves_out = nblocks;                  // one d_theta slice per workgroup
             a.l_lo = 1;
             if (int rc = umnn_allow_lds((const void*)wv->fn, lds_ws)) return rc;
 #ifdef UMNN_WS_TIMING

@@ -1123,8 +1123,10 @@ __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws_kernel(const BwdBf
     sh.ne = a.n + 1 + sh.tan0;
     sh.nit = blockIdx.x < a.ngroups ? (int)((a.ngroups - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
     const int S = sh.nit * sh.ne + WS_DEPTH;
-    // one d_theta slice per workgroup: every parameter is owned by exactly one of its waves
-    float* part = a.partials + (size_t)blockIdx.x * UMNN_WAVES_PER_BLOCK * a.n_params;
+    // one d_theta slice per workgroup: every parameter is owned by exactly one of its waves.  One-pass launches use slices
+    // 0 .. gridDim.x - 1 (the reduction then reads a quarter of what the four-slices-per-workgroup kernels make it read); as the
+    // middle stage of the three-stage backward the slice is the first of the workgroup's four (the front kernels use all four)
+    float* part = a.partials + (size_t)blockIdx.x * (FRONT ? UMNN_WAVES_PER_BLOCK : 1) * a.n_params;
     if (!upper) {
         if (role == 0) ws_role_Ca<NRL, FRONT>(args, lds16, S, sh, part);
         else if (role == 1) ws_role_F<NRL, 1, FRONT>(args, lds16, S, sh, part);
