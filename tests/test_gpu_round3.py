@@ -396,6 +396,8 @@ def test_software_pipelined_backward_agrees_with_the_round2_loop(shape, with_gfx
     (2100, 8, 10, [50] * 4, 15, False, "Sigmoid", torch.float32, torch.float32, False),
     (1100, 16, 6, [50] * 4, 7, True, "ELU", torch.bfloat16, torch.bfloat16, False),
     (1030, 16, 5, [50] * 4, 9, True, "ELU", torch.float32, torch.float32, True),
+    (300, 63, 30, [50] * 4, 1, True, "ELU", torch.float32, torch.float32, False),      # fewer elements per tile than pipeline stages
+    (300, 63, 30, [50] * 4, 2, False, "ELU", torch.float32, torch.float32, False),
 ])
 def test_weight_stationary_backward_agrees_with_the_pipelined_loop_and_fp32(case, dev):
     """cc_bwd_ws_kernel (eight role waves per workgroup: the weights of one layer resident in each GEMM wave's registers,
