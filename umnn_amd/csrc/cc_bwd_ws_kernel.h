@@ -107,6 +107,9 @@ __device__ __forceinline__ u32x2 ws_tr_read(const unsigned short* src) {
 #ifndef UMNN_WS_PAIRING
 #define UMNN_WS_PAIRING 0
 #endif
+#ifndef UMNN_WS_PREFETCH_B
+#define UMNN_WS_PREFETCH_B 1         // the a_l operands of the dW products (written steps ago) are fetched BEFORE the step barrier
+#endif
 #ifndef UMNN_WS_SPREAD
 #define UMNN_WS_SPREAD 1             // companion vector work spread evenly over the matrix loops (0: front-loaded, the first schedule)
 #endif
@@ -320,6 +323,13 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         const float uu = a.ccs[k] + 1.f;
         tk = (k == 0) ? xv : __fadd_rn(x0v, __fmul_rn(dxv, uu) * 0.5f);
     }
+    WsOps ops;
+#if !UMNN_WS_C_SPLIT && UMNN_WS_PREFETCH_B
+    {
+        const unsigned short* A3n = lds16 + WS_OFF_A3 + rA3 + trb;
+        ws_load_op<4>(ops, A3n, A3n); ws_load_op<6>(ops, A3n, A3n); ws_load_op<5>(ops, A3n, A3n); ws_load_op<7>(ops, A3n, A3n);
+    }
+#endif
     for (int s = 0; s < S; ++s) {
         WS_T(t0);
         const WsCursor nx = live ? ws_next(sh, cu) : cu;
@@ -347,8 +357,10 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         for (int s2 = 0; s2 < BKS; ++s2) sg4[s2] = *reinterpret_cast<const u32x4*>(S4 + own + s2 * 8);
         const float dout4 = *reinterpret_cast<const float*>(S4 + p * TRS + 64);
 #endif
-        WsOps ops;
-#if !UMNN_WS_C_SPLIT
+#if !UMNN_WS_C_SPLIT && UMNN_WS_PREFETCH_B
+        // operands of dW_3: the a_3 half came in before the barrier, the delta_4 half (written last step) here
+        ws_load_op<0>(ops, D4, A3); ws_load_op<2>(ops, D4, A3); ws_load_op<1>(ops, D4, A3); ws_load_op<3>(ops, D4, A3);
+#elif !UMNN_WS_C_SPLIT
         // operands of dW_3 (A hi, B hi, B lo, A lo); then the layer-1 activations (registers only) while those fetches fly
         ws_load_op<0>(ops, D4, A3); ws_load_op<2>(ops, D4, A3); ws_load_op<4>(ops, D4, A3); ws_load_op<6>(ops, D4, A3);
         ws_load_op<5>(ops, D4, A3); ws_load_op<7>(ops, D4, A3); ws_load_op<1>(ops, D4, A3); ws_load_op<3>(ops, D4, A3);
@@ -440,6 +452,12 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         }
         ws_adv<WS_NS3, WS_TILE>(rA3); ws_adv<2, WS_TILE>(rD4);
         ws_adv<WS_NS1, WS_TILE>(rO1); ws_adv<2, WS_P3>(rO3);
+#if !UMNN_WS_C_SPLIT && UMNN_WS_PREFETCH_B
+        {   // next step's a_3 operand of dW_3 (a tile written four steps ago)
+            const unsigned short* A3n = lds16 + WS_OFF_A3 + rA3 + trb;
+            ws_load_op<4>(ops, A3n, A3n); ws_load_op<6>(ops, A3n, A3n); ws_load_op<5>(ops, A3n, A3n); ws_load_op<7>(ops, A3n, A3n);
+        }
+#endif
         ws_adv<2, WS_P3>(rS4); ws_adv<2, WS_TILE>(rD4w);
         WS_T(t2);
         __syncthreads();
@@ -492,6 +510,15 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
     int rD3 = ws_ring0<2, WS_TILE>(9), rD2 = ws_ring0<2, WS_TILE>(10);
     int rS4 = ws_ring0<2, WS_P3>(7), rD4 = ws_ring0<2, WS_TILE>(7);
     int rA3c = ws_ring0<WS_NS3, WS_TILE>(8), rD4c = ws_ring0<2, WS_TILE>(8);
+    WsOps o2, o1;
+#if UMNN_WS_PREFETCH_B && !UMNN_WS_C_SPLIT
+    {   // (first step: the tiles are still zero)
+        const unsigned short* A2n = lds16 + WS_OFF_A2 + rA2 + trb;
+        const unsigned short* A1n = lds16 + WS_OFF_A1 + rA1 + trb;
+        ws_load_op<4>(o2, A2n, A2n); ws_load_op<6>(o2, A2n, A2n); ws_load_op<5>(o2, A2n, A2n); ws_load_op<7>(o2, A2n, A2n);
+        ws_load_op<4>(o1, A1n, A1n); ws_load_op<6>(o1, A1n, A1n); ws_load_op<5>(o1, A1n, A1n); ws_load_op<7>(o1, A1n, A1n);
+    }
+#endif
     ws_f32x16 dW3[2][2];
 #pragma unroll
     for (int to = 0; to < 2; ++to)
@@ -516,7 +543,6 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
         const unsigned short* A1 = lds16 + WS_OFF_A1 + rA1 + trb;
         const unsigned short* D3 = lds16 + WS_OFF_D + 2 * WS_TILE + rD3 + trb;
         const unsigned short* D2 = lds16 + WS_OFF_D + 0 * WS_TILE + rD2 + trb;
-        WsOps o2, o1;
 #if UMNN_WS_C_SPLIT
         // all three dW products here: operands of dW_3 first (o1's registers: dW_1's operands replace them during dW_2)
         const unsigned short* A3c = lds16 + WS_OFF_A3 + rA3c + trb;
@@ -529,6 +555,9 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
             if constexpr (nn < 8) ws_load_op<nn>(o2, D3, A2);
             __builtin_amdgcn_sched_barrier(0);
         });
+#elif UMNN_WS_PREFETCH_B
+        // (the a_2 / a_1 halves of the operands came in before the barrier: only the cotangent halves, written last step, are fetched here)
+        ws_load_op<0>(o2, D3, A2); ws_load_op<2>(o2, D3, A2); ws_load_op<1>(o2, D3, A2); ws_load_op<3>(o2, D3, A2);
 #else
         ws_load_op<0>(o2, D3, A2); ws_load_op<2>(o2, D3, A2); ws_load_op<4>(o2, D3, A2); ws_load_op<6>(o2, D3, A2);
         ws_load_op<5>(o2, D3, A2); ws_load_op<7>(o2, D3, A2); ws_load_op<1>(o2, D3, A2); ws_load_op<3>(o2, D3, A2);
@@ -558,7 +587,11 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
             if constexpr (nn < 12) ws_dw_mfma<nn>(dW2, o2);
             else ws_dw_mfma<nn - 12>(dW1, o1);
 #endif
+#if UMNN_WS_PREFETCH_B && !UMNN_WS_C_SPLIT
+            if constexpr (nn < 4 && !UMNN_WS_DW1_IN_B1) ws_load_op<nn>(o1, D2, A1);
+#else
             if constexpr (nn < 8 && !UMNN_WS_DW1_IN_B1) ws_load_op<nn>(o1, D2, A1);
+#endif
             // delta_4: two registers per slot, pair j split at slots j + 1 / j + 2, K-steps stored at 6, 7 / 10, 11
 #if !UMNN_WS_D4_IN_CA && !defined(UMNN_WS_EXP_NOD4_CB)
 #if UMNN_WS_SPREAD && !UMNN_WS_DW1_IN_B1
@@ -582,6 +615,14 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
         ws_adv<2, WS_TILE>(rD3); ws_adv<2, WS_TILE>(rD2);
         ws_adv<2, WS_P3>(rS4); ws_adv<2, WS_TILE>(rD4);
         ws_adv<WS_NS3, WS_TILE>(rA3c); ws_adv<2, WS_TILE>(rD4c);
+#if UMNN_WS_PREFETCH_B && !UMNN_WS_C_SPLIT
+        {   // next step's a_2 / a_1 operands (tiles written six and ten steps ago)
+            const unsigned short* A2n = lds16 + WS_OFF_A2 + rA2 + trb;
+            const unsigned short* A1n = lds16 + WS_OFF_A1 + rA1 + trb;
+            ws_load_op<4>(o2, A2n, A2n); ws_load_op<6>(o2, A2n, A2n); ws_load_op<5>(o2, A2n, A2n); ws_load_op<7>(o2, A2n, A2n);
+            if constexpr (!UMNN_WS_DW1_IN_B1) { ws_load_op<4>(o1, A1n, A1n); ws_load_op<6>(o1, A1n, A1n); ws_load_op<5>(o1, A1n, A1n); ws_load_op<7>(o1, A1n, A1n); }
+        }
+#endif
         WS_T(t2);
         __syncthreads();
         WS_T(t3);
