@@ -7,6 +7,7 @@ for S in ${1:-0 1}; do
   O=$R/gpurun_out/pmc_bwd_ws$S; rm -rf $O; mkdir -p $O
   UMNN_BWD_WS=$S timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $O/pmc1 -- python $R/tools/bwd_sweep.py --shape bsds300 --reps 2 > /dev/null 2>&1
   UMNN_BWD_WS=$S timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc2 -- python $R/tools/bwd_sweep.py --shape bsds300 --reps 2 > /dev/null 2>&1
+  UMNN_BWD_WS=$S timeout 200 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_WAIT_INST_ANY --output-format csv -d $O/pmc3 -- python $R/tools/bwd_sweep.py --shape bsds300 --reps 2 > /dev/null 2>&1
   python $R/tools/pmc_summary.py $O | grep -i "cc_bwd_bf16\|cc_bwd_swp\|cc_bwd_ws\|kernel,counter" > $O/summary.csv
   find $O -name "*_counter_collection.csv" -size +1M -delete; find $O -name "*kernel_trace.csv" -size +1M -delete
   cat $O/summary.csv
