@@ -107,6 +107,11 @@ __device__ __forceinline__ u32x2 ws_tr_read(const unsigned short* src) {
 #ifndef UMNN_WS_PAIRING
 #define UMNN_WS_PAIRING 0
 #endif
+#ifdef UMNN_WS_EXP_NOBARRIER                 // timing only (results wrong): the role waves free-running
+#define WS_STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define WS_STEP_SYNC() __syncthreads()
+#endif
 #ifndef UMNN_WS_PREFETCH_B
 #define UMNN_WS_PREFETCH_B 1         // the a_l operands of the dW products (written steps ago) are fetched BEFORE the step barrier
 #endif
@@ -460,7 +465,7 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
 #endif
         ws_adv<2, WS_P3>(rS4); ws_adv<2, WS_TILE>(rD4w);
         WS_T(t2);
-        __syncthreads();
+        WS_STEP_SYNC();
         WS_T(t3);
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
@@ -624,7 +629,7 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
         }
 #endif
         WS_T(t2);
-        __syncthreads();
+        WS_STEP_SYNC();
         WS_T(t3);
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
@@ -934,7 +939,7 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
         ws_adv<ws_a_ns(LAYER), WS_TILE>(rAin); ws_adv<2, WS_P3>(rAin3);
         ws_adv<ws_a_ns(LO), WS_TILE>(rAout); ws_adv<2, WS_P3>(rAout3); ws_adv<2, WS_P3>(rD4);
         WS_T(t2);
-        __syncthreads();
+        WS_STEP_SYNC();
         WS_T(t3);
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
@@ -1121,7 +1126,7 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
         }
         ws_adv<ws_a_ns(LAYER), WS_TILE>(rAsg); ws_adv<2, WS_TILE>(rDin); ws_adv<2, WS_TILE>(rDout);
         WS_T(t2);
-        __syncthreads();
+        WS_STEP_SYNC();
         WS_T(t3);
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
