@@ -265,6 +265,15 @@ int umnn_made_mlp_forward(const umnn_made_net* net, const float* x, long long B,
  * layer given here is followed by ReLU and written as umnn_made_split3's operand [hi | lo | hi | 1 | 1 | 0...] (out_ld bf16 per row)
  * for a wide output layer that stays a library GEMM (BSDS300's 1890, the VAE flow's 1920 columns). */
 int umnn_made_mlp_forward_ex(const umnn_made_net* net, const float* x, long long B, void* out, int out_mode, int out_ld, void* stream);
+/* ONE masked linear layer as its own launch (made.py:16-27 MaskedLinear.forward = F.linear(input, mask * weight, bias)), for
+ * conditioners whose OUTPUT layer is wide (the VAE flow's 1920, BSDS300's 1890 columns), where one workgroup per row group cannot
+ * fill the chip: the grid is (row groups of 16*row_tiles rows) x (feature_groups groups of output tiles); the bf16 split of the
+ * input happens in the operand load (relu_in != 0: the input is the previous layer's pre-activation and ReLU is applied on load, so
+ * a hidden layer needs no separate activation / split launch); x2 != NULL: the input is [x | x2] with x [B, K1] and x2 [B, K - K1]
+ * (ConditionnalMADE's cat((context, x), 1), made.py:167, without the copy); out = in' W^T + b as fp32 (out_bf16 == 0) or bf16.
+ * W_frag / bias / arithmetic as in umnn_made_net; K <= 512.  row_tiles 0 (auto) | 1 | 2 | 4; feature_groups 0 (auto) or a count. */
+int umnn_made_linear_forward(const void* W_frag, const float* bias, int K, int N, const float* x, const float* x2, int K1,
+                             long long B, int relu_in, void* out, int out_bf16, int row_tiles, int feature_groups, void* stream);
 
 #ifdef __cplusplus
 }

@@ -193,8 +193,10 @@ def test_hidden_stack_kernel_feeding_the_library_gemm_of_a_wide_output_layer(dev
     with torch.no_grad():
         n0 = _lib.lib().umnn_made_launch_count()
         made.raw(*args)
-        assert _lib.lib().umnn_made_launch_count() == n0, "wide outputs default to the per-layer path (measured: no gain from the kernel)"
+        assert _lib.lib().umnn_made_launch_count() == n0 + 3 and "made_linear" in _lib.lib().umnn_last_made_kernel_name().decode(), \
+            "wide outputs at launch-bound batch sizes default to one launch of made_linear_kernel per masked linear"
         umnn_amd.set_made_fused(True, hybrid=True)
+        n0 = _lib.lib().umnn_made_launch_count()
         fused = made.raw(*args)
         assert _lib.lib().umnn_made_launch_count() == n0 + 1 and "made_fused" in _lib.lib().umnn_last_made_kernel_name().decode()
         fused16 = made.raw(*args, out_dtype=torch.bfloat16)
@@ -211,3 +213,93 @@ def test_hidden_stack_kernel_feeding_the_library_gemm_of_a_wide_output_layer(dev
     assert (fused - exact).abs().max().item() <= 2e-5 * scale
     assert (fused - per_layer).abs().max().item() <= 1e-5 * scale
     assert fused16.dtype == torch.bfloat16 and (fused16.float() - exact).abs().max().item() <= 6e-3 * scale
+
+
+@pytest.mark.parametrize("nin,cond,hid,E,B", [(64, 320, [512, 512], 30, 1024),       # the VAE prior flow's conditioner (C4)
+                                              (63, 0, [512, 512], 30, 777),            # BSDS300's widths, K0 = 63: scalar operand loads
+                                              (20, 12, [100, 37], 30, 19),             # widths off every tile size, one ragged row tile
+                                              (40, 0, [64], 20, 1), (33, 7, [512, 256, 300], 16, 300)])
+@pytest.mark.parametrize("out_dtype", [None, torch.bfloat16])
+def test_one_launch_per_masked_linear_matches_the_library_route_and_the_oracle(dev, nin, cond, hid, E, B, out_dtype):
+    """umnn_made_linear_forward (made_linear_kernel: one masked linear per launch, grid over row groups x output-tile groups,
+    ReLU of the previous layer and the bf16 split in the operand load, ConditionnalMADE's two input blocks read without the cat)
+    against the split + library GEMM route (same three bf16 products), the fp32 chain and the float64 oracle of
+    models/UMNN/made.py:16-27,113-119,165-168."""
+    import umnn_amd
+    from umnn_amd import MADE, ConditionnalMADE, _lib
+    from umnn_amd.made import MaskedLinear
+    torch.manual_seed(nin + B)
+    if cond:
+        made = ConditionnalMADE(nin, cond, hid, (nin + cond) * E, num_masks=1, natural_ordering=True).to(dev)
+        args = (torch.randn(B, nin, device=dev) * 2, torch.randn(B, cond, device=dev))
+    else:
+        made = MADE(nin, hid, nin * E, num_masks=1, natural_ordering=True).to(dev)
+        args = (torch.randn(B, nin, device=dev) * 2,)
+    lin = [m for m in made.net if isinstance(m, MaskedLinear)]
+    with torch.no_grad():
+        for m in lin:
+            m.bias.uniform_(-1.0, 1.0)
+    assert nin * E > 512
+    try:
+        with torch.no_grad():
+            n0 = _lib.lib().umnn_made_launch_count()
+            layered = made.raw(*args, out_dtype=out_dtype)
+            assert _lib.lib().umnn_made_launch_count() - n0 == len(lin)
+            assert "made_linear" in _lib.lib().umnn_last_made_kernel_name().decode()
+            again = made.raw(*args, out_dtype=out_dtype)
+            umnn_amd.set_made_fused(True, layered=False)
+            library = made.raw(*args, out_dtype=out_dtype)
+            assert _lib.lib().umnn_made_launch_count() - n0 == 2 * len(lin)
+            umnn_amd.set_made_fast_path(False)
+            exact = made.raw(*args)
+    finally:
+        umnn_amd.set_made_fused(True, layered=True)
+        umnn_amd.set_made_fast_path(True)
+    assert torch.equal(layered, again), "bit-reproducible"
+    assert layered.dtype == (out_dtype or torch.float32) and layered.shape == exact.shape == (B, nin * E)
+    scale = exact.abs().max().item()
+    tol = 2e-5 if out_dtype is None else 6e-3
+    assert (layered.float() - exact).abs().max().item() <= tol * scale
+    assert (layered.float() - library.float()).abs().max().item() <= (1e-5 if out_dtype is None else 8e-3) * scale
+    if not cond:
+        ref = O.made_forward([m.weight.detach().cpu().numpy().astype(np.float64) for m in lin],
+                             [m.bias.detach().cpu().numpy().astype(np.float64) for m in lin],
+                             [m.mask.cpu().numpy().astype(np.float64) for m in lin], args[0][:64].cpu().numpy().astype(np.float64))
+        assert np.abs(layered[:64].float().cpu().numpy() - ref).max() <= tol * scale
+
+
+def test_made_linear_entry_point_over_grid_shapes_and_argument_errors(dev):
+    """The C entry itself: every row-tile count x output-tile grouping gives the same numbers (several passes per workgroup,
+    groups with no tile, more groups than tiles), ReLU on load, two input blocks; argument errors are reported, not launched."""
+    import ctypes
+    from umnn_amd import _lib
+    from umnn_amd.made import pack_fragments
+    lib = _lib.lib()
+    torch.manual_seed(3)
+    B, K, K1, N = 83, 200, 72, 1000
+    W = torch.randn(N, K, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev)
+    x = torch.randn(B, K, device=dev)
+    frags = pack_fragments(W)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    want = torch.relu(x).double() @ W.double().t() + b.double()
+    scale = want.abs().max().item()
+    x1, x2 = x[:, :K1].contiguous(), x[:, K1:].contiguous()
+    first = None
+    for rt, fg in [(0, 0), (1, 1), (1, 7), (2, 3), (4, 1), (4, 63), (2, 500), (1, 16)]:
+        for two in (False, True):
+            out = torch.full((B, N), float("nan"), device=dev)
+            _lib.check(lib.umnn_made_linear_forward(frags.data_ptr(), b.data_ptr(), K, N, (x1 if two else x).data_ptr(),
+                                                    x2.data_ptr() if two else None, K1 if two else 0, B, 1, out.data_ptr(), 0, rt, fg,
+                                                    stream), "made_linear")
+            assert (out.double() - want).abs().max().item() <= 2e-5 * scale, (rt, fg, two)
+            first = out if first is None else first
+            assert (out - first).abs().max().item() <= 2e-6 * scale       # (one or three accumulators per tile: summation order)
+    out = torch.empty(B, N, device=dev)
+    for bad in [dict(K=513), dict(rt=3), dict(fg=-1), dict(K1=K, two=True), dict(B=-1)]:
+        a = dict(K=K, rt=0, fg=0, K1=K1, two=False, B=B)
+        a.update(bad)
+        rc = lib.umnn_made_linear_forward(frags.data_ptr(), b.data_ptr(), a["K"], N, x.data_ptr(), x2.data_ptr() if a["two"] else None,
+                                          a["K1"], a["B"], 0, out.data_ptr(), 0, a["rt"], a["fg"], stream)
+        assert rc != 0 and lib.umnn_last_error(), bad
+    assert lib.umnn_made_linear_forward(frags.data_ptr(), b.data_ptr(), K, N, x.data_ptr(), None, 0, 0, 0, out.data_ptr(), 0, 0, 0, stream) == 0

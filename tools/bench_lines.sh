@@ -2,20 +2,22 @@
 # One bench.py line per workload and mode -> gpurun_out/bench_lines.jsonl (copied to profiles/rNN/bench_lines.jsonl)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/bench_lines.jsonl; : > $O
-run() { timeout 400 python $R/bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5 "$@" 2>/dev/null | tail -1 >> $O; }
+run() { timeout 400 python $R/bench.py --no-cpu-baseline --no-extras --steps ${STEPS:-20} --warmup ${WARMUP:-5} "$@" 2>/dev/null | tail -1 >> $O; }
+fast() { STEPS=200 WARMUP=40 run "$@"; }          # the sub-3-ms steps: 200 timed steps
 run --workload bsds300
 run --workload bsds300 --precision fp32
 run --workload bsds300 --embedding bf16
-run --workload power
-run --workload toy
-run --workload toy --graph
-run --workload vae
-run --workload mnist
+fast --workload power
+fast --workload toy
+fast --workload toy --graph
+fast --workload vae
+fast --workload vae --graph
+fast --workload mnist
 run --workload bsds300 --mode train
 run --workload power --mode train
 run --workload vae --mode train
 run --workload mnist --mode train
-run --workload power --mode train --rows 100 --graph
+fast --workload power --mode train --rows 100 --graph
 python - <<PY
 import json
 for l in open("$O"):

@@ -91,6 +91,8 @@ SIGNATURES = {
     "umnn_last_made_kernel_name": (ctypes.c_char_p, []),
     "umnn_made_mlp_forward": (ctypes.c_int, [ctypes.c_void_p, _fp, _ll, _fp, ctypes.c_int, _fp]),
     "umnn_made_mlp_forward_ex": (ctypes.c_int, [ctypes.c_void_p, _fp, _ll, _fp, ctypes.c_int, ctypes.c_int, _fp]),
+    "umnn_made_linear_forward": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, ctypes.c_int, _ll, ctypes.c_int, _fp,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
 }
 
 MADE_MAX_LAYERS = 8

@@ -37,6 +37,10 @@ struct MadeArgs {
     void* out;                                          // [B, NL] fp32 or bf16
     int out_bf16;                                       // 0 fp32 h, 1 bf16 h, 2 split3 operand of relu(h) for a following library GEMM
     int out_ld;                                         // (mode 2) bf16 elements per operand row
+    int relu_in;                                        // (made_linear_kernel) x is a pre-activation: ReLU in the operand load
+    int x_vec;                                          // (made_linear_kernel) K % 4 == 0 and x 16-byte aligned: b128 loads
+    const float* x2;                                    // (made_linear_kernel) second input block [B, K - K1] or null
+    int K1;
     long long B;
 };
 
@@ -203,6 +207,191 @@ __global__ __launch_bounds__(64 * MF_WAVES, 1) void made_fused_kernel(const Made
         }
     }
 }
+
+// ONE masked linear layer per launch (umnn_made_linear_forward): the conditioners with a wide OUTPUT layer (the VAE prior flow's
+// 1920, BSDS300's 1890 columns), where a grid over row groups alone cannot fill the chip.  Grid = (groups of 16 RT rows) x (G
+// groups of output tiles: workgroup y owns tiles y, y + G, ...); same operand layout, fragments and arithmetic as the kernel above.
+// A launch is a few microseconds of work, so it is organised around memory LATENCY: the first PD K-steps of the wave's weight
+// fragments are requested before anything else, all of the workgroup's x rows are loaded in one batch (ReLU of the previous
+// layer and the bf16 split applied on the way into LDS), and the K loop keeps PD K-steps of fragments in flight in a register ring.
+template <int RT, int TPC, int PD, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void made_linear_kernel(const MadeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short act[];       // [RT][MF_SMAX][2][64][8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, p = lane & 15;
+    const long long row0 = (long long)blockIdx.x * (16 * RT);
+    auto act_at = [&](int rt, int s, int piece) { return act + (((rt * MF_SMAX + s) * 2 + piece) * 64 + lane) * 8; };
+    const int K = a.width[0], N = a.width[1], K1 = a.x2 ? a.K1 : a.width[0];
+    const int S = (K + 31) / 32, T = (N + 15) / 16;
+    const unsigned short* __restrict__ Wl = a.W[0];
+    const float* __restrict__ bl = a.b[0];
+    const int G = gridDim.y, fg = blockIdx.y;
+    const int TG = fg < T ? (T - fg + G - 1) / G : 0;                           // this workgroup's tiles
+    const int npass = (TG + NW * TPC - 1) / (NW * TPC);
+
+    u32x4 fr[PD][TPC][2];                                                       // ring: K-step s lives in buffer s % PD
+    auto fetch = [&](int buf, int s, int t0, int nc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < TPC; ++c)
+            if (c < nc) {
+                const int t = fg + G * (t0 + NW * c);
+#pragma unroll
+                for (int piece = 0; piece < 2; ++piece)
+                    fr[buf][c][piece] = *reinterpret_cast<const u32x4*>(Wl + ((size_t)(t * S + s) * 2 + piece) * MF_FRAG + lane * 8);
+            }
+    };
+    auto tiles_of = [&](int pass, int& t0, int& nc) __attribute__((always_inline)) {
+        t0 = wid + pass * NW * TPC;                                       // (index among the workgroup's TG tiles)
+        nc = t0 < TG ? (TG - t0 + NW - 1) / NW : 0;
+        nc = nc > TPC ? TPC : nc;
+    };
+    int t0, nc;
+    tiles_of(0, t0, nc);
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+        if (d < S) fetch(d, d, t0, nc);
+
+    // ---- operands from x: every wave stages its share of the (row tile, K-step) pairs, all loads in flight together
+    {
+        constexpr int NST = RT * MF_SMAX / NW;
+        const bool vec = a.x_vec != 0;
+        float v[NST][8];
+#pragma unroll
+        for (int c = 0; c < NST; ++c) {
+            const int it = wid + NW * c;
+            const int rt = it / S, s = it - rt * S;
+            const long long row = row0 + 16 * rt + p;
+            const bool ok = it < RT * S && row < a.B;
+            // x = [x1 | x2] (the conditional MADE's cat((context, x), 1), made.py:167): columns < K1 from x1, the rest from x2
+            const long long rr = row < a.B ? row : a.B - 1;
+            const float* xr1 = a.x + rr * K1;
+            const float* xr2 = a.x2 ? a.x2 + rr * (K - K1) - K1 : xr1;
+            if (vec) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = kfeat(s, g, 4 * h);
+                    f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ok && k < K) q = *reinterpret_cast<const f32x4*>((k < K1 ? xr1 : xr2) + k);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[c][4 * h + r] = q[r];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = kfeat(s, g, j);
+                    v[c][j] = (ok && k < K) ? (k < K1 ? xr1 : xr2)[k] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NST; ++c) {
+            const int it = wid + NW * c;
+            if (it < RT * S) {
+                const int rt = it / S, s = it - rt * S;
+                if (a.relu_in) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[c][j] = fmaxf(v[c][j], 0.f);
+                }
+                unsigned q0[2], q1[2], q2[2], q3[2];
+                split_pair<2>(v[c][0], v[c][1], q0); split_pair<2>(v[c][2], v[c][3], q1);
+                split_pair<2>(v[c][4], v[c][5], q2); split_pair<2>(v[c][6], v[c][7], q3);
+#pragma unroll
+                for (int piece = 0; piece < 2; ++piece)
+                    *reinterpret_cast<u32x4*>(act_at(rt, s, piece)) = u32x4{q0[piece], q1[piece], q2[piece], q3[piece]};
+            }
+        }
+    }
+    __syncthreads();
+
+    // one accumulator per cross term when a wave owns a single tile (three independent MFMA chains per row tile instead of one
+    // chain of 3 S dependent instructions); the bias enters through the accumulator init, fetched before the K loop
+    constexpr int NT = TPC == 1 ? 3 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        f32x4 acc[NT][TPC][RT];
+#pragma unroll
+        for (int c = 0; c < TPC; ++c) {
+            const int f0 = 16 * (fg + G * (t0 + NW * c)) + 4 * g;               // this lane's four features of tile c
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < nc) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[r] = f0 + r < N ? bl[f0 + r] : 0.f;
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                acc[0][c][rt] = bv;
+#pragma unroll
+                for (int ti = 1; ti < NT; ++ti) acc[ti][c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        u32x4 bh[2][RT], bo[2][RT];                                             // B operands of K-step ss in buffer ss & 1, read one step ahead
+        auto ldb = [&](int buf, int ss) __attribute__((always_inline)) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                bh[buf][rt] = *reinterpret_cast<const u32x4*>(act_at(rt, ss, 0));
+                bo[buf][rt] = *reinterpret_cast<const u32x4*>(act_at(rt, ss, 1));
+            }
+        };
+        if (nc > 0) {
+            ldb(0, 0);
+            for (int s = 0; s < S; s += PD) {
+#pragma unroll
+                for (int d = 0; d < PD; ++d) {
+                    const int ss = s + d;
+                    if (ss < S) {
+                        if (ss + 1 < S) ldb((d + 1) & 1, ss + 1);
+#pragma unroll
+                        for (int term = 0; term < 3; ++term)
+#pragma unroll
+                            for (int c = 0; c < TPC; ++c)
+                                if (c < nc) {
+#pragma unroll
+                                    for (int rt = 0; rt < RT; ++rt)
+                                        acc[NT == 3 ? term : 0][c][rt] = mfma_bf16(fr[d][c][term == 2 ? 1 : 0], term == 1 ? bo[d & 1][rt] : bh[d & 1][rt],
+                                                                                  acc[NT == 3 ? term : 0][c][rt]);   // Wh xh, Wh xl, Wl xh
+                                }
+                        if (ss + PD < S) fetch(d, ss + PD, t0, nc);          // the buffer is free again
+                    }
+                }
+            }
+        }
+        const int t0e = t0, nce = nc;
+        if (pass + 1 < npass) {                                                 // next pass: its first fragments behind this epilogue
+            tiles_of(pass + 1, t0, nc);
+#pragma unroll
+            for (int d = 0; d < PD; ++d)
+                if (d < S) fetch(d, d, t0, nc);
+        }
+#pragma unroll
+        for (int c = 0; c < TPC; ++c) {
+            if (c >= nce) continue;
+            const int t = fg + G * (t0e + NW * c);
+            const int f0 = 16 * t + 4 * g;                                      // this lane's four features
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const long long row = row0 + 16 * rt + p;
+                if (row >= a.B) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[0][c][rt][r];
+                    if constexpr (NT == 3) v[r] += acc[1][c][rt][r] + acc[2][c][rt][r];
+                }
+                if (a.out_bf16) {
+                    unsigned short* o = reinterpret_cast<unsigned short*>(a.out) + row * N + f0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (f0 + r < N) o[r] = f32_to_bf16_rn(v[r]);
+                } else {
+                    float* o = reinterpret_cast<float*>(a.out) + row * N + f0;
+                    if (f0 + 3 < N && (N & 3) == 0) *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                    else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (f0 + r < N) o[r] = v[r];
+                }
+            }
+        }
+    }
+}
 }  // namespace
 
 extern "C" int umnn_made_mlp_forward(const umnn_made_net* net, const float* x, long long B, void* h_out, int out_bf16,
@@ -216,7 +405,7 @@ extern "C" int umnn_made_mlp_forward_ex(const umnn_made_net* net, const float* x
     const int L = net->n_layers;
     if (L < 1 || L > UMNN_MADE_MAX_LAYERS) return umnn_fail(UMNN_EUNSUPPORTED, "made_mlp: 1..UMNN_MADE_MAX_LAYERS linear layers");
     if (B < 0) return umnn_fail(UMNN_EINVAL, "made_mlp: B < 0");
-    MadeArgs a;
+    MadeArgs a = {};
     for (int l = 0; l <= L; ++l) {
         a.width[l] = net->widths[l];
         if (a.width[l] < 1) return umnn_fail(UMNN_EINVAL, "made_mlp: widths must be >= 1");
@@ -250,4 +439,64 @@ extern "C" int umnn_made_mlp_forward_ex(const umnn_made_net* net, const float* x
         umnn_note_made_launch("made_fused<RT=1>");
     }
     return umnn_check(hipGetLastError(), "made_fused launch");
+}
+
+extern "C" int umnn_made_linear_forward(const void* W_frag, const float* bias, int K, int N, const float* x, const float* x2, int K1,
+                                        long long B, int relu_in, void* out, int out_bf16, int row_tiles, int feature_groups,
+                                        void* stream_) {
+    if (K < 1 || N < 1) return umnn_fail(UMNN_EINVAL, "made_linear: widths must be >= 1");
+    if (K > 32 * MF_SMAX) return umnn_fail(UMNN_EUNSUPPORTED, "made_linear: input width up to 512 (wider layers keep the library GEMMs)");
+    if (B < 0) return umnn_fail(UMNN_EINVAL, "made_linear: B < 0");
+    if (x2 && (K1 < 1 || K1 >= K)) return umnn_fail(UMNN_EINVAL, "made_linear: two input blocks need 1 <= K1 < K");
+    if (row_tiles != 0 && row_tiles != 1 && row_tiles != 2 && row_tiles != 4) return umnn_fail(UMNN_EINVAL, "made_linear: row_tiles is 0 (auto), 1, 2 or 4");
+    if (feature_groups < 0 || feature_groups > 65535) return umnn_fail(UMNN_EINVAL, "made_linear: feature_groups is 0 (auto) .. 65535");
+    if (B == 0) return 0;
+    if (!W_frag || !bias || !x || !out) return umnn_fail(UMNN_EINVAL, "made_linear: null pointer");
+    MadeArgs a = {};
+    a.width[0] = K; a.width[1] = N; a.n_layers = 1;
+    a.W[0] = reinterpret_cast<const unsigned short*>(W_frag); a.b[0] = bias;
+    a.x = x; a.x2 = x2; a.K1 = x2 ? K1 : K; a.out = out; a.out_bf16 = out_bf16 ? 1 : 0; a.out_ld = 0; a.relu_in = relu_in ? 1 : 0; a.B = B;
+    a.x_vec = (a.K1 % 4 == 0 && (K - a.K1) % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(x2) & 15) == 0) ? 1 : 0;
+    // grid: (row groups of 16 RT rows) x (G groups of output tiles).  A weight fragment fetched from L2 serves RT row tiles, so RT
+    // as large as still fills the chip with at least four tiles per workgroup; then one tile per wave (four or eight waves) with
+    // the tile's whole K extent of fragments in flight, or two tiles per wave and half of it
+    const int cus = umnn_num_cus(), T = (N + 15) / 16;
+    const int gmax = T >= 4 ? T / 4 : 1;
+    int RT = row_tiles, G = feature_groups;
+    if (RT == 0) {
+        RT = 1;
+        for (int rt = 4; rt >= 1; rt >>= 1) {
+            const long long rows = (B + 16 * rt - 1) / (16 * rt);
+            if (rows * gmax >= cus || rt == 1) { RT = rt; break; }
+        }
+    }
+    if (G == 0) {
+        const long long rows = (B + 16 * RT - 1) / (16 * RT);
+        const long long want = (cus + rows - 1) / rows;
+        G = (int)(want < 1 ? 1 : (want > gmax ? gmax : want));
+    }
+    if (G > T) G = T;
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t lds = (size_t)RT * MF_SMAX * 2 * 64 * 8 * sizeof(unsigned short);
+    const dim3 grid((unsigned)((B + 16 * RT - 1) / (16 * RT)), (unsigned)G);
+    const int TG = (T + G - 1) / G;                       // tiles of the fullest workgroup
+#define UMNN_ML_LAUNCH(RT_, TPC_, PD_, NW_)                                                                                \
+    do {                                                                                                                   \
+        if (int rc = umnn_allow_lds((const void*)made_linear_kernel<RT_, TPC_, PD_, NW_>, lds)) return rc;                 \
+        hipLaunchKernelGGL((made_linear_kernel<RT_, TPC_, PD_, NW_>), grid, dim3(64 * NW_), lds, stream, a);               \
+        umnn_note_made_launch("made_linear<RT=" #RT_ ",TPC=" #TPC_ ",PD=" #PD_ ",NW=" #NW_ ">");                          \
+    } while (0)
+#define UMNN_ML_PICK(RT_, PD4_, PD8_)                                                                                            \
+    do {                                                                                                                   \
+        if (TG <= 4) UMNN_ML_LAUNCH(RT_, 1, PD4_, 4);                                                                      \
+        else if (TG <= 8) UMNN_ML_LAUNCH(RT_, 1, PD8_, 8);                                                                   \
+        else UMNN_ML_LAUNCH(RT_, 2, 8, 8);                                                                                 \
+    } while (0)
+    if (RT == 4) UMNN_ML_PICK(4, 8, 8);                      // (four waves stage 16 operand pairs each: 128 registers beside the ring)
+    else if (RT == 2) UMNN_ML_PICK(2, 16, 16);
+    else UMNN_ML_PICK(1, 16, 16);
+#undef UMNN_ML_PICK
+#undef UMNN_ML_LAUNCH
+    return umnn_check(hipGetLastError(), "made_linear launch");
 }

@@ -221,10 +221,11 @@ def _fast_chain(a, layers, last_rows=None, out_dtype=None):
 
 _FUSED = {"enabled": os.environ.get("UMNN_MADE_FUSED", "1") != "0", "max_rows": int(os.environ.get("UMNN_MADE_FUSED_MAX_ROWS", "32768")),
           "wide_out": os.environ.get("UMNN_MADE_FUSED_WIDE_OUT", "0") == "1",
-          "hybrid": os.environ.get("UMNN_MADE_FUSED_HYBRID", "0") == "1"}
+          "hybrid": os.environ.get("UMNN_MADE_FUSED_HYBRID", "0") == "1",
+          "layered": os.environ.get("UMNN_MADE_LAYERED", "1") != "0"}
 
 
-def set_made_fused(enabled, max_rows=None, wide_out=None, hybrid=None):
+def set_made_fused(enabled, max_rows=None, wide_out=None, hybrid=None, layered=None):
     """The whole conditioner of a block as ONE launch (``umnn_made_mlp_forward``) on the inference path when every width is
     <= 512 (see ``_fused_ok``) and the batch has at most ``max_rows`` rows (default 32768).  ``False``: always the per-layer
     path.  ``wide_out=True`` lifts the limit on the OUTPUT width (tests / measurements)."""
@@ -235,16 +236,20 @@ def set_made_fused(enabled, max_rows=None, wide_out=None, hybrid=None):
         _FUSED["wide_out"] = bool(wide_out)
     if hybrid is not None:           # wide outputs: hidden stack in the kernel, output layer as one library GEMM (measured: no gain)
         _FUSED["hybrid"] = bool(hybrid)
+    if layered is not None:          # wide outputs: one launch of the kernel per masked linear, grid over rows x output tiles
+        _FUSED["layered"] = bool(layered)
 
 
 def _fused_ok(a, layers, n_out=None):
-    """-> 0 (per-layer path), 1 (whole conditioner in one launch) or 2 (hidden stack in one launch + the output layer as ONE
-    library GEMM).  Every input / hidden width must be <= 512.  Measured with bench.py's workloads (tools/bench_fused.sh):
-    narrow outputs (toy 20, POWER 180 columns) win with the whole MLP in the kernel (0.203 -> 0.162 ms, 2.21 -> 2.00 ms per step);
-    wide output layers (BSDS300's 1890, the VAE flow's 1920 columns) lose there (several passes of a kernel that streams its
-    weights at one wave per SIMD: 12.92 vs 13.11 ms, 1.02 vs 1.34 ms), and feeding hipBLASLt's output GEMM from the kernel's
-    hidden stack (mode 2) does not beat four short launches either (VAE 1.03 vs 1.11 ms, BSDS300 13.55 vs 13.58 ms): wide outputs
-    keep the per-layer path unless ``set_made_fused(hybrid=True)`` / ``wide_out=True`` ask otherwise."""
+    """-> 0 (split + library GEMM per layer), 1 (whole conditioner in one launch), 2 (hidden stack in one launch + the output
+    layer as ONE library GEMM) or 3 (one launch of ``made_linear_kernel`` per masked linear).  Every input / hidden width must
+    be <= 512.  Measured with bench.py's workloads (tools/bench_fused.sh, tools/made_layered_check.py): narrow outputs (toy 20,
+    POWER 180 columns) win with the whole MLP in the kernel (0.203 -> 0.162 ms, 2.21 -> 2.00 ms per step); wide output layers
+    (BSDS300's 1890, the VAE flow's 1920 columns) lose there (several passes of a kernel that streams its weights at one wave
+    per SIMD: 12.92 vs 13.11 ms, 1.02 vs 1.34 ms), and feeding hipBLASLt's output GEMM from the kernel's hidden stack (mode 2,
+    ``hybrid=True``) does not beat four short launches either (VAE 1.03 vs 1.11 ms, BSDS300 13.55 vs 13.58 ms); one launch per
+    layer with the grid split over output tiles (mode 3) wins at launch-bound batch sizes (VAE at 1024 rows 1.00 -> 0.91 ms) and
+    ties with the library GEMMs at 8192 rows, so it is taken up to ``UMNN_MADE_LAYERED_MAX_ROWS`` rows (4096)."""
     if not _FUSED["enabled"] or a.shape[0] > _FUSED["max_rows"] or len(layers) > 8:
         return 0
     if not all(l.in_features <= 512 for l in layers):
@@ -252,7 +257,9 @@ def _fused_ok(a, layers, n_out=None):
     n_out = layers[-1].out_features if n_out is None else n_out
     if n_out <= 512 or _FUSED.get("wide_out", False):
         return 1
-    return 2 if (len(layers) >= 2 and _FUSED.get("hybrid", False)) else 0
+    if len(layers) >= 2 and _FUSED.get("hybrid", False):
+        return 2
+    return 3 if (_FUSED.get("layered", True) and a.shape[0] <= _LAYERED_MAX_ROWS) else 0
 
 
 def _fused_chain(a, layers, last_rows=None, out_dtype=None, mode=1):
@@ -286,6 +293,34 @@ def _fused_chain(a, layers, last_rows=None, out_dtype=None, mode=1):
     if bf16:
         return torch.mm(op, packed.t())                                  # bf16 out, fp32 accumulate inside the GEMM
     return torch.mm(op, packed.t(), out_dtype=torch.float32)
+
+
+_LAYERED_MAX_ROWS = int(os.environ.get("UMNN_MADE_LAYERED_MAX_ROWS", "4096"))
+
+
+def _layered_chain(a, layers, last_rows=None, out_dtype=None, a2=None):
+    """a [B, K0] fp32 (or the two column blocks a | a2 of it) -> conditioner output, one launch of ``made_linear_kernel`` per
+    masked linear (``umnn_made_linear_forward``: grid over row groups x output-tile groups, the bf16 split and the previous
+    layer's ReLU in the operand load) -- the route of conditioners with a wide output layer at launch-bound batch sizes,
+    replacing split + library GEMM pairs (two launches per layer) and the cat of ConditionnalMADE's two inputs."""
+    from . import _lib
+    lib = _lib.lib()
+    cur, cur2 = a.contiguous(), (None if a2 is None else a2.contiguous())
+    B = cur.shape[0]
+    rt, fg = int(os.environ.get("UMNN_MADE_LINEAR_RT", "0")), int(os.environ.get("UMNN_MADE_LINEAR_G", "0"))
+    with torch.cuda.device(a.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        for i, layer in enumerate(layers):
+            last = i == len(layers) - 1
+            frags, bias = layer.packed_fragments(last_rows if last else None)
+            bf16 = last and out_dtype == torch.bfloat16
+            out = torch.empty(B, bias.shape[0], device=a.device, dtype=torch.bfloat16 if bf16 else torch.float32)
+            K = cur.shape[1] + (0 if cur2 is None else cur2.shape[1])
+            _lib.check(lib.umnn_made_linear_forward(frags.data_ptr(), bias.data_ptr(), K, bias.shape[0], cur.data_ptr(),
+                                                    None if cur2 is None else cur2.data_ptr(), cur.shape[1], B, 1 if i > 0 else 0,
+                                                    out.data_ptr(), 1 if bf16 else 0, rt, fg, stream), "umnn_made_linear_forward")
+            cur, cur2 = out, None
+    return cur
 
 
 def _to_weight_dtype(x, layer):
@@ -348,6 +383,8 @@ class MADE(nn.Module):
         if _fast_path_ok(x):
             layers = [l for l in self.net if isinstance(l, MaskedLinear)]
             mode = _fused_ok(x, layers)
+            if mode == 3:
+                return _layered_chain(x, layers, out_dtype=out_dtype)
             if mode:
                 return _fused_chain(x, layers, out_dtype=out_dtype, mode=mode)
             return _fast_chain(x, layers, out_dtype=out_dtype)
@@ -399,10 +436,16 @@ class ConditionnalMADE(MADE):
     def raw(self, x, context, out_dtype=None):
         if context.dtype != x.dtype:
             context = context.to(x.dtype)
+        if x.dtype == context.dtype == torch.float32 == self.net[0].weight.dtype and _fast_path_ok(x):
+            layers = [l for l in self.net if isinstance(l, MaskedLinear)]
+            if _fused_ok(x, layers, self.nin_non_cond * (self.nout // self.nin)) == 3:    # the kernel reads both blocks: no cat
+                return _layered_chain(context, layers, self._kept_rows(x.device), out_dtype, a2=x)
         a = _to_weight_dtype(torch.cat((context, x), 1), self.net[0])
         if _fast_path_ok(a):
             layers = [l for l in self.net if isinstance(l, MaskedLinear)]
             mode = _fused_ok(a, layers, self.nin_non_cond * (self.nout // self.nin))
+            if mode == 3:
+                return _layered_chain(a, layers, self._kept_rows(a.device), out_dtype)
             if mode:
                 return _fused_chain(a, layers, self._kept_rows(a.device), out_dtype, mode=mode)
             return _fast_chain(a, layers, self._kept_rows(a.device), out_dtype)
