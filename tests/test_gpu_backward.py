@@ -273,9 +273,9 @@ def test_graphed_train_step_matches_eager_training(dev):
 def test_mixed_wide_nets_backward_routes_match_the_oracle(hid, dev, monkeypatch, bwd_precision):
     """Nets with hidden layers wider than four tiles and no one-pass shape-exact backward.  With the default (bf16x3)
     arithmetic, nets whose FIRST hidden layer is wide and the rest narrow (MNISTExperiment's 100-50-50-50-50) run the
-    three-stage HIP backward of cc_backward_front.hip; everything else (and the fp32 mode) is differentiated with the
-    materialised ATen chain on the GPU unless UMNN_BWD_WIDE=hip forces the generic HIP kernels.  Every route must match the
-    oracle's restatement of the reference backward."""
+    three-stage HIP backward of cc_backward_front.hip; other nets up to 103 wide (and those in the fp32 mode) run zero-padded on
+    the 5- / 7-tile shape-exact fp32 kernels; the rest is differentiated with the materialised ATen chain on the GPU unless
+    UMNN_BWD_WIDE=hip forces the generic HIP kernels.  Every route must match the oracle's restatement of the reference backward."""
     import ctypes
     from umnn_amd import integral as I, IntegrandNetwork, _lib
     from umnn_amd.nets import mlp_spec
@@ -292,8 +292,11 @@ def test_mixed_wide_nets_backward_routes_match_the_oracle(hid, dev, monkeypatch,
     ref = O.integrate_backward(onet, x0.cpu().numpy(), x.cpu().numpy(), h.cpu().numpy(), n, g.cpu().numpy())
     ref_dh, ref_dtheta = ref[2], ref[5]
     staged = bwd_precision == "bf16x3" and hid[0] > 63 and max(hid[1:]) <= 63
+    # zero-padded onto the 5- / 7- / 8-tile shape-exact fp32 family (pad_to_exact_family) -- where the padded weight images fit
+    # the LDS: the four- and five-hidden-layer nets of this list do not (3 x 68 KB, 4 x 45 KB) and keep the ATen chain
+    padded = not staged and len(hid) <= 3
     desc, keep = I._desc(spec)
-    assert (_lib.lib().umnn_cc_backward_kind(ctypes.byref(desc), E) >= 0) == staged
+    assert (_lib.lib().umnn_cc_backward_kind(ctypes.byref(desc), E) >= 0) == (staged or padded)
     for mode in ("", "hip"):
         monkeypatch.setitem(I._BWD_WIDE, "hip", mode == "hip")
         xr, hr = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
@@ -304,7 +307,10 @@ def test_mixed_wide_nets_backward_routes_match_the_oracle(hid, dev, monkeypatch,
         F.backward(g)
         torch.cuda.synchronize()
         # (autograd runs backward on its own thread: count library launches instead of asking path_taken())
-        assert (_lib.lib().umnn_launch_count() > launches) == (mode == "hip" or staged)
+        assert (_lib.lib().umnn_launch_count() > launches) == (mode == "hip" or staged or padded)
+        if padded:
+            name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+            assert "KS=17" in name or "KS=26" in name or "KS=32" in name, name
         if staged:
             assert "FRONT" in _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
         dtheta = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()

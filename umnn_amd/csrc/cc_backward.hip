@@ -609,6 +609,7 @@ static const BwdVariant kBwdVariants[] = {
     BWD_VARIANT(7, 1, 1, 26), BWD_VARIANT(7, 0, 1, 26), BWD_VARIANT(7, 1, 0, 26),   // exact: every hidden layer 100 wide (toy flows, MonotonicNN): no spills
     BWD_VARIANT(7, 0, 1, 0), BWD_VARIANT(7, 1, 0, 0),
     BWD_VARIANT(8, 0, 1, 0), BWD_VARIANT(8, 1, 0, 0),
+    BWD_VARIANT(8, 0, 1, 32), BWD_VARIANT(8, 1, 0, 32),     // exact: every hidden layer 124..127 wide, or zero-padded to that (edge pass without dW: no spills; 51 in the others)
 };
 
 static const BwdVariant* find_bwd(int tmax, int nacc, int edge, int ksu) {
@@ -631,6 +632,33 @@ static int best_nacc(int T, int edge, int ksu) {
             for (const BwdVariant& v : kBwdVariants)
                 if (v.tmax == T && v.nacc == n && v.edge == edge && (exact ? (v.ksc && v.ksc == ksu) : !v.ksc)) return n;
     return -1;
+}
+
+// Nets with UNEQUAL hidden widths above 63 units (5..7 tiles) have no shape-exact variant of their own, and the generic
+// variants with runtime tile counts spill hundreds of registers there (687 ms per call at 256 x 784 integrals).  Pad them --
+// virtually: only the per-layer tile and K-step counts change, the staged images carry the zeros and the constant-one feature
+// of every layer stays at its own index width[l] -- to the smallest shape-exact family that holds the widest layer: (5 tiles,
+// 17 K-steps: widths up to 67) or (7, 26: up to 103).  A padded unit has zero weights and bias, so z = 0, act(0) = 0, and it
+// contributes exact zeros to every sum; d_theta is written for the real entries only.  Returns 1 if the net was padded.
+static int pad_to_exact_family(MlpDev& m, int* tmax, int* ksu) {
+    if (*tmax <= 4) return 0;
+    if (*ksu)
+        for (const BwdVariant& v : kBwdVariants)
+            if (v.ksc == *ksu && v.tmax == *tmax) return 0;
+    const int L = m.n_linear - 1;
+    int ksmax = 0;
+    for (int l = 1; l <= L; ++l) ksmax = m.ks_in[l] > ksmax ? m.ks_in[l] : ksmax;
+    static const int kFamilies[][2] = {{5, 17}, {7, 26}, {8, 32}};
+    for (const auto& f : kFamilies) {
+        if (*tmax > f[0] || ksmax > f[1]) continue;
+        for (int l = 1; l <= L; ++l) { m.t_out[l] = m.t_mfma[l] = f[0]; m.ks_in[l] = f[1]; }
+        int off = 0;
+        for (int l = 1; l < L; ++l) { m.lds_off[l] = off; off += m.t_out[l + 1] * m.ks_in[l] * 64; }
+        m.lds_off[L] = off;
+        *tmax = f[0]; *ksu = f[1];
+        return 1;
+    }
+    return 0;
 }
 
 // row stride for the row-major image: >= cols, minimising bank conflicts of both fragment shapes
@@ -668,11 +696,26 @@ struct BwdPlan {
     int nparts0, chunk0;
 };
 
-static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan* pl) {
+static int plan_backward_impl(const umnn_mlp* net, long long B, int d, int E, BwdPlan* pl, bool allow_pad, int* padded);
+static int plan_backward(const umnn_mlp* net, long long B, int d, int E, BwdPlan* pl, int* padded_out = nullptr) {
+    int padded = 0;
+    int rc = plan_backward_impl(net, B, d, E, pl, true, &padded);
+    if (rc == UMNN_EUNSUPPORTED && padded) {              // (the padded images of a deep net can exceed the LDS: the net's own counts then)
+        padded = 0;
+        rc = plan_backward_impl(net, B, d, E, pl, false, &padded);
+    }
+    if (padded_out) *padded_out = padded;
+    return rc;
+}
+
+static int plan_backward_impl(const umnn_mlp* net, long long B, int d, int E, BwdPlan* pl, bool allow_pad, int* padded) {
     int tmax = 0, ksu = 0;
     if (int rc = umnn_prepare_mlp(net, E, &pl->a.m, &tmax, &ksu)) return rc;
     BwdArgs& a = pl->a;
     const int L = a.m.n_linear - 1;
+    // (the three-stage kernels of cc_backward_front.hip take their shape first: they read the unpadded tile counts)
+    const bool front = umnn_options().bwd_precision == UMNN_PRECISION_BF16X3 && umnn_backward_front_shape(a.m);
+    *padded = (!front && allow_pad) ? pad_to_exact_family(a.m, &tmax, &ksu) : 0;
     pl->tmax = pick_tmax_bwd(tmax, ksu);
     pl->ksu = (ksu && tmax == pl->tmax) ? ksu : 0;
     int off = 0;
@@ -746,18 +789,25 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
 // Which kernel family umnn_cc_backward would use for this net: 1 = shape-exact kernels (compile-time tile counts),
 // 0 = generic kernels with at most four tiles per layer (runtime guards, ~2.5x slower), -1 = generic kernels with more
 // than four tiles -- those spill hundreds of registers per lane and are kept for completeness only: the Python host
-// routes such nets (mixed widths above 63) to the materialised ATen chain on the GPU instead.  < -1: error code.
+// routes such nets to the materialised ATen chain on the GPU instead.  Since round 3 that is only what is left when the zero-padded
+// weight images of a deep wide net do not fit the LDS: unequal widths of 64..127 run zero-padded on the 5- / 7- / 8-tile
+// shape-exact families (pad_to_exact_family) and report 1.  < -1: error code.
 extern "C" int umnn_cc_backward_kind(const umnn_mlp* net, int E) {
     MlpDev m;
     int tmax = 0, ksu = 0;
     if (int rc = umnn_prepare_mlp(net, E, &m, &tmax, &ksu)) return rc < -1 ? rc : -2;
+    // wide first hidden layer + narrow rest (MNISTExperiment's 100-50-50-50-50): the three-stage kernels of
+    // cc_backward_front.hip (bf16 arithmetic only)
+    if (umnn_backward_front_shape(m) && umnn_options().bwd_precision == UMNN_PRECISION_BF16X3) return 1;
+    {   // unequal widths of 5..8 tiles run zero-padded on a shape-exact family, if the padded weight images fit the LDS
+        BwdPlan pl;
+        int padded = 0;
+        if (plan_backward(net, 16, 1, E, &pl, &padded) == 0 && padded) pad_to_exact_family(m, &tmax, &ksu);
+    }
     const int T = pick_tmax_bwd(tmax, ksu);
     const int ks = (ksu && tmax == T) ? ksu : 0;
     const int nm = best_nacc(T, 1, ks);
     if (ks && nm >= 0 && find_bwd(T, nm, 1, ks)->ksc) return 1;
-    // wide first hidden layer + narrow rest (MNISTExperiment's 100-50-50-50-50): the three-stage kernels of
-    // cc_backward_front.hip (bf16 arithmetic only)
-    if (umnn_backward_front_shape(m) && umnn_options().bwd_precision == UMNN_PRECISION_BF16X3) return 1;
     return T <= 4 ? 0 : -1;
 }
 

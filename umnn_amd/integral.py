@@ -140,10 +140,11 @@ def set_backward_wide(force_hip):
 
 
 def _hip_backward_ok(spec, x, h):
-    """False for nets the HIP backward only covers with its register-spilling generic wide variants (several hidden
-    layers above 63 units of unequal width: 687 ms per call at 256x784 against ~190 ms for the materialised ATen chain on
-    the same GPU).  Nets with a wide FIRST hidden layer and a narrow rest (MNISTExperiment's 100-50-50-50-50) have the
-    three-stage kernels of cc_backward_front.hip.  ``UMNN_BWD_WIDE=hip`` forces the HIP kernels anyway."""
+    """False for nets the HIP backward only covers with its register-spilling generic wide variants: since round 3 only deep
+    nets whose zero-padded weight images exceed the LDS (four or more hidden layers above 103 units, five above 63) --
+    unequal widths up to 127 otherwise run the shape-exact fp32 kernels zero-padded (cc_backward.hip pad_to_exact_family),
+    and a wide FIRST hidden layer over a narrow rest (MNISTExperiment's 100-50-50-50-50) has the three-stage kernels of
+    cc_backward_front.hip.  ``UMNN_BWD_WIDE=hip`` forces the HIP kernels anyway."""
     if _BWD_WIDE["hip"]:
         return True
     E = h.shape[1] // x.shape[1]
@@ -155,7 +156,7 @@ def _hip_backward_ok(spec, x, h):
     if kind < 0:
         _warn_once(("bwd-aten", key[0]),
                    f"umnn_amd: the HIP backward has no shape-exact kernel for integrand widths {[w for _, w in key[0]]} "
-                   "(several unequal hidden layers above 63 units): differentiating with the materialised ATen chain on the "
+                   "(deep net of unequal wide hidden layers: its zero-padded weight images exceed the LDS): differentiating with the materialised ATen chain on the "
                    "GPU instead (forward stays on the HIP kernel; umnn_amd.set_backward_wide(True) forces the HIP kernels).")
     return kind >= 0
 
