@@ -249,7 +249,8 @@ def _fused_ok(a, layers, n_out=None):
     per SIMD: 12.92 vs 13.11 ms, 1.02 vs 1.34 ms), and feeding hipBLASLt's output GEMM from the kernel's hidden stack (mode 2,
     ``hybrid=True``) does not beat four short launches either (VAE 1.03 vs 1.11 ms, BSDS300 13.55 vs 13.58 ms); one launch per
     layer with the grid split over output tiles (mode 3) wins at launch-bound batch sizes (VAE at 1024 rows 1.00 -> 0.91 ms) and
-    ties with the library GEMMs at 8192 rows, so it is taken up to ``UMNN_MADE_LAYERED_MAX_ROWS`` rows (4096)."""
+    the hidden layers also at 8192 rows (C3: 140 -> 100 us per block with the 1890-column output layer back on split + hipBLASLt
+    above ``UMNN_MADE_LAYERED_LIB_OUT_ROWS`` = 4096 rows); taken up to ``UMNN_MADE_LAYERED_MAX_ROWS`` rows (32768)."""
     if not _FUSED["enabled"] or a.shape[0] > _FUSED["max_rows"] or len(layers) > 8:
         return 0
     if not all(l.in_features <= 512 for l in layers):
@@ -295,7 +296,10 @@ def _fused_chain(a, layers, last_rows=None, out_dtype=None, mode=1):
     return torch.mm(op, packed.t(), out_dtype=torch.float32)
 
 
-_LAYERED_MAX_ROWS = int(os.environ.get("UMNN_MADE_LAYERED_MAX_ROWS", "4096"))
+_LAYERED_MAX_ROWS = int(os.environ.get("UMNN_MADE_LAYERED_MAX_ROWS", "32768"))
+# above this many rows a wide OUTPUT layer goes back to split + library GEMM (hipBLASLt's large tiles win there: 67 + 9 us against
+# 97 us at 8192 x 512 x 1890), the hidden layers stay on made_linear_kernel (11-13 us against 9 + 23 us each)
+_LAYERED_LIB_OUT_ROWS = int(os.environ.get("UMNN_MADE_LAYERED_LIB_OUT_ROWS", "4096"))
 
 
 def _layered_chain(a, layers, last_rows=None, out_dtype=None, a2=None):
@@ -312,8 +316,13 @@ def _layered_chain(a, layers, last_rows=None, out_dtype=None, a2=None):
         stream = ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
         for i, layer in enumerate(layers):
             last = i == len(layers) - 1
-            frags, bias = layer.packed_fragments(last_rows if last else None)
             bf16 = last and out_dtype == torch.bfloat16
+            if last and i > 0 and B > _LAYERED_LIB_OUT_ROWS and layer.out_features > 512:
+                packed = layer.packed_bf16(last_rows)                   # [N, pad8(3K+2)]: the library route's weight operand
+                op = torch.empty(B, packed.shape[1], dtype=torch.bfloat16, device=a.device)
+                _lib.check(lib.umnn_made_split3(cur.data_ptr(), B, cur.shape[1], 1, op.data_ptr(), op.shape[1], stream), "made_split3")
+                return torch.mm(op, packed.t()) if bf16 else torch.mm(op, packed.t(), out_dtype=torch.float32)
+            frags, bias = layer.packed_fragments(last_rows if last else None)
             out = torch.empty(B, bias.shape[0], device=a.device, dtype=torch.bfloat16 if bf16 else torch.float32)
             K = cur.shape[1] + (0 if cur2 is None else cur2.shape[1])
             _lib.check(lib.umnn_made_linear_forward(frags.data_ptr(), bias.data_ptr(), K, bias.shape[0], cur.data_ptr(),
