@@ -105,7 +105,8 @@ for tag, title in (("bsds300", "C3 BSDS300-shaped eval (8192 x 63 integrals per 
     if tag.endswith("_train"):
         if tag.startswith("mnist"):     # three kernels per chunk share the backward's work: report each with its own counters
             for part, ttl in (("cc_front_fwd_kernel", "stage A: front forward (a1, z2 -> HBM)"),
-                              ("cc_bwd_bf16_kernel", "stage B: flagship kernel on the net from hidden layer 2 on (FRONT)"),
+                              ("cc_bwd_ws_kernel" if any("cc_bwd_ws_kernel" in r["Name"] for r in stats) else "cc_bwd_bf16_kernel",
+                               "stage B: flagship kernel on the net from hidden layer 2 on (FRONT; since round 3 the workgroup pipeline)"),
                               ("cc_front_bwd_kernel", "stage C: front backward (dG1, delta_1)")):
                 e = kernel_entry(stats, pmc, part, fl)
                 e["algorithmic_flops_per_launch"] = None
