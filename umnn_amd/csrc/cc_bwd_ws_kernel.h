@@ -403,8 +403,10 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         };
         WS_T(t1);
         // (only these sixteen registers differ for a tangent element: the branch stays outside the matrix loop)
+#ifndef UMNN_WS_EXP_NOVALU_CA              // (timing experiment only: layer 1 and its split skipped, results wrong)
         if (is_tan) swp_static_for<16>([&](auto ec) { layer1_reg(ec, std::true_type{}); });
         else swp_static_for<16>([&](auto ec) { layer1_reg(ec, std::false_type{}); });
+#endif
         __builtin_amdgcn_sched_barrier(0);
         swp_static_for<12>([&](auto nc) {
             constexpr int nn = decltype(nc)::value;
@@ -413,9 +415,11 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
             ws_dw_mfma<nn>(dW, ops);
 #endif
             // the split of a_1: two pairs per slot, stage by stage; then the stores
+#ifndef UMNN_WS_EXP_NOVALU_CA
             if constexpr (nn < 4) { pairF(std::integral_constant<int, 2 * nn>{}, std::integral_constant<int, 0>{}); pairF(std::integral_constant<int, 2 * nn + 1>{}, std::integral_constant<int, 0>{}); }
             if constexpr (nn >= 1 && nn < 5) { pairF(std::integral_constant<int, 2 * (nn - 1)>{}, std::integral_constant<int, 1>{}); pairF(std::integral_constant<int, 2 * (nn - 1) + 1>{}, std::integral_constant<int, 1>{}); }
             if constexpr (nn >= 2 && nn < 6) { pairF(std::integral_constant<int, 2 * (nn - 2)>{}, std::integral_constant<int, 2>{}); pairF(std::integral_constant<int, 2 * (nn - 2) + 1>{}, std::integral_constant<int, 2>{}); }
+#endif
             if constexpr (nn >= 5 && nn < 8) store_a(std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 5>{});
             if constexpr (nn >= 8 && nn < 11) store_a(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 8>{});
             __builtin_amdgcn_sched_barrier(0);
