@@ -112,6 +112,12 @@ __device__ __forceinline__ u32x2 ws_tr_read(const unsigned short* src) {
 #else
 #define WS_STEP_SYNC() __syncthreads()
 #endif
+#ifndef UMNN_WS_SLEEP_CA                     // s_sleep units (64 cycles) wave Ca waits after the step barrier (experiment: 0)
+#define UMNN_WS_SLEEP_CA 0
+#endif
+#ifndef UMNN_WS_ITEM_PREFETCH                // 1: the next tile's x, x0 and first 32 embedding columns are requested at the top of the step that
+#define UMNN_WS_ITEM_PREFETCH 0              //    ends the current tile (ten more live registers in wave Ca: spills 48-74, 13.1 vs 12.6 ms -- off)
+#endif
 #ifndef UMNN_WS_PREFETCH_B
 #define UMNN_WS_PREFETCH_B 1         // the a_l operands of the dW products (written steps ago) are fetched BEFORE the step barrier
 #endif
@@ -269,12 +275,35 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
                 if (j < NLIVE) { const float v = src[base + (size_t)jj * 64]; dst[t][r] = j < nl2 ? v : 0.f; }
             }
     };
-    auto new_item = [&]() __attribute__((always_inline)) {
+    // Opening a tile: x, x0 and the tile's 16 x E embedding values from HBM, c = b_1 + W_1[:, 1:] h on the fp32 matrix pipe.  The
+    // whole workgroup waits at the step barrier while this wave does that (a timing build that never re-opens, -DUMNN_WS_EXP_NONEWITEM,
+    // is 0.6 ms faster at C3), so everything loaded at the opening is issued in ONE batch of eight K-steps before the first product:
+    // one memory latency instead of eight, 12.86 -> 12.63 ms per launch, bit-identical.  Requesting the HBM part a step ahead
+    // (UMNN_WS_ITEM_PREFETCH) costs ten registers this wave does not have.
+    constexpr int NI_CH = 8, NI_A = UMNN_WS_ITEM_PREFETCH ? 4 : 8;   // K-steps of h fetched ahead / per trip; K-steps of W_1 per trip
+    float hv_n[NI_CH], xv_n = 0.f, x0v_n = 0.f;
+#pragma unroll
+    for (int q = 0; q < NI_CH; ++q) hv_n[q] = 0.f;
+    auto item_prefetch = [&](const WsCursor& c2) __attribute__((always_inline)) {
+        if constexpr (FRONT || !UMNN_WS_ITEM_PREFETCH) return;
+        const long long q0 = (long long)(args.grp0 + ws_grp(c2)) * 16 + p;
+        const long long qq = q0 < a.NI ? q0 : a.NI - 1;
+        xv_n = io_ld(a.x, qq, a.x_bf16);
+        x0v_n = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
+        const long long bi = qq / d;
+        const IoView hb = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
+#pragma unroll
+        for (int q = 0; q < NI_CH; ++q) {
+            const int e = 4 * q + g;
+            hv_n[q] = e < E ? hb[(long long)e * d] : 0.f;
+        }
+    };
+    auto new_item = [&]() __attribute__((always_inline)) {          // (item_prefetch of the same tile went before)
         if constexpr (FRONT) return;
-        const long long q = (long long)(args.grp0 + ws_grp(cu)) * 16 + p;
-        const long long qq = q < a.NI ? q : a.NI - 1;
-        xv = io_ld(a.x, qq, a.x_bf16);
-        x0v = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
+        const long long q0 = (long long)(args.grp0 + ws_grp(cu)) * 16 + p;
+        const long long qq = q0 < a.NI ? q0 : a.NI - 1;
+        if constexpr (UMNN_WS_ITEM_PREFETCH) { xv = xv_n; x0v = x0v_n; }
+        else { xv = io_ld(a.x, qq, a.x_bf16); x0v = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f; }
         dxv = xv - x0v;
         const long long bi = qq / d;
         const IoView hb = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
@@ -287,18 +316,31 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
                 const int f = feat_of(t, r, g);
                 c[t][r] = f < H1 ? b0[f] : (f == H1 ? 1.f : 0.f);
             }
-        for (int se = 0; se < (E + 3) / 4; ++se) {
-            const int e = 4 * se + g;
-            const float hv = e < E ? hb[(long long)e * d] : 0.f;
+        for (int se0 = 0; se0 < (E + 3) / 4; se0 += NI_A) {
+            float hv[NI_A], A[NI_A][BT];
 #pragma unroll
-            for (int t = 0; t < BT; ++t) {
-                const int fo = fout_of(t, p);
-                const float A = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
-                c[t] = mfma16(A, hv, c[t]);
+            for (int q = 0; q < NI_A; ++q) {
+                const int e = 4 * (se0 + q) + g;
+                hv[q] = (e < E && (!UMNN_WS_ITEM_PREFETCH || se0 + q >= NI_CH)) ? hb[(long long)e * d] : 0.f;
+#pragma unroll
+                for (int t = 0; t < BT; ++t) {
+                    const int fo = fout_of(t, p);
+                    A[q][t] = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NI_A; ++q) {
+                float hq = hv[q];
+                if constexpr (UMNN_WS_ITEM_PREFETCH) {
+#pragma unroll
+                    for (int q2 = 0; q2 < NI_CH; ++q2) hq = (se0 + q == q2) ? hv_n[q2] : hq;     // (the prefetched K-steps)
+                }
+#pragma unroll
+                for (int t = 0; t < BT; ++t) c[t] = mfma16(A[q][t], hq, c[t]);
             }
         }
     };
-    if (nit > 0) new_item();
+    if (nit > 0) { item_prefetch(cu); new_item(); }
     if constexpr (FRONT) { if (nit > 0) fetch_z(cu, zc); }
 
     float actF[BT][4];
@@ -341,6 +383,7 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         const int kn = ws_node(sh, nx);
         float ccs_n = 0.f;
         if constexpr (!FRONT) ccs_n = a.ccs[kn];
+        if (live && nx.j != cu.j && nx.j < nit) item_prefetch(nx);       // this step ends the tile: the next one's HBM loads now
         if constexpr (FRONT) {
             if (live && cu.e == 0) {
 #pragma unroll
@@ -447,7 +490,9 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
             const bool crossed = nx.j != cu.j;
             cu = nx;
             live = cu.j < nit;
+#ifndef UMNN_WS_EXP_NONEWITEM              // (timing experiment only: every tile reuses the first tile's item data, results wrong)
             if (crossed && live) new_item();
+#endif
             is_tan = live && ws_is_tan(sh, cu);
             if constexpr (FRONT) {
 #pragma unroll
@@ -470,6 +515,7 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         ws_adv<2, WS_P3>(rS4); ws_adv<2, WS_TILE>(rD4w);
         WS_T(t2);
         WS_STEP_SYNC();
+        if constexpr (UMNN_WS_SLEEP_CA > 0) __builtin_amdgcn_s_sleep(UMNN_WS_SLEEP_CA);
         WS_T(t3);
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
