@@ -98,16 +98,7 @@ __device__ __forceinline__ void front_prologue(const MlpDev& m, const IoView& hb
             const int f = feat_of(t, r, g);
             c[t][r] = f < H1 ? b0[f] : (f == H1 ? 1.f : 0.f);
         }
-    for (int se = 0; se < (E + 3) / 4; ++se) {
-        const int e = 4 * se + g;
-        const float hv = e < E ? hb[(long long)e * d] : 0.f;
-#pragma unroll
-        for (int t = 0; t < T1; ++t) {
-            const int fo = fout_of(t, p);
-            const float A = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
-            c[t] = mfma16(A, hv, c[t]);
-        }
-    }
+    item_embedding_gemm<T1, 4>(hb, W0, H1, E, d, g, p, c);
 }
 
 // out[BT] = G1-fragments x split(act[T1]) with NP pieces / the cross terms wa + ba < NP

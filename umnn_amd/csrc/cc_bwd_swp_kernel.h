@@ -242,16 +242,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
                     const int f = feat_of(t, r, g);
                     c[t][r] = f < H1 ? b0[f] : (f == H1 ? 1.f : 0.f);
                 }
-            for (int se = 0; se < (E + 3) / 4; ++se) {
-                const int e = 4 * se + g;
-                const float hv = e < E ? hb[(long long)e * d] : 0.f;
-#pragma unroll
-                for (int t = 0; t < BT; ++t) {
-                    const int fo = fout_of(t, p);
-                    const float A = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
-                    c[t] = mfma16(A, hv, c[t]);
-                }
-            }
+            item_embedding_gemm<BT, 8>(hb, W0, H1, E, d, g, p, c);
         }
         if (k_hi <= k_lo) {                             // (cannot happen: the launcher keeps ns <= n + 1)
             if (ok)

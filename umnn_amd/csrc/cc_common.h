@@ -75,6 +75,32 @@ struct IoView {          // read-only view of an fp32 or bf16 array: view[i], vi
     }
 };
 
+// c += W_1[:, 1:] h for one tile of 16 integrals (c = the per-tile constants of layer 1, feature-major accumulators of the fp32
+// MFMA; lane (g, p): K = embedding columns 4 se + g, output rows fout_of(t, p)).  CH K-steps per trip, ALL their loads (h from HBM,
+// W_1 from L2) issued before the first product: opening a tile costs one memory latency per trip, not one per K-step -- a wave
+// that opens a tile has nothing else to issue meanwhile (and in the workgroup pipeline seven other waves wait for it).
+template <int NT, int CH>
+__device__ __forceinline__ void item_embedding_gemm(const IoView& hb, const float* __restrict__ W0, int H1, int E, int d, int g, int p,
+                                                    f32x4 (&c)[NT]) {
+    for (int se0 = 0; se0 < (E + 3) / 4; se0 += CH) {
+        float hv[CH], A[CH][NT];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int e = 4 * (se0 + q) + g;
+            hv[q] = e < E ? hb[(long long)e * d] : 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int fo = fout_of(t, p);
+                A[q][t] = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) c[t] = mfma16(A[q][t], hv[q], c[t]);
+    }
+}
+
 // v_max_f32 without the canonicalising v_max(v,v) hipcc puts in front of fmaxf on MFMA results (fmaxf must quiet
 // signalling NaNs; the hardware instruction on already-finite data does not need it).  One VALU op instead of two.
 __device__ __forceinline__ float vmax_f32(float a, float b) {
