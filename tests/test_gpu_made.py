@@ -305,3 +305,26 @@ def test_made_linear_entry_point_over_grid_shapes_and_argument_errors(dev):
                                           a["K1"], a["B"], 0, out.data_ptr(), 0, a["rt"], a["fg"], stream)
         assert rc != 0 and lib.umnn_last_error(), bad
     assert lib.umnn_made_linear_forward(frags.data_ptr(), b.data_ptr(), K, N, x.data_ptr(), None, 0, 0, 0, out.data_ptr(), 0, 0, 0, stream) == 0
+
+
+def test_gather_indices_built_inside_a_capture_are_not_cached(dev):
+    """pack_fragments caches its gather indices per (N, K, device).  Inside a stream capture the kernels that fill them are only
+    RECORDED, so an index tensor cached from there holds nothing until that graph is replayed -- and a later eager call with the
+    same layer shape would gather with garbage (seen as x-independent conditioner outputs when a captured-but-never-replayed
+    GraphedLL came first in a process).  The cache must stay empty for shapes first met inside a capture."""
+    from umnn_amd import MADE, made as M
+    torch.manual_seed(5)
+    M._FRAG_INDEX.clear()
+    x = torch.randn(50, 7, device=dev)
+    first = MADE(7, [96, 96], 21, num_masks=1, natural_ordering=True).to(dev)
+    with torch.no_grad():
+        assert M._fast_path_ok(x)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            first.raw(x)                                   # recorded, never replayed
+    assert not any(k[0] == 96 and k[1] == 96 for k in M._FRAG_INDEX), "indices built under capture must not be cached"
+    second = MADE(7, [96, 96], 21, num_masks=1, natural_ordering=True).to(dev)
+    fast, slow = _both(lambda: second.raw(x))
+    assert (fast - slow).abs().max().item() <= 2e-5 * slow.abs().max().item()
+    assert any(k[0] == 96 and k[1] == 96 for k in M._FRAG_INDEX)      # (the eager call did cache them)

@@ -46,6 +46,15 @@ class GraphedLL:
                 for _ in range(self.warmup):
                     self._run()
             torch.cuda.current_stream(self.x.device).wait_stream(side)
+            # (the library probe of the conditioner's GEMM route must not run for the first time inside the capture -- with
+            #  warmup = 0 in a fresh process hipBLASLt would initialise under capture and abort)
+            made._fast_path_ok(self.x if self.x.dtype == torch.float32 else self.x.float())
+            # (likewise the quadrature tables: their host -> device upload is not capturable; warm-up runs create them, warmup = 0 does not)
+            from . import quadrature
+            for mod in self.model.modules():
+                n = getattr(mod, "nb_steps", None)
+                if isinstance(n, int) and n >= 1:
+                    quadrature.device_tables(n, self.x.device)
             self.graph = torch.cuda.CUDAGraph()
             with made.capture_may_cache(), torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
                 self.out = self._run()

@@ -146,9 +146,12 @@ def pack_fragments(W):
         k = 32 * torch.arange(S, device=W.device).view(1, S, 1, 1) + (16 * (j >> 2) + (j & 3)).view(1, 1, 1, 8) \
             + 4 * g.view(1, 1, 64, 1)                                                                            # [1,S,64,8]
         idx = (n.expand(T, S, 64, 8) * (32 * S) + k.expand(T, S, 64, 8)).reshape(-1)
-        if len(_FRAG_INDEX) > 64:
-            _FRAG_INDEX.clear()
-        _FRAG_INDEX[key] = idx
+        # (never cached from inside a stream capture: the kernels that fill it have only been RECORDED then -- the tensor holds
+        #  nothing until that graph is replayed, and an eager call that found it in the cache would gather with garbage)
+        if not (W.is_cuda and torch.cuda.is_current_stream_capturing()):
+            if len(_FRAG_INDEX) > 64:
+                _FRAG_INDEX.clear()
+            _FRAG_INDEX[key] = idx
     Wp = torch.zeros(16 * T, 32 * S, dtype=torch.float32, device=W.device)
     Wp[:N, :K] = W
     frag = Wp.reshape(-1).index_select(0, idx).view(T, S, 64, 8)
