@@ -15,6 +15,19 @@ def _capture_mode():
     return "thread_local" if dist.is_available() and dist.is_initialized() else "global"
 
 
+def _prime_for_capture(model, x):
+    """What must exist BEFORE a capture whatever ``warmup`` is: the library probe of the conditioner's GEMM route (run for the first
+    time inside a capture, hipBLASLt would initialise under capture and abort) and the quadrature tables of every block (their host
+    -> device upload is not capturable).  Warm-up runs create both; ``warmup=0`` in a fresh process does not."""
+    from . import made, quadrature
+    with torch.no_grad():
+        made._fast_path_ok(x if x.dtype == torch.float32 else x.float())
+    for mod in model.modules():
+        n = getattr(mod, "nb_steps", None)
+        if isinstance(n, int) and n >= 1:
+            quadrature.device_tables(n, x.device)
+
+
 class GraphedLL:
     """``GraphedLL(model, x_example)(x)`` -> the captured ``(ll, z)`` tensors (overwritten by the next call).
 
@@ -46,15 +59,7 @@ class GraphedLL:
                 for _ in range(self.warmup):
                     self._run()
             torch.cuda.current_stream(self.x.device).wait_stream(side)
-            # (the library probe of the conditioner's GEMM route must not run for the first time inside the capture -- with
-            #  warmup = 0 in a fresh process hipBLASLt would initialise under capture and abort)
-            made._fast_path_ok(self.x if self.x.dtype == torch.float32 else self.x.float())
-            # (likewise the quadrature tables: their host -> device upload is not capturable; warm-up runs create them, warmup = 0 does not)
-            from . import quadrature
-            for mod in self.model.modules():
-                n = getattr(mod, "nb_steps", None)
-                if isinstance(n, int) and n >= 1:
-                    quadrature.device_tables(n, self.x.device)
+            _prime_for_capture(self.model, self.x)
             self.graph = torch.cuda.CUDAGraph()
             with made.capture_may_cache(), torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
                 self.out = self._run()
@@ -141,6 +146,7 @@ class GraphedTrainStep:
             for _ in range(warmup):
                 one_step()
         torch.cuda.current_stream(x_example.device).wait_stream(side)
+        _prime_for_capture(model, x_example)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             self.loss = one_step()
