@@ -9,7 +9,7 @@ torch.manual_seed(7)
 m = umnn_amd.UMNNMAFFlow(nb_flow=2, nb_in=8, hidden_derivative=[50, 50, 50, 50], hidden_embedding=[64, 64], embedding_s=10, nb_steps=20, solver="CCParallel").to(dev).train()
 x = (torch.randn(2100, 8, device=dev) * 0.8).requires_grad_()
 res = {}
-for key in ("ws", "swp", "fp32bwd", "fp32all", "generic"):
+for key in ("ws16", "ws", "swp", "fp32bwd", "fp32all", "generic"):
     m.zero_grad(set_to_none=True); x.grad = None
     if key == "generic":
         with I.force_generic():
@@ -17,7 +17,7 @@ for key in ("ws", "swp", "fp32bwd", "fp32all", "generic"):
     else:
         _lib.set_backward_precision("fp32" if key.startswith("fp32") else "bf16x3")
         umnn_amd.set_forward_precision("fp32" if key == "fp32all" else "bf16x3")
-        with _lib.options(bwd_ws=1 if key == "ws" else 0):
+        with _lib.options(bwd_ws=1 if key.startswith("ws") else 0, bwd_ws16=1 if key == "ws16" else 0):
             ll, _ = m.compute_ll(x); (-ll.mean()).backward()
         _lib.set_backward_precision("bf16x3"); umnn_amd.set_forward_precision("bf16x3")
     res[key] = {"x": x.grad.detach().double().clone(), **{k: p.grad.detach().double().clone() for k, p in m.named_parameters() if p.grad is not None}}

@@ -27,19 +27,19 @@ for (B, d, E, hid, n, gfx) in CASES:
     h, gg = torch.randn(B, E * d, device=dev), torch.randn(B, d, device=dev)
     gf = torch.randn(B, d, device=dev) if gfx else None
     outs = {}
-    for key, ws, prec in (("swp", 0, "bf16x3"), ("ws", 1, "bf16x3"), ("fp32", 0, "fp32")):
+    for key, ws, prec in (("swp", 0, "bf16x3"), ("ws", 1, "bf16x3"), ("ws16", 2, "bf16x3"), ("fp32", 0, "fp32")):
         _lib.set_backward_precision(prec)
-        with _lib.options(bwd_ws=ws):
+        with _lib.options(bwd_ws=int(ws > 0), bwd_ws16=int(ws == 2)):
             outs[key] = I.hip_backward(spec, x0, x, h, gg, gf, n)
             torch.cuda.synchronize()
         print(key, _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode(), flush=True)
     _lib.set_backward_precision("bf16x3")
     for name, i in (("dx0", 0), ("dx", 1), ("dh", 2), ("dtheta", 3)):
-        a, b, r = outs["swp"][i], outs["ws"][i], outs["fp32"][i]
+        a, b, c, r = outs["swp"][i], outs["ws"][i], outs["ws16"][i], outs["fp32"][i]
         sc = float(r.abs().max())
         print(f"  {hid} B={B} {name:7s} |ws-swp|/max {float((a - b).abs().max()) / sc:.3e}   |swp-fp32| {float((a - r).abs().max()) / sc:.3e}"
-              f"   |ws-fp32| {float((b - r).abs().max()) / sc:.3e}   nan {bool(torch.isnan(b).any())}", flush=True)
-    dd = (outs["swp"][3] - outs["ws"][3]).abs()
+              f"   |ws-fp32| {float((b - r).abs().max()) / sc:.3e}   |ws16-fp32| {float((c - r).abs().max()) / sc:.3e}   nan {bool(torch.isnan(c).any())}", flush=True)
+    dd = (outs["fp32"][3] - outs["ws16"][3]).abs()
     o = 0
     for li, l in enumerate(spec.linears):
         a0, a1, a2 = o, o + l.weight.numel(), o + l.weight.numel() + l.bias.numel()
@@ -55,8 +55,8 @@ net = umnn_amd.IntegrandNetwork(d, 1 + E, hid, 1).to(dev)
 spec = mlp_spec(net)
 x, h, g = torch.randn(B, d, device=dev), torch.randn(B, E * d, device=dev), torch.randn(B, d, device=dev)
 gf = torch.randn(B, d, device=dev)
-for ws in (0, 1, 0, 1):
-    with _lib.options(bwd_ws=ws):
+for ws in (1, 2, 1, 2):
+    with _lib.options(bwd_ws=int(ws > 0), bwd_ws16=int(ws == 2)):
         I.hip_backward(spec, None, x, h, g, gf, n)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

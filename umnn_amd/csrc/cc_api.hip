@@ -92,12 +92,14 @@ static void load_env(UmnnOptions& o) {
     int v = env_int("UMNN_FWD_P", -1); o.fwd_p = v == 1 || v == 2 ? v : -1;
     v = env_int("UMNN_FWD_NS", -1); o.fwd_ns = v == 1 || v == 2 || v == 4 ? v : -1;
     v = env_int("UMNN_FWD_TAIL", -1); o.fwd_tail = v < 0 ? -1 : (v != 0);
-    o.fwd_pipe = env_int("UMNN_FWD_PIPE", 1);          // 0 plain loop, 1 pipelined 16x16x32 loop, 2 the 32x32x16 formulation (experimental)
+    // (every stored value must round-trip through umnn_set_option: out-of-range environment values fall back to the default)
+    v = env_int("UMNN_FWD_PIPE", 1); o.fwd_pipe = v >= 0 && v <= 2 ? v : 1;   // 0 plain loop, 1 pipelined 16x16x32 loop, 2 the 32x32x16 formulation
     o.fwd_pad = env_int("UMNN_FWD_PAD", 1) != 0;
-    o.fwd_pad_min = env_int("UMNN_FWD_PAD_MIN", 1);
+    v = env_int("UMNN_FWD_PAD_MIN", 1); o.fwd_pad_min = v >= 0 && v <= 127 ? v : 1;
     v = env_int("UMNN_BWD_NS", -1); o.bwd_ns = v >= 1 && v <= 32 ? v : -1;
     o.bwd_swp = env_int("UMNN_BWD_SWP", 1) != 0;
     o.bwd_ws = env_int("UMNN_BWD_WS", 1) != 0;
+    o.bwd_ws16 = env_int("UMNN_BWD_WS16", 1) != 0;
 }
 UmnnOptions& umnn_options() {
     static UmnnOptions opts;
@@ -121,6 +123,7 @@ static std::atomic<int>* option_slot(const char* name) {
     if (!strcmp(name, "bwd_ns")) return &o.bwd_ns;
     if (!strcmp(name, "bwd_swp")) return &o.bwd_swp;
     if (!strcmp(name, "bwd_ws")) return &o.bwd_ws;
+    if (!strcmp(name, "bwd_ws16")) return &o.bwd_ws16;
     return nullptr;
 }
 // the same per-option ranges load_env accepts (anything else would reach the launchers as "no such variant")
@@ -136,6 +139,7 @@ static bool option_value_ok(const char* name, int v) {
     if (!strcmp(name, "bwd_ns")) return v == -1 || (v >= 1 && v <= 32);
     if (!strcmp(name, "bwd_swp")) return v == 0 || v == 1;
     if (!strcmp(name, "bwd_ws")) return v == 0 || v == 1;
+    if (!strcmp(name, "bwd_ws16")) return v == 0 || v == 1;
     return true;
 }
 extern "C" int umnn_set_option(const char* name, int value) {

@@ -691,6 +691,7 @@ struct BwdPlan {
     int ns;            // node-range split of the fp32 kernels (small batches: fewer tiles than waves)
     size_t lds_bytes_for(int nacc, int waves) const { return (size_t)(a.scratch_off + waves * (nacc + 1) * tmax * 256) * sizeof(float); }
     long long ws_partials, ws_dc, ws_p0;   // byte offsets in the workspace
+    long long ws_scal;                     // 256 B of launch scalars (cc_bwd_ws16_kernel.h)
     long long ws_front, ws_front_bytes;    // HBM scratch of the staged backward (wide first hidden layer), 0 if not that family
     long long ws_total;
     int nparts0, chunk0;
@@ -767,6 +768,7 @@ static int plan_backward_impl(const umnn_mlp* net, long long B, int d, int E, Bw
     pl->ws_partials = o; o += (long long)pl->nwaves * a.n_params * 4; o = (o + 255) & ~255LL;
     pl->ws_dc = o; o += a.NI * H1 * 4 * pl->ns; o = (o + 255) & ~255LL;
     pl->ws_p0 = o; o += (long long)pl->nparts0 * H1 * (E + 1) * 4; o = (o + 255) & ~255LL;
+    pl->ws_scal = o; o += 256;
     pl->ws_front = o;
     // (only the bf16x3 staged kernels use it: under bwd_precision = fp32 the reservation would be a dead 2 GiB per call)
     pl->ws_front_bytes = (umnn_options().bwd_precision == UMNN_PRECISION_BF16X3 && umnn_backward_front_shape(a.m) && pl->wpb == 4)
@@ -850,6 +852,7 @@ extern "C" int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const
     a.inv_f = inv_f != 0;
     a.partials = (float*)(ws + pl.ws_partials);
     a.dc = (float*)(ws + pl.ws_dc);
+    a.scal = (unsigned*)(ws + pl.ws_scal);
     float* p0 = (float*)(ws + pl.ws_p0);
     if (int rc = umnn_check(hipMemsetAsync(a.partials, 0, (size_t)pl.nwaves * a.n_params * 4, stream), "memset partials")) return rc;
 

@@ -4,6 +4,7 @@
 #include "cc_bwd_bf16_kernel.h"
 #include "cc_bwd_swp_kernel.h"
 #include "cc_bwd_ws_kernel.h"
+#include "cc_bwd_ws16_kernel.h"
 
 // ------------------------------------------------------------------------------------------
 typedef void (*bwd_bf16_kernel_t)(const BwdBf16Args);
@@ -31,6 +32,11 @@ static const BwdWsVariant kBwdWsVariants[] = {
     { 13, cc_bwd_ws_kernel<13>, "cc_bwd_bf16<L=4,LIVE=13,WS>" },
     { 0, cc_bwd_ws_kernel<0>, "cc_bwd_bf16<L=4,LIVE=0,WS>" },
 };
+// the same pipeline on fp16 pieces (cc_bwd_ws16_kernel.h): three-term recompute, scaled cotangents, overflow flag + queued fallback
+static const BwdWsVariant kBwdWs16Variants[] = {
+    { 13, cc_bwd_ws16_kernel<13>, "cc_bwd_f16<L=4,LIVE=13,WS>" },
+    { 0, cc_bwd_ws16_kernel<0>, "cc_bwd_f16<L=4,LIVE=0,WS>" },
+};
 
 // Plans and launches the main backward pass with the bf16 kernels.  Returns UMNN_EUNSUPPORTED when the shape is
 // outside this family (caller falls back to the fp32 kernels).
@@ -39,6 +45,7 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
     BwdBf16Args args;
     args.b = base;
     args.z2 = nullptr; args.d2 = nullptr; args.tz2 = nullptr; args.grp0 = 0; args.nl2 = 0; args.accumulate = 0;
+    args.scal = nullptr; args.only_if = nullptr;
     BwdArgs& a = args.b;
     const int L = a.m.n_linear - 1;
     if (L < 2 || L - 1 > 3) return UMNN_EUNSUPPORTED;
@@ -63,6 +70,51 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
             *nwaves_out = nblocks;                  // one d_theta slice per workgroup
             a.l_lo = 1;
             if (int rc = umnn_allow_lds((const void*)wv->fn, lds_ws)) return rc;
+            // fp16 pieces (default): cotangent scale first, then the pipeline, then the bf16 pipeline queued behind it as the
+            // fallback that only runs if a piece overflowed (same outputs, rewritten).  1/f launches keep the bf16 pipeline.
+            const BwdWsVariant* hv = nullptr;
+            if (umnn_options().bwd_ws16 && !a.inv_f && a.scal)
+                for (const BwdWsVariant& c : kBwdWs16Variants)
+                    if (c.nrl == nrl) { hv = &c; break; }
+            if (hv) {
+                const size_t lds16b = (size_t)W16_LDS_USHORTS * sizeof(unsigned short);
+                if (int rc = umnn_allow_lds((const void*)hv->fn, lds16b)) return rc;
+                args.scal = a.scal;
+                umnn_prof_begin(stream);
+                if (int rc = umnn_check(hipMemsetAsync(a.scal, 0, sizeof(Ws16Scal), stream), "memset launch scalars")) return rc;
+                const long long want = (a.NI + 255) / 256;
+                const unsigned nbm = (unsigned)(want < 4LL * nblocks_max ? want : 4LL * nblocks_max);
+                hipLaunchKernelGGL(cc_bwd_cotmax_kernel, dim3(nbm), dim3(256), 0, stream, a, reinterpret_cast<Ws16Scal*>(a.scal));
+#ifdef UMNN_WS_TIMING
+                static double* tbuf16 = nullptr;
+                const int nw16 = nblocks * WS_WAVES;
+                if (!tbuf16) hipMalloc(&tbuf16, sizeof(double) * 6 * 8192);
+                hipMemsetAsync(tbuf16, 0, sizeof(double) * 6 * nw16, stream);
+                args.tz2 = reinterpret_cast<const float*>(tbuf16);
+#endif
+                hipLaunchKernelGGL(hv->fn, dim3(nblocks), dim3(64 * WS_WAVES), lds16b, stream, args);
+#ifdef UMNN_WS_TIMING
+                {
+                    hipStreamSynchronize(stream);
+                    static double host[6 * 8192];
+                    hipMemcpy(host, tbuf16, sizeof(double) * 6 * nw16, hipMemcpyDeviceToHost);
+                    const char* role[8] = {"Ca", "F1", "F2", "F3", "Cb", "B1", "B2", "B3"};
+                    for (int r = 0; r < WS_WAVES; ++r) {
+                        double sm[6] = {0};
+                        for (int w = r; w < nw16; w += WS_WAVES) for (int j = 0; j < 6; ++j) sm[j] += host[6 * w + j];
+                        const double st = sm[4] > 0 ? sm[4] : 1;
+                        fprintf(stderr, "WS16_TIMING %s per step (s_memtime ticks): prep %.0f | work to the %d %% mark %.0f | rest of the work %.0f | barrier wait %.0f   (steps per wave %.0f)\n",
+                                role[r], sm[0] / st, UMNN_WS_TRACE_FRAC, sm[1] / st, sm[2] / st, sm[3] / st, sm[4] / (nw16 / WS_WAVES));
+                    }
+                    args.tz2 = nullptr;
+                }
+#endif
+                args.only_if = &reinterpret_cast<Ws16Scal*>(a.scal)->flag;
+                hipLaunchKernelGGL(wv->fn, dim3(nblocks), dim3(64 * WS_WAVES), lds_ws, stream, args);
+                umnn_prof_end(stream, 3.0 * umnn_cc_forward_flops_per_integral(net, a.n) * (double)a.NI, UMNN_PROF_BACKWARD);
+                umnn_note_launch(hv->name);
+                return umnn_check(hipGetLastError(), "cc_bwd_f16 (ws) launch");
+            }
 #ifdef UMNN_WS_TIMING
             static double* tbuf = nullptr;
             const int nw = nblocks * WS_WAVES;

@@ -526,6 +526,7 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
     // ---- the middle stage sees the net from hidden layer 2 on
     BwdBf16Args mid;
     mid.b = base;
+    mid.scal = nullptr; mid.only_if = nullptr;
     {
         MlpDev& s = mid.b.m;
         s.n_linear = m.n_linear - 1;

@@ -41,6 +41,8 @@ struct BwdBf16Args {
     int nl2;                         // live registers of that layer: ceil((H2 + 1) / 4)
     int accumulate;                  // d_theta slices: 0 overwrite (first chunk), 1 add
     int off_trtile;                  // ushort offset in LDS of the per-wave transpose tiles (one-pass kernels)
+    unsigned* scal;                  // launch scalars of the fp16-piece pipeline (Ws16Scal, cc_bwd_ws16_kernel.h); nullable
+    const unsigned* only_if;         // non-null: the kernel runs only if *only_if != 0 (the queued fallback behind the fp16-piece pipeline)
 };
 
 // fragment (tile t, K-step s, piece) of W (TRANSPOSED = false: rows = out features, K = in features incl. the

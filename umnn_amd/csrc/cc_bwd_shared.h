@@ -31,6 +31,7 @@ struct BwdArgs {
     int n_params;
     int scratch_off;                // float offset of the per-wave scratch region in LDS
     int scratch_per_wave;           // floats
+    unsigned* scal;                 // 256 B of launch scalars in the workspace (cotangent scale / overflow flag of cc_bwd_ws16_kernel.h)
 };
 
 // permutation that turns an accumulator row (lane&15 in an A operand) into a feature offset inside a tile

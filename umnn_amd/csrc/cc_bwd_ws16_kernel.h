@@ -1,0 +1,927 @@
+// Weight-stationary workgroup-pipeline backward on fp16 PIECES (round 4).  Same pipeline, roles, LDS tiles and timetable as
+// cc_bwd_ws_kernel.h (read its header first); what changes is the number format of everything that crosses the matrix cores
+// (reference lines: ParallelNeuralIntegral.py:66-94,110-123).
+//
+// Why.  The backward needs the SIGN of every hidden pre-activation (LeakyReLU / ReLU kinks), so its forward recompute has to be
+// fp32-accurate.  On bf16 pieces (8 significand bits) that takes THREE pieces and six cross terms: 48 of the 72 GEMM MFMAs of a
+// tile-node and layer.  An fp16 piece carries 11 bits: two pieces hold 22 bits of a value, and the three products
+// hi*hi + hi*lo + lo*hi are exact fp16 x fp16 -> fp32 products that miss only lo*lo (2^-22 of the term) -- measured on the matrix
+// core (tools/ubench/f16_split.hip): 4.8e-8 of the sum of |terms| for K = 32, BETTER than an fp32 fma chain (7.8e-8); subnormal
+// low pieces are kept by v_mfma_f32_16x16x32_f16 (probed there), so the absolute error of a piece pair is <= max(2^-22 |a|, 2^-25).
+// The recompute therefore drops from 48 to 24 MFMAs per layer, the forward weights from 96 to 64 registers, the activation tiles
+// lose their third-piece companions (13.5 KB of LDS), and the split of an activation pair is FOUR instructions
+// (v_cvt_pk_f16_f32, two v_fma_mix_f32 that subtract the packed halves straight from the fp32 values, v_cvt_pk_f16_f32) instead
+// of eleven.  The delta chain and the dW products run on the same two fp16 pieces (three terms each, as before on bf16).
+//
+// Range.  fp16 has five exponent bits.  Activations and weights of these nets are O(1e-3 .. 1e2): inside it, with subnormal low
+// pieces below 2^-3 (absolute error 2^-25, see above).  Cotangents are not: delta = g (x - x0)/2 w_k f'(..) w_out .. is ~1e-8
+// for a mean log-likelihood over 8192 rows.  They are therefore carried SCALED by a power of two sigma chosen per launch from
+// max |g (x - x0) / 2| max_k w_k + max |g_fx| (cc_bwd_cotmax_kernel, one pass over g, x, x0 ahead of this kernel; sigma puts that
+// maximum at 2^WS16_T): wave F3 multiplies the per-integral cotangent base by sigma once per tile, everything downstream is linear
+// in it, and dc, d_theta leave multiplied by 1 / sigma (exact: powers of two).  Elements more than 2^-(WS16_T + 3) below the
+// launch's largest root cotangent lose relative precision gracefully (one bit per binade; the absolute error stays 2^-25 sigma^-1,
+// i.e. 2^-(25 + WS16_T) of the largest cotangent) -- they are the ones that do not matter to d_theta, and for d_h / d_x of their
+// own rows the error is still below 2^-16 relative down to 2^-(WS16_T + 9) of the maximum.
+// Overflow (|a_l| or |sigma delta_l| >= 65520) cannot be excluded for arbitrary weights, so it is DETECTED, not assumed away: an
+// overflowing piece is +-inf, which reaches the output-layer sum of wave F3 (activations) or the dc sum of wave B1 (cotangents)
+// as inf / NaN; both are checked (one compare per step / per tile) and raise a device flag, and the launcher queues the bf16
+// kernel of cc_bwd_ws_kernel.h right behind this one with "run only if the flag is set": same outputs, rewritten.  inv_f launches
+// (cotangent x -1/f^2, unbounded) and the FRONT middle stage stay on the bf16 kernel.
+#pragma once
+#include "cc_bwd_ws_kernel.h"
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+#ifndef WS16_T
+#define WS16_T 8                                  // the launch's largest root cotangent lands in [2^(T-1), 2^T)
+#endif
+constexpr int W16_NP = 2;                         // fp16 pieces of every matrix operand (three cross terms)
+constexpr int W16_OFF_S4 = WS_OFF_P3;             // (no third-piece tiles: the S4 tiles follow the cotangent tiles)
+constexpr int W16_LDS_USHORTS = W16_OFF_S4 + 2 * WS_P3;
+constexpr int W16_IMG = BT * BKS * W16_NP * FRAG; // staging image of one weight matrix (start of the launch only)
+static_assert(6 * W16_IMG <= W16_LDS_USHORTS, "the staging images must fit the tile area");
+
+// device scalars of a launch (workspace): filled by cc_bwd_cotmax_kernel, read by every role that scales
+struct Ws16Scal { unsigned cotmax, gfxmax, wmax, flag; };
+
+__device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ ws_f32x16 ws16_mfma32(u32x4 a, u32x4 b, ws_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+// first stage of the two-piece split of a pair: returns the packed leading pieces (round to nearest even), leaves the EXACT
+// remainders in x0 / x1 -- v_fma_mix_f32 reads an f16 half of a register as a source operand, so no unpacking instruction
+__device__ __forceinline__ unsigned h16_split_stage(float& x0, float& x1) {
+    const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, h16x2));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(x0) : "v"(bits));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x1) : "v"(bits));
+    return bits;
+}
+__device__ __forceinline__ unsigned h16_split_last(float x0, float x1) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, h16x2));
+}
+template <int NRL>
+__device__ __forceinline__ void h16_split_regs(const f32x4 (&act)[BT], BFrag<W16_NP>& bf) {
+    constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
+#pragma unroll
+    for (int s = 0; s < BKS; ++s) {
+        unsigned q[4][W16_NP];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            q[j][0] = q[j][1] = 0u;
+            if (8 * s + 2 * j < NLIVE) {
+                float x0 = act[2 * s + (j >> 1)][2 * (j & 1)], x1 = act[2 * s + (j >> 1)][2 * (j & 1) + 1];
+                q[j][0] = h16_split_stage(x0, x1);
+                q[j][1] = h16_split_last(x0, x1);
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < W16_NP; ++k2) bf.v[s][k2] = u32x4{q[0][k2], q[1][k2], q[2][k2], q[3][k2]};
+    }
+}
+
+// fragment image of W_l (rows = out features, K = in features incl. the constant-one feature / bias column) or of W_l^T
+// (rows = in features, K = out features, nothing through the constant feature) as two fp16 pieces: the index arithmetic of
+// stage_frag_image (cc_bwd_bf16_kernel.h), the pieces of this file
+template <bool TRANSPOSED>
+__device__ __forceinline__ void ws16_stage_image(const MlpDev& m, int l, unsigned short* img, int tid, int nthreads) {
+    const int Hin = m.width[l], Hout = m.width[l + 1];
+    const float* __restrict__ W = m.W[l];
+    const float* __restrict__ b = m.b[l];
+    for (int idx = tid; idx < BT * BKS * FRAG; idx += nthreads) {
+        const int j = idx & 7, ln = (idx >> 3) & 63, ts = idx >> 9;
+        const int s = ts % BKS, t = ts / BKS;
+        const int frow = fout_of(t, ln & 15);
+        const int fk = feat_of(2 * s + (j >> 2), j & 3, ln >> 4);
+        float v = 0.f;
+        if (!TRANSPOSED) {
+            const int fo = frow, fi = fk;
+            if (fo < Hout) {
+                if (fi < Hin) v = W[fo * Hin + fi];
+                else if (fi == Hin) v = b[fo];
+            } else if (fo == Hout && fi == Hin) {
+                v = 1.f;
+            }
+        } else {
+            const int fi = frow, fo = fk;
+            if (fo < Hout && fi < Hin) v = W[fo * Hin + fi];
+        }
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        img[(ts * W16_NP + 0) * FRAG + ln * 8 + j] = __builtin_bit_cast(unsigned short, hi);
+        img[(ts * W16_NP + 1) * FRAG + ln * 8 + j] = __builtin_bit_cast(unsigned short, lo);
+    }
+}
+
+// sigma = 2^(WS16_T - ceil(log2 R)), R = the launch's largest root cotangent; 1 when there is nothing to scale
+__device__ __forceinline__ float ws16_sigma(const Ws16Scal* sc, float& inv_sigma) {
+    const float R = fmaf(__uint_as_float(sc->cotmax), __uint_as_float(sc->wmax), __uint_as_float(sc->gfxmax));
+    int se = 127;
+    if (R > 0.f && R < __builtin_inff()) {
+        const int e = (int)((__float_as_uint(R) >> 23) & 0xffu);        // R in [2^(e-127), 2^(e-126))
+        se = 127 + WS16_T - (e - 126);
+        se = se < 8 ? 8 : (se > 246 ? 246 : se);                        // (sigma and 1 / sigma both normal)
+    }
+    inv_sigma = __uint_as_float((unsigned)(254 - se) << 23);
+    return __uint_as_float((unsigned)se << 23);
+}
+__device__ __forceinline__ bool ws16_finite(float v) { return __builtin_fabsf(v) < __builtin_inff(); }
+
+// max |g (x - x0) / 2|, max |g_fx| over the integrals and max |w_k| over the nodes, as the bit patterns of non-negative floats
+// (which order like unsigned integers): order-independent, so the result -- and with it sigma -- is deterministic
+__global__ __launch_bounds__(256) void cc_bwd_cotmax_kernel(const BwdArgs a, Ws16Scal* sc) {
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < a.NI; q += (long long)gridDim.x * blockDim.x) {
+        const float xv = io_ld(a.x, q, a.x_bf16), x0v = a.x0 ? io_ld(a.x0, q, a.x_bf16) : 0.f;
+        m0 = fmaxf(m0, fabsf(io_ld(a.g, q, a.x_bf16) * (xv - x0v) * 0.5f));
+        if (a.gfx) m1 = fmaxf(m1, fabsf(io_ld(a.gfx, q, a.x_bf16)));
+    }
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k <= a.n; k += blockDim.x) m2 = fmaxf(m2, fabsf(a.ccw[k]));
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        m0 = fmaxf(m0, __shfl_xor(m0, o));
+        m1 = fmaxf(m1, __shfl_xor(m1, o));
+        m2 = fmaxf(m2, __shfl_xor(m2, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        // (a non-finite cotangent has the largest bit pattern: sigma falls back to 1 and the run ends in the flag)
+        atomicMax(&sc->cotmax, __float_as_uint(m0));
+        if (a.gfx) atomicMax(&sc->gfxmax, __float_as_uint(m1));
+        if (blockIdx.x == 0) atomicMax(&sc->wmax, __float_as_uint(m2));
+    }
+}
+
+// the 12 matrix instructions of one dW layer on fp16 operands (cross terms outermost, as ws_dw_mfma)
+template <int IDX>
+__device__ __forceinline__ void ws16_dw_mfma(ws_f32x16 (&dW)[2][2], const WsOps& o) {
+    constexpr int term = IDX / 4, to = (IDX % 4) / 2, ti = IDX % 2;
+    constexpr int pa = term == 2 ? 1 : 0, pb = term == 1 ? 1 : 0;
+    dW[to][ti] = ws16_mfma32(o.A[to][pa], o.B[ti][pb], dW[to][ti]);
+}
+// this workgroup's d_theta slice (layout: ws_write_dw), the accumulators un-scaled on the way out
+__device__ __forceinline__ void ws16_write_dw(const BwdArgs& a, float* part, int l, const ws_f32x16 (&dW)[2][2], int lane, float inv_sigma) {
+    const MlpDev& m = a.m;
+    const int Hin = m.width[l], Hout = m.width[l + 1];
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int fo = slot_feature(32 * to + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3));
+                const int fi = slot_feature(32 * ti + (lane & 31));
+                if (fo < Hout) {
+                    const int idx = fi < Hin ? a.poffW[l] + fo * Hin + fi : (fi == Hin ? a.poffb[l] + fo : -1);
+                    if (idx >= 0) part[idx] = dW[to][ti][v] * inv_sigma;
+                }
+            }
+}
+__device__ __forceinline__ void ws16_zero_dw(ws_f32x16 (&dW)[2][2]) {
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) dW[to][ti][v] = 0.f;
+}
+__device__ __forceinline__ void ws16_clear_tiles(unsigned short* lds16) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < W16_LDS_USHORTS / 8; i += blockDim.x) reinterpret_cast<u32x4*>(lds16)[i] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+}
+#define W16_LOAD_B(ops, At) do { ws_load_op<4>(ops, At, At); ws_load_op<6>(ops, At, At); ws_load_op<5>(ops, At, At); ws_load_op<7>(ops, At, At); } while (0)
+#define W16_LOAD_A(ops, Dt) do { ws_load_op<0>(ops, Dt, Dt); ws_load_op<2>(ops, Dt, Dt); ws_load_op<1>(ops, Dt, Dt); ws_load_op<3>(ops, Dt, Dt); } while (0)
+
+// ============================================================================================================ wave Ca
+// layer 1 (a_1 of a new tile-node per step, two fp16 pieces -> tile A1) and dW_3
+template <int NRL>
+__device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
+    constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
+    constexpr int NPAIR = (NLIVE + 1) / 2;
+    const BwdArgs& a = args.b;
+    const MlpDev& m = a.m;
+    const int lane = threadIdx.x & 63, g = lane >> 4, p = lane & 15;
+    const int H1 = m.width[1], E = a.E, d = a.d;
+    const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
+    const int own = p * TRS + g * 16;
+    const int trb = (8 * (g >> 1) + (p >> 2)) * TRS + 16 * (g & 1) + 4 * (p & 3);
+    const int nit = sh.nit;
+    ws16_clear_tiles(lds16);
+    float inv_sigma;
+    (void)ws16_sigma(reinterpret_cast<const Ws16Scal*>(args.scal), inv_sigma);
+
+    float w1x[BT][4];
+    {
+        const float* __restrict__ W0 = m.W[0];
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = feat_of(t, r, g);
+                w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
+            }
+    }
+    ws_f32x16 dW[2][2];
+    ws16_zero_dw(dW);
+
+    WsCursor cu{0, 0};
+    float xv = 0.f, x0v = 0.f, dxv = 0.f;
+    f32x4 c[BT];
+#pragma unroll
+    for (int t = 0; t < BT; ++t) c[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Opening a tile: x, x0, the tile's 16 x E embedding values from HBM, c = b_1 + W_1[:, 1:] h on the fp32 matrix pipe; all loads
+    // of eight K-steps issued before the first product (item_embedding_gemm)
+    auto new_item = [&]() __attribute__((always_inline)) {
+        const long long q0 = (long long)(args.grp0 + ws_grp(cu)) * 16 + p;
+        const long long qq = q0 < a.NI ? q0 : a.NI - 1;
+        xv = io_ld(a.x, qq, a.x_bf16);
+        x0v = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
+        dxv = xv - x0v;
+        const long long bi = qq / d;
+        const IoView hb = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
+        const float* __restrict__ b0 = m.b[0];
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = feat_of(t, r, g);
+                c[t][r] = f < H1 ? b0[f] : (f == H1 ? 1.f : 0.f);
+            }
+        item_embedding_gemm<BT, 8>(hb, m.W[0], H1, E, d, g, p, c);
+    };
+    if (nit > 0) new_item();
+
+    float actF[BT][4];
+    unsigned qF[8][W16_NP];
+    float rf0[8], rf1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { rf0[j] = rf1[j] = 0.f; qF[j][0] = qF[j][1] = 0u; }
+#pragma unroll
+    for (int t = 0; t < BT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) actF[t][r] = 0.f;
+
+    WS_TIMING_DECL;
+    int rA3 = ws_ring0<WS_NS3, WS_TILE>(8), rD4 = ws_ring0<2, WS_TILE>(8);
+    int rO1 = ws_ring0<WS_NS1, WS_TILE>(0);
+    bool live = cu.j < nit;
+    bool is_tan = live && ws_is_tan(sh, cu);
+    float tk = 0.f;
+    {
+        const int k = ws_node(sh, cu);
+        const float uu = a.ccs[k] + 1.f;
+        tk = (k == 0) ? xv : __fadd_rn(x0v, __fmul_rn(dxv, uu) * 0.5f);
+    }
+    WsOps ops;
+    {
+        const unsigned short* A3n = lds16 + WS_OFF_A3 + rA3 + trb;
+        W16_LOAD_B(ops, A3n);
+    }
+    for (int s = 0; s < S; ++s) {
+        WS_T(t0);
+        const WsCursor nx = live ? ws_next(sh, cu) : cu;
+        const int kn = ws_node(sh, nx);
+        const float ccs_n = a.ccs[kn];
+        const unsigned short* D4 = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + trb;
+        unsigned short* const O1 = lds16 + WS_OFF_A1 + rO1 + own;
+        // operands of dW_3: the a_3 half came in before the barrier, the delta_4 half (written last step) here
+        W16_LOAD_A(ops, D4);
+        // layer 1 of element s (tangent element: w1 . act'(z_1) of node 0)
+        auto layer1_reg = [&](auto ec, auto tanc) __attribute__((always_inline)) {
+            constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
+            constexpr bool TAN = decltype(tanc)::value;
+            if constexpr (e < NLIVE) {
+                const float z = fmaf(w1x[t][r], tk, c[t][r]);
+                if constexpr (TAN) actF[t][r] = w1x[t][r] * (z > 0.f ? 1.f : slope);
+                else actF[t][r] = hidden_act_f(z, slope);
+            }
+        };
+        auto pairF = [&](auto jc, auto stc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value, st = decltype(stc)::value, t = j / 2, r = 2 * (j & 1);
+            if constexpr (j < NPAIR) {
+                if constexpr (st == 0) { rf0[j] = actF[t][r]; rf1[j] = actF[t][r + 1]; qF[j][0] = h16_split_stage(rf0[j], rf1[j]); }
+                if constexpr (st == 1) qF[j][1] = h16_split_last(rf0[j], rf1[j]);
+            }
+        };
+        auto store_a = [&](auto sc, auto kc) __attribute__((always_inline)) {
+            constexpr int ks = decltype(sc)::value, k2 = decltype(kc)::value;
+            *reinterpret_cast<u32x4*>(O1 + k2 * 16 * TRS + ks * 8) = u32x4{qF[4 * ks][k2], qF[4 * ks + 1][k2], qF[4 * ks + 2][k2], qF[4 * ks + 3][k2]};
+        };
+        WS_T(t1);
+        if (is_tan) swp_static_for<16>([&](auto ec) { layer1_reg(ec, std::true_type{}); });
+        else swp_static_for<16>([&](auto ec) { layer1_reg(ec, std::false_type{}); });
+        __builtin_amdgcn_sched_barrier(0);
+        swp_static_for<12>([&](auto nc) {
+            constexpr int nn = decltype(nc)::value;
+            WS_MARK(nn, 12);
+            ws16_dw_mfma<nn>(dW, ops);
+            // the split of a_1: two pairs per slot, stage by stage; then the four stores
+            if constexpr (nn < 4) { pairF(std::integral_constant<int, 2 * nn>{}, std::integral_constant<int, 0>{}); pairF(std::integral_constant<int, 2 * nn + 1>{}, std::integral_constant<int, 0>{}); }
+            if constexpr (nn >= 1 && nn < 5) { pairF(std::integral_constant<int, 2 * (nn - 1)>{}, std::integral_constant<int, 1>{}); pairF(std::integral_constant<int, 2 * (nn - 1) + 1>{}, std::integral_constant<int, 1>{}); }
+            if constexpr (nn == 5 || nn == 6) store_a(std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 5>{});
+            if constexpr (nn == 7 || nn == 8) store_a(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 7>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // next element: its item data if it opens a new tile, its node position from the table value fetched above
+        if (live) {
+            const bool crossed = nx.j != cu.j;
+            cu = nx;
+            live = cu.j < nit;
+            if (crossed && live) new_item();
+            is_tan = live && ws_is_tan(sh, cu);
+            const float uu = ccs_n + 1.f;
+            tk = (kn == 0) ? xv : __fadd_rn(x0v, __fmul_rn(dxv, uu) * 0.5f);
+        }
+        ws_adv<WS_NS3, WS_TILE>(rA3); ws_adv<2, WS_TILE>(rD4);
+        ws_adv<WS_NS1, WS_TILE>(rO1);
+        {   // next step's a_3 operand of dW_3 (a tile written four steps ago)
+            const unsigned short* A3n = lds16 + WS_OFF_A3 + rA3 + trb;
+            W16_LOAD_B(ops, A3n);
+        }
+        WS_T(t2);
+        __syncthreads();
+        WS_T(t3);
+        WS_TIMING_ACC(t0, t1, t2, t3);
+    }
+    WS_TIMING_OUT(S);
+    ws16_write_dw(a, part, 3, dW, lane, inv_sigma);
+}
+
+// ============================================================================================================ wave Cb
+// delta_4 = dout w_out act'(a_4) (dout arrives scaled by sigma), dW_2 and dW_1
+template <int NRL>
+__device__ __forceinline__ void ws16_role_Cb(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
+    constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
+    constexpr int L = 4;
+    const BwdArgs& a = args.b;
+    const MlpDev& m = a.m;
+    const int lane = threadIdx.x & 63, g = lane >> 4, p = lane & 15;
+    const int HL = m.width[L];
+    const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
+    const int own = p * TRS + g * 16;
+    const int trb = (8 * (g >> 1) + (p >> 2)) * TRS + 16 * (g & 1) + 4 * (p & 3);
+    ws16_clear_tiles(lds16);
+    float inv_sigma;
+    (void)ws16_sigma(reinterpret_cast<const Ws16Scal*>(args.scal), inv_sigma);
+    float wout[BT][4];
+#pragma unroll
+    for (int t = 0; t < BT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = feat_of(t, r, g);
+            wout[t][r] = f < HL ? m.W[L][f] : 0.f;       // (no cotangent through the constant feature's slot)
+        }
+    ws_f32x16 dW2[2][2], dW1[2][2];
+    ws16_zero_dw(dW2);
+    ws16_zero_dw(dW1);
+    unsigned q4[8][W16_NP];
+    float rb0[8], rb1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { rb0[j] = rb1[j] = 0.f; q4[j][0] = q4[j][1] = 0u; }
+    WS_TIMING_DECL;
+    int rA2 = ws_ring0<WS_NS2, WS_TILE>(9), rA1 = ws_ring0<WS_NS1, WS_TILE>(10);
+    int rD3 = ws_ring0<2, WS_TILE>(9), rD2 = ws_ring0<2, WS_TILE>(10);
+    int rS4 = ws_ring0<2, WS_P3>(7), rD4 = ws_ring0<2, WS_TILE>(7);
+    WsOps o2, o1;
+    {   // (first step: the tiles are still zero)
+        const unsigned short* A2n = lds16 + WS_OFF_A2 + rA2 + trb;
+        const unsigned short* A1n = lds16 + WS_OFF_A1 + rA1 + trb;
+        W16_LOAD_B(o2, A2n);
+        W16_LOAD_B(o1, A1n);
+    }
+    for (int s = 0; s < S; ++s) {
+        WS_T(t0);
+        // delta_4 of element s - 7 from what F3 left a step ago, as micro-operations behind the matrix instructions below
+        const unsigned short* S4 = lds16 + W16_OFF_S4 + rS4;
+        unsigned short* const D4o = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + own;
+        u32x4 sg4[BKS];
+#pragma unroll
+        for (int s2 = 0; s2 < BKS; ++s2) sg4[s2] = *reinterpret_cast<const u32x4*>(S4 + own + s2 * 8);
+        const float dout = *reinterpret_cast<const float*>(S4 + p * TRS + 64);
+        const unsigned short* D3 = lds16 + WS_OFF_D + 2 * WS_TILE + rD3 + trb;
+        const unsigned short* D2 = lds16 + WS_OFF_D + 0 * WS_TILE + rD2 + trb;
+        // (the a_2 / a_1 halves of the operands came in before the barrier: only the cotangent halves, written last step, are fetched here)
+        W16_LOAD_A(o2, D3);
+        float d4[BT][4];
+        auto d4_reg = [&](auto ec) __attribute__((always_inline)) {
+            constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
+            if constexpr (e < NLIVE) d4[t][r] = (dout * wout[t][r]) * act_grad_q(sg4, t, r, slope);
+            else d4[t][r] = 0.f;
+        };
+        auto pair4 = [&](auto jc, auto stc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value, st = decltype(stc)::value, t = j / 2, r = 2 * (j & 1);
+            if constexpr (2 * j < NLIVE) {
+                if constexpr (st == 0) { rb0[j] = d4[t][r]; rb1[j] = d4[t][r + 1]; q4[j][0] = h16_split_stage(rb0[j], rb1[j]); }
+                if constexpr (st == 1) q4[j][1] = h16_split_last(rb0[j], rb1[j]);
+            }
+        };
+        auto store_d4 = [&](auto sc, auto kc) __attribute__((always_inline)) {
+            constexpr int ks = decltype(sc)::value, k2 = decltype(kc)::value;
+            *reinterpret_cast<u32x4*>(D4o + k2 * 16 * TRS + ks * 8) = u32x4{q4[4 * ks][k2], q4[4 * ks + 1][k2], q4[4 * ks + 2][k2], q4[4 * ks + 3][k2]};
+        };
+        WS_T(t1);
+        swp_static_for<24>([&](auto nc) {
+            constexpr int nn = decltype(nc)::value;
+            WS_MARK(nn, 24);
+            if constexpr (nn < 12) ws16_dw_mfma<nn>(dW2, o2);
+            else ws16_dw_mfma<nn - 12>(dW1, o1);
+            if constexpr (nn < 4) ws_load_op<nn>(o1, D2, D2);
+            // one register per slot, pair j split at slots 2j + 2 / 2j + 3, K-steps stored at 10, 11 / 18, 19
+            if constexpr (nn < 16) d4_reg(std::integral_constant<int, nn>{});
+            if constexpr (nn >= 2 && nn < 18 && (nn % 2) == 0) pair4(std::integral_constant<int, (nn - 2) / 2>{}, std::integral_constant<int, 0>{});
+            if constexpr (nn >= 3 && nn < 19 && (nn % 2) == 1) pair4(std::integral_constant<int, (nn - 3) / 2>{}, std::integral_constant<int, 1>{});
+            if constexpr (nn == 10 || nn == 11) store_d4(std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 10>{});
+            if constexpr (nn == 18 || nn == 19) store_d4(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 18>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        ws_adv<WS_NS2, WS_TILE>(rA2); ws_adv<WS_NS1, WS_TILE>(rA1);
+        ws_adv<2, WS_TILE>(rD3); ws_adv<2, WS_TILE>(rD2);
+        ws_adv<2, WS_P3>(rS4); ws_adv<2, WS_TILE>(rD4);
+        {   // next step's a_2 / a_1 operands (tiles written six and ten steps ago)
+            const unsigned short* A2n = lds16 + WS_OFF_A2 + rA2 + trb;
+            const unsigned short* A1n = lds16 + WS_OFF_A1 + rA1 + trb;
+            W16_LOAD_B(o2, A2n);
+            W16_LOAD_B(o1, A1n);
+        }
+        WS_T(t2);
+        __syncthreads();
+        WS_T(t3);
+        WS_TIMING_ACC(t0, t1, t2, t3);
+    }
+    WS_TIMING_OUT(S);
+    ws16_write_dw(a, part, 2, dW2, lane, inv_sigma);
+    ws16_write_dw(a, part, 1, dW1, lane, inv_sigma);
+}
+
+// ============================================================================================================ waves F1..F3
+// forward GEMM of hidden layer LAYER -> LAYER + 1: W_l as two fp16 pieces (64 registers) for the whole launch; per step 24 MFMAs
+// on one tile-node with the activation / split of the tile-node before behind them; F3 ends in the output layer
+template <int NRL, int LAYER>
+__device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
+    constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
+    constexpr int NPAIR = (NLIVE + 1) / 2;
+    constexpr int L = 4;
+    constexpr int DF = 2 * LAYER - 1;                  // the GEMM works on element s - DF, its vector work runs one step later
+    constexpr int DP = 2 * LAYER;
+    constexpr bool IS_OUT = LAYER == 3;
+    constexpr int LO = LAYER < 3 ? LAYER + 1 : 3;      // layer of the activation tile this wave writes (F3 writes the S4 tile instead)
+    const BwdArgs& a = args.b;
+    const MlpDev& m = a.m;
+    const int lane = threadIdx.x & 63, g = lane >> 4, p = lane & 15;
+    const int HL = m.width[L], n = a.n;
+    const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
+    const int own = p * TRS + g * 16;
+    const int nit = sh.nit;
+    u32x4 Wf[BT][BKS][W16_NP];
+    {
+        const unsigned short* imf = lds16 + (LAYER - 1) * W16_IMG + lane * 8;
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < BKS; ++s2)
+#pragma unroll
+                for (int k2 = 0; k2 < W16_NP; ++k2) Wf[t][s2][k2] = *reinterpret_cast<const u32x4*>(imf + ((t * BKS + s2) * W16_NP + k2) * FRAG);
+    }
+    ws16_clear_tiles(lds16);
+    float inv_sigma;
+    const float sigma = ws16_sigma(reinterpret_cast<const Ws16Scal*>(args.scal), inv_sigma);
+
+    float wout[BT][4];
+#pragma unroll
+    for (int t = 0; t < BT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            wout[t][r] = 0.f;
+            if constexpr (IS_OUT) {
+                const int f = feat_of(t, r, g);
+                wout[t][r] = f < HL ? m.W[L][f] : (f == HL ? m.b[L][0] : 0.f);
+            }
+        }
+    f32x4 dwo[BT];
+#pragma unroll
+    for (int t = 0; t < BT; ++t) dwo[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    WsCursor cp{0, 0};                                  // element of the vector work (s - DP)
+    float xvP = 0.f, x0vP = 0.f, gvP = 0.f, gfxvP = 0.f, gfxS = 0.f, cotbase = 0.f;
+    float fxv = 0.f, fx0v = 0.f, dfdt = 0.f, fp0 = 0.f;
+    bool bad = false;                                   // an inf / NaN reached the output-layer sum: some piece overflowed
+    auto new_item_P = [&]() __attribute__((always_inline)) {
+        if constexpr (IS_OUT) {
+            const long long q = (long long)(args.grp0 + ws_grp(cp)) * 16 + p;
+            const bool ok = q < a.NI;
+            const long long qq = ok ? q : a.NI - 1;
+            xvP = io_ld(a.x, qq, a.x_bf16);
+            x0vP = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
+            gvP = ok ? io_ld(a.g, qq, a.x_bf16) : 0.f;
+            gfxvP = (ok && a.gfx) ? io_ld(a.gfx, qq, a.x_bf16) : 0.f;
+            cotbase = (gvP * (xvP - x0vP) * 0.5f) * sigma;             // (everything downstream of here carries sigma)
+            gfxS = gfxvP * sigma;
+            fxv = 0.f; fx0v = 0.f; dfdt = 0.f;
+        }
+    };
+    if (nit > 0) new_item_P();
+
+    f32x4 acc[BT];
+    float actF[BT][4], delta[BT][4];                   // (delta: the tangent values of a tangent element)
+#pragma unroll
+    for (int t = 0; t < BT; ++t) {
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { actF[t][r] = 0.f; delta[t][r] = 0.f; }
+    }
+    unsigned qF[8][W16_NP], q4[8];
+    float rf0[8], rf1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { rf0[j] = rf1[j] = 0.f; qF[j][0] = qF[j][1] = 0u; q4[j] = 0u; }
+    float sd4[4] = {0.f, 0.f, 0.f, 0.f}, doutN = 0.f;
+    float sc_a = 0.f, sc_sd = 0.f, sc_ex = 0.f, sc_s1 = 0.f, sc_f = 0.f, sc_fp = 0.f;
+    const bool sig = m.out_act != UMNN_OUT_ELU_PLUS_ONE;
+
+    WS_TIMING_DECL;
+    int rAin = ws_ring0<ws_a_ns(LAYER), WS_TILE>(DF);
+    int rAout = ws_ring0<ws_a_ns(LO), WS_TILE>(DP), rD4 = ws_ring0<2, WS_P3>(DP);
+    float ccwP = 0.f;
+    if constexpr (IS_OUT) ccwP = a.ccw[ws_node(sh, cp)];
+    for (int s = 0; s < S; ++s) {
+        WS_T(t0);
+        const bool liveP = s >= DP && cp.j < nit;
+        const bool tanP = liveP && ws_is_tan(sh, cp);
+        const int kP = ws_node(sh, cp);
+        const WsCursor nxP = liveP ? ws_next(sh, cp) : cp;
+        float ccw_n = 0.f;
+        if constexpr (IS_OUT) {
+            ccw_n = a.ccw[ws_node(sh, nxP)];
+            if (liveP && cp.e == 0) new_item_P();
+        }
+        const unsigned short* Ain = lds16 + ws_a_off(LAYER) + rAin + own;                  // a_l[s - DF]
+        unsigned short* const Aout = lds16 + ws_a_off(LO) + rAout + own;                   // a_{l+1}[s - DP]
+        unsigned short* const S4out = lds16 + W16_OFF_S4 + rD4;                            // F3: leading piece of a_4[s - 6], dout
+        BFrag<W16_NP> bf;
+#pragma unroll
+        for (int s2 = 0; s2 < BKS; ++s2)
+#pragma unroll
+            for (int k2 = 0; k2 < W16_NP; ++k2) bf.v[s2][k2] = *reinterpret_cast<const u32x4*>(Ain + k2 * 16 * TRS + s2 * 8);
+
+        // ---- micro-operations of the vector work of element s - DP
+        auto act_reg = [&](auto ec, auto tanc) __attribute__((always_inline)) {
+            constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4, j = e / 2;
+            constexpr bool TAN = decltype(tanc)::value;
+            if constexpr (e < NLIVE) {
+                if constexpr (!IS_OUT) {
+                    if constexpr (TAN) {
+                        // tangent element: times act'(a_{l+1}) of the element before (node 0), read off its leading piece
+                        const unsigned u = qF[j][0];
+                        const bool pos = (e & 1) ? ((int)u > 0xffff) : ((short)(u & 0xffffu) > 0);
+                        actF[t][r] = acc[t][r] * (pos ? 1.f : slope);
+                    } else {
+                        actF[t][r] = hidden_act_f(acc[t][r], slope);
+                    }
+                } else {
+                    if constexpr (TAN) delta[t][r] = acc[t][r] * (actF[t][r] > 0.f ? 1.f : slope);
+                    else actF[t][r] = hidden_act_f(acc[t][r], slope);
+                }
+            }
+        };
+        auto pairF = [&](auto jc, auto stc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value, st = decltype(stc)::value, t = j / 2, r = 2 * (j & 1);
+            if constexpr (j < NPAIR) {
+                if constexpr (st == 0) { rf0[j] = actF[t][r]; rf1[j] = actF[t][r + 1]; qF[j][0] = h16_split_stage(rf0[j], rf1[j]); }
+                if constexpr (st == 1) qF[j][1] = h16_split_last(rf0[j], rf1[j]);
+            }
+        };
+        auto store_a = [&](auto sc, auto kc) __attribute__((always_inline)) {
+            constexpr int ks = decltype(sc)::value, k2 = decltype(kc)::value;
+            *reinterpret_cast<u32x4*>(Aout + k2 * 16 * TRS + ks * 8) = u32x4{qF[4 * ks][k2], qF[4 * ks + 1][k2], qF[4 * ks + 2][k2], qF[4 * ks + 3][k2]};
+        };
+        // F3: output layer of element s - 6 (four partial sums: no thirteen-deep dependent chain in front of the matrix loop)
+        auto out_dot = [&](auto ec, auto tanc) __attribute__((always_inline)) {
+            constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
+            constexpr bool TAN = decltype(tanc)::value;
+            if constexpr (e < 4) sd4[e] = 0.f;
+            if constexpr (e < NLIVE) sd4[r] = fmaf(wout[t][r], TAN ? delta[t][r] : actF[t][r], sd4[r]);
+        };
+        // the scalar part in stages, one per matrix-instruction slot (a serial chain: cross-lane sum, exp, reciprocal, selects)
+        auto out_scalar = [&](auto stc) __attribute__((always_inline)) {
+            constexpr int st = decltype(stc)::value;
+            if constexpr (st == 0) sc_a = (sd4[0] + sd4[1]) + (sd4[2] + sd4[3]);
+            if constexpr (st == 1) {
+                const unsigned u = __float_as_uint(sc_a);
+                auto q = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+                sc_a = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+            }
+            if constexpr (st == 2) {
+                const unsigned w = __float_as_uint(sc_a);
+                auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+                sc_sd = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+            }
+            if constexpr (st == 3) sc_ex = __expf(sig ? -sc_sd : sc_sd);
+            if constexpr (st == 4) sc_s1 = __builtin_amdgcn_rcpf(1.f + sc_ex);   // (sigmoid outputs only: 1 ulp; ELU+1 does not use it)
+            if constexpr (st == 5) {
+                sc_f = sig ? sc_s1 : (sc_sd > 0.f ? sc_sd + 1.f : sc_ex);
+                sc_fp = sig ? sc_s1 * (1.f - sc_s1) : (sc_sd > 0.f ? 1.f : sc_ex);
+            }
+            if constexpr (st == 6) {
+                const bool node = liveP && !tanP;
+                if (node && kP == 0) { fxv = sc_f; fp0 = sc_fp; }
+                if (node && kP == n) fx0v = sc_f;
+                // tangent element: the sum is w_out . d a_L / d t at node 0 -> d f / d t
+                if (tanP) dfdt = fp0 * sc_sd;
+                bad = bad || (liveP && !ws16_finite(sc_sd));
+            }
+            if constexpr (st == 7) {
+                const bool node = liveP && !tanP;
+                const float cot = fmaf(cotbase, ccwP, kP == 0 ? gfxS : 0.f) * (node ? 1.f : 0.f);
+                doutN = cot * sc_fp;                                               // (no cotangent flows back from a tangent element)
+            }
+        };
+        auto out_reg = [&](auto ec) __attribute__((always_inline)) {       // d w_out += dout a_L  (delta_L is formed by wave Cb)
+            constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
+            if constexpr (e < NLIVE) dwo[t][r] = fmaf(doutN, actF[t][r], dwo[t][r]);
+        };
+        auto pair4 = [&](auto jc) __attribute__((always_inline)) {          // leading piece of a_L: carries its sign
+            constexpr int j = decltype(jc)::value, t = j / 2, r = 2 * (j & 1);
+            if constexpr (j < NPAIR) q4[j] = h16_split_last(actF[t][r], actF[t][r + 1]);
+        };
+        auto store_s4 = [&](auto sc) __attribute__((always_inline)) {
+            constexpr int ks = decltype(sc)::value;
+            *reinterpret_cast<u32x4*>(S4out + own + ks * 8) = u32x4{q4[4 * ks], q4[4 * ks + 1], q4[4 * ks + 2], q4[4 * ks + 3]};
+        };
+        WS_T(t1);
+        // ---- the activations of element s - DP first (registers only: the operand fetches above are still in flight)
+        if (tanP) {
+            swp_static_for<16>([&](auto ec) { act_reg(ec, std::true_type{}); });
+            if constexpr (IS_OUT) swp_static_for<16>([&](auto ec) { out_dot(ec, std::true_type{}); });
+        } else {
+            swp_static_for<16>([&](auto ec) { act_reg(ec, std::false_type{}); });
+            if constexpr (IS_OUT) swp_static_for<16>([&](auto ec) { out_dot(ec, std::false_type{}); });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the GEMM of element s - DF (24 MFMAs, A operands = this wave's registers); behind it the rest of the vector work
+        {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            swp_static_for<24>([&](auto nc) {
+                constexpr int nn = decltype(nc)::value;
+                WS_MARK(nn, 24);
+                constexpr int s2 = nn / 12, term = (nn % 12) / 4, t = nn % 4;
+                constexpr int wa = term == 2 ? 1 : 0, ba = term == 1 ? 1 : 0;
+                acc[t] = mfma_f16(Wf[t][s2][wa], bf.v[s2][ba], nn < 4 ? zero : acc[t]);
+                if constexpr (!IS_OUT) {
+                    // the split of a_{l+1}: per K-step the four pairs stage by stage, then its two stores (20 micro-operations)
+                    if constexpr (nn < 20) {
+                        constexpr int ks = nn / 10, w = nn % 10;
+                        if constexpr (w < 8) pairF(std::integral_constant<int, 4 * ks + w % 4>{}, std::integral_constant<int, w / 4>{});
+                        else store_a(std::integral_constant<int, ks>{}, std::integral_constant<int, w - 8>{});
+                    }
+                } else {
+                    // the leading piece of a_L does not wait for the scalar chain; dout and d w_out follow it
+                    if constexpr (nn < 8) out_scalar(std::integral_constant<int, nn>{});
+                    if constexpr (nn < 8) pair4(std::integral_constant<int, nn>{});
+                    if constexpr (nn == 8 || nn == 9) store_s4(std::integral_constant<int, nn - 8>{});
+                    if constexpr (nn == 9) *reinterpret_cast<float*>(S4out + p * TRS + 64) = doutN;
+                    if constexpr (nn >= 10 && nn < 18) { out_reg(std::integral_constant<int, 2 * (nn - 10)>{}); out_reg(std::integral_constant<int, 2 * (nn - 10) + 1>{}); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        // ---- item boundary (outside the scheduled region: uniform branch)
+        if constexpr (IS_OUT) {
+            if (liveP && cp.e == sh.ne - 1) {
+                const long long q = (long long)(args.grp0 + ws_grp(cp)) * 16 + p;
+                if (q < a.NI && g == 0) {
+                    if (a.dx) io_st(a.dx, q, fmaf(gfxvP, dfdt, fxv * gvP), a.x_bf16);
+                    if (a.dx0) io_st(a.dx0, q, -fx0v * gvP, a.x_bf16);
+                }
+            }
+        }
+        cp = nxP;
+        ccwP = ccw_n;
+        ws_adv<ws_a_ns(LAYER), WS_TILE>(rAin);
+        ws_adv<ws_a_ns(LO), WS_TILE>(rAout); ws_adv<2, WS_P3>(rD4);
+        WS_T(t2);
+        __syncthreads();
+        WS_T(t3);
+        WS_TIMING_ACC(t0, t1, t2, t3);
+    }
+    WS_TIMING_OUT(S);
+    if constexpr (IS_OUT) {
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = dwo[t][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+                const int f = feat_of(t, r, g);
+                if (p == 0) {
+                    const int idx = f < HL ? a.poffW[L] + f : (f == HL ? a.poffb[L] : -1);
+                    if (idx >= 0) part[idx] = v * inv_sigma;
+                }
+            }
+        if (__any(bad) && lane == 0) atomicOr(&reinterpret_cast<Ws16Scal*>(args.scal)->flag, 1u);
+    }
+}
+
+// ============================================================================================================ waves B1..B3
+// W_l^T (two fp16 pieces, 64 registers): per step 24 MFMAs, then delta_l = (W_l^T delta_{l+1}) . act'(a_l), split, stored for the
+// next wave down.  B1 ends in the tail (dc, dW1[:,0]), un-scaled on the way out.
+template <int NRL, int LAYER>
+__device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
+    constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
+    constexpr int DB = 11 - LAYER;                     // element s - DB: W_l^T GEMM, then its vector work, in the same step
+    constexpr bool IS_TAIL = LAYER == 1;
+    const BwdArgs& a = args.b;
+    const MlpDev& m = a.m;
+    const int lane = threadIdx.x & 63, g = lane >> 4, p = lane & 15;
+    const int H1 = m.width[1], E = a.E;
+    const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
+    const int own = p * TRS + g * 16;
+    const int nit = sh.nit;
+    u32x4 WT[BT][BKS][W16_NP];
+    {
+        const unsigned short* imt = lds16 + (3 + LAYER - 1) * W16_IMG + lane * 8;
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < BKS; ++s2)
+#pragma unroll
+                for (int k2 = 0; k2 < W16_NP; ++k2) WT[t][s2][k2] = *reinterpret_cast<const u32x4*>(imt + ((t * BKS + s2) * W16_NP + k2) * FRAG);
+    }
+    ws16_clear_tiles(lds16);
+    float inv_sigma;
+    (void)ws16_sigma(reinterpret_cast<const Ws16Scal*>(args.scal), inv_sigma);
+
+    f32x4 dW1x[BT], dcs[BT];
+#pragma unroll
+    for (int t = 0; t < BT; ++t) { dW1x[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    bool bad = false;                                   // an inf / NaN reached a dc sum: some cotangent piece overflowed
+    WsCursor cb{0, 0};
+    float xvB = 0.f, x0vB = 0.f, dxvB = 0.f;
+    auto new_item_B = [&]() __attribute__((always_inline)) {
+        if constexpr (IS_TAIL) {
+            const long long q = (long long)(args.grp0 + ws_grp(cb)) * 16 + p;
+            const long long qq = q < a.NI ? q : a.NI - 1;
+            xvB = io_ld(a.x, qq, a.x_bf16);
+            x0vB = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
+            dxvB = xvB - x0vB;
+        }
+    };
+    if (nit > 0) new_item_B();
+
+    WS_TIMING_DECL;
+    int rAsg = ws_ring0<ws_a_ns(LAYER), WS_TILE>(DB), rDin = ws_ring0<2, WS_TILE>(DB), rDout = ws_ring0<2, WS_TILE>(DB);
+    float tkB = 0.f;
+    if constexpr (IS_TAIL) {
+        const int kB = ws_node(sh, cb);
+        const float uu = a.ccs[kB] + 1.f;
+        tkB = (kB == 0) ? xvB : __fadd_rn(x0vB, __fmul_rn(dxvB, uu) * 0.5f);
+    }
+    for (int s = 0; s < S; ++s) {
+        WS_T(t0);
+        const bool liveB = s >= DB && cb.j < nit;
+        WsCursor nxB = cb;
+        float ccs_n = 0.f;
+        int kBn = 0;
+        if constexpr (IS_TAIL) {
+            if (liveB) nxB = ws_next(sh, cb);
+            kBn = ws_node(sh, nxB);
+            ccs_n = a.ccs[kBn];
+        }
+        const unsigned short* Asg = lds16 + ws_a_off(LAYER) + rAsg + own;                                  // a_l[s - DB]
+        const unsigned short* Din = lds16 + WS_OFF_D + (LAYER + 1 - 2) * 2 * WS_TILE + rDin + own;         // delta_{l+1}[s - DB]
+        unsigned short* const Dout = lds16 + WS_OFF_D + (LAYER >= 2 ? LAYER - 2 : 0) * 2 * WS_TILE + rDout + own;   // delta_l[s - DB]
+        BFrag<W16_NP> bd;
+        u32x4 sg[BKS];
+#pragma unroll
+        for (int s2 = 0; s2 < BKS; ++s2)
+#pragma unroll
+            for (int k2 = 0; k2 < W16_NP; ++k2) bd.v[s2][k2] = *reinterpret_cast<const u32x4*>(Din + k2 * 16 * TRS + s2 * 8);
+#pragma unroll
+        for (int s2 = 0; s2 < BKS; ++s2) sg[s2] = *reinterpret_cast<const u32x4*>(Asg + s2 * 8);
+        WS_T(t1);
+        // ---- W_l^T GEMM (24 MFMAs, A operands = this wave's registers)
+        f32x4 nd[BT];
+        {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < BKS; ++s2) {
+#pragma unroll
+                for (int ba = 0; ba < W16_NP; ++ba)
+#pragma unroll
+                    for (int t = 0; t < BT; ++t) nd[t] = mfma_f16(WT[t][s2][0], bd.v[s2][ba], (s2 == 0 && ba == 0) ? zero : nd[t]);
+#pragma unroll
+                for (int t = 0; t < BT; ++t) nd[t] = mfma_f16(WT[t][s2][1], bd.v[s2][0], nd[t]);
+            }
+        }
+        WS_MARK_HERE();
+        // ---- delta_l = (W_l^T delta_{l+1}) . act'(a_l); B1: the tail of the node; B2, B3: split and store for the wave below
+        f32x4 dl[BT];
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (4 * t + r < NLIVE) {
+                    dl[t][r] = nd[t][r] * act_grad_q(sg, t, r, slope);
+                    if constexpr (IS_TAIL) {
+                        dcs[t][r] += dl[t][r];
+                        dW1x[t][r] = fmaf(dl[t][r], tkB, dW1x[t][r]);
+                    }
+                } else {
+                    dl[t][r] = 0.f;
+                }
+            }
+        if constexpr (!IS_TAIL) {
+            BFrag<W16_NP> q;
+            h16_split_regs<NRL>(dl, q);
+#pragma unroll
+            for (int s2 = 0; s2 < BKS; ++s2)
+#pragma unroll
+                for (int k2 = 0; k2 < W16_NP; ++k2) *reinterpret_cast<u32x4*>(Dout + k2 * 16 * TRS + s2 * 8) = q.v[s2][k2];
+        }
+        if constexpr (IS_TAIL) {
+            if (liveB && cb.e == sh.ne - 1) {
+                const long long q = (long long)(args.grp0 + ws_grp(cb)) * 16 + p;
+                float chk = 0.f;
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) chk = fmaf(dcs[t][r], 0.f, chk);         // (NaN iff some entry is inf / NaN)
+                bad = bad || !(chk == 0.f);
+                if (q < a.NI) {
+#pragma unroll
+                    for (int t = 0; t < BT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int f = feat_of(t, r, g);
+                            if (f < H1) a.dc[q * H1 + f] = dcs[t][r] * inv_sigma;
+                        }
+                }
+#pragma unroll
+                for (int t = 0; t < BT; ++t) dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (liveB) {
+                const bool crossed = nxB.j != cb.j;
+                cb = nxB;
+                if (crossed && cb.j < nit) new_item_B();
+                const float uu = ccs_n + 1.f;
+                tkB = (kBn == 0) ? xvB : __fadd_rn(x0vB, __fmul_rn(dxvB, uu) * 0.5f);
+            }
+        }
+        ws_adv<ws_a_ns(LAYER), WS_TILE>(rAsg); ws_adv<2, WS_TILE>(rDin); ws_adv<2, WS_TILE>(rDout);
+        WS_T(t2);
+        __syncthreads();
+        WS_T(t3);
+        WS_TIMING_ACC(t0, t1, t2, t3);
+    }
+    WS_TIMING_OUT(S);
+    if constexpr (IS_TAIL) {
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = dW1x[t][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+                const int f = feat_of(t, r, g);
+                if (p == 0 && f < H1) part[a.poffW[0] + f * (1 + E)] = v * inv_sigma;
+            }
+        if (__any(bad) && lane == 0) atomicOr(&reinterpret_cast<Ws16Scal*>(args.scal)->flag, 1u);
+    }
+}
+
+// wave -> role.  Waves w and w + 4 share a SIMD: Ca + Cb, F1 + B1, F2 + B2, F3 + B3.
+template <int NRL>
+__global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws16_kernel(const BwdBf16Args args) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
+    const BwdArgs& a = args.b;
+    const MlpDev& m = a.m;
+    const int tid = threadIdx.x;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- the weights: staged once as fp16 fragment images, then read into the owners' registers
+    for (int l = 1; l <= 3; ++l) {
+        ws16_stage_image<false>(m, l, lds16 + (l - 1) * W16_IMG, tid, blockDim.x);
+        ws16_stage_image<true>(m, l, lds16 + (3 + l - 1) * W16_IMG, tid, blockDim.x);
+    }
+    __syncthreads();
+    const int role = wid & 3, upper = wid >> 2;
+    WsShape sh;
+    sh.tan0 = a.gfx != nullptr ? 1 : 0;
+    sh.ne = a.n + 1 + sh.tan0;
+    sh.nit = blockIdx.x < a.ngroups ? (int)((a.ngroups - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
+    const int S = sh.nit * sh.ne + WS_DEPTH;
+    float* part = a.partials + (size_t)blockIdx.x * a.n_params;          // one d_theta slice per workgroup
+    if (!upper) {
+        if (role == 0) ws16_role_Ca<NRL>(args, lds16, S, sh, part);
+        else if (role == 1) ws16_role_F<NRL, 1>(args, lds16, S, sh, part);
+        else if (role == 2) ws16_role_F<NRL, 2>(args, lds16, S, sh, part);
+        else ws16_role_F<NRL, 3>(args, lds16, S, sh, part);
+    } else {
+        if (role == 0) ws16_role_Cb<NRL>(args, lds16, S, sh, part);
+        else if (role == 1) ws16_role_B<NRL, 1>(args, lds16, S, sh, part);
+        else if (role == 2) ws16_role_B<NRL, 2>(args, lds16, S, sh, part);
+        else ws16_role_B<NRL, 3>(args, lds16, S, sh, part);
+    }
+}

@@ -1207,6 +1207,7 @@ __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws_kernel(const BwdBf
     const MlpDev& m = a.m;
     const int tid = threadIdx.x;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (args.only_if && *args.only_if == 0) return;      // queued as the fallback of the fp16-piece pipeline: nothing overflowed
     // ---- the weights: staged once as fragment images (the other kernels' staging code), then read into the owners' registers
     for (int l = 1; l <= 3; ++l) {
         stage_frag_image<false, NPF>(m, l, lds16 + (l - 1) * WS_IMGF, tid, blockDim.x);
