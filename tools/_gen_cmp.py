@@ -17,7 +17,7 @@ for key in ("ws16", "ws", "swp", "fp32bwd", "fp32all", "generic"):
     else:
         _lib.set_backward_precision("fp32" if key.startswith("fp32") else "bf16x3")
         umnn_amd.set_forward_precision("fp32" if key == "fp32all" else "bf16x3")
-        with _lib.options(bwd_ws=1 if key.startswith("ws") else 0, bwd_ws16=1 if key == "ws16" else 0):
+        with _lib.options(bwd_ws=1 if key.startswith("ws") else 0, bwd_ws16=2 if key == "ws16" else 0):
             ll, _ = m.compute_ll(x); (-ll.mean()).backward()
         _lib.set_backward_precision("bf16x3"); umnn_amd.set_forward_precision("bf16x3")
     res[key] = {"x": x.grad.detach().double().clone(), **{k: p.grad.detach().double().clone() for k, p in m.named_parameters() if p.grad is not None}}

@@ -59,7 +59,7 @@ for (B, d, E, hid, n, gfx, scale) in CASES:
     line = f"B={B} d={d} n={n} x{scale}:"
     for key, ws, ws16, prec in (("swp", 0, 0, "bf16x3"), ("ws", 1, 0, "bf16x3"), ("ws16", 1, 1, "bf16x3"), ("fp32", 0, 0, "fp32")):
         _lib.set_backward_precision(prec)
-        with _lib.options(bwd_ws=ws, bwd_ws16=ws16):
+        with _lib.options(bwd_ws=ws, bwd_ws16=2 * ws16):
             out = I.hip_backward(spec, x0, x, h, gg, gf, n)
             torch.cuda.synchronize()
         _lib.set_backward_precision("bf16x3")

@@ -29,7 +29,7 @@ for (B, d, E, hid, n, gfx) in CASES:
     outs = {}
     for key, ws, prec in (("swp", 0, "bf16x3"), ("ws", 1, "bf16x3"), ("ws16", 2, "bf16x3"), ("fp32", 0, "fp32")):
         _lib.set_backward_precision(prec)
-        with _lib.options(bwd_ws=int(ws > 0), bwd_ws16=int(ws == 2)):
+        with _lib.options(bwd_ws=int(ws > 0), bwd_ws16=2 * int(ws == 2)):
             outs[key] = I.hip_backward(spec, x0, x, h, gg, gf, n)
             torch.cuda.synchronize()
         print(key, _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode(), flush=True)
@@ -56,7 +56,7 @@ spec = mlp_spec(net)
 x, h, g = torch.randn(B, d, device=dev), torch.randn(B, E * d, device=dev), torch.randn(B, d, device=dev)
 gf = torch.randn(B, d, device=dev)
 for ws in (1, 2, 1, 2):
-    with _lib.options(bwd_ws=int(ws > 0), bwd_ws16=int(ws == 2)):
+    with _lib.options(bwd_ws=int(ws > 0), bwd_ws16=2 * int(ws == 2)):
         I.hip_backward(spec, None, x, h, g, gf, n)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

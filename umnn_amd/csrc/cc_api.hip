@@ -99,7 +99,7 @@ static void load_env(UmnnOptions& o) {
     v = env_int("UMNN_BWD_NS", -1); o.bwd_ns = v >= 1 && v <= 32 ? v : -1;
     o.bwd_swp = env_int("UMNN_BWD_SWP", 1) != 0;
     o.bwd_ws = env_int("UMNN_BWD_WS", 1) != 0;
-    o.bwd_ws16 = env_int("UMNN_BWD_WS16", 1) != 0;
+    v = env_int("UMNN_BWD_WS16", 1); o.bwd_ws16 = v >= 0 && v <= 2 ? v : 1;
 }
 UmnnOptions& umnn_options() {
     static UmnnOptions opts;
@@ -139,7 +139,7 @@ static bool option_value_ok(const char* name, int v) {
     if (!strcmp(name, "bwd_ns")) return v == -1 || (v >= 1 && v <= 32);
     if (!strcmp(name, "bwd_swp")) return v == 0 || v == 1;
     if (!strcmp(name, "bwd_ws")) return v == 0 || v == 1;
-    if (!strcmp(name, "bwd_ws16")) return v == 0 || v == 1;
+    if (!strcmp(name, "bwd_ws16")) return v >= 0 && v <= 2;
     return true;
 }
 extern "C" int umnn_set_option(const char* name, int value) {

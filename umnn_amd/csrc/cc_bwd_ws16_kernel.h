@@ -38,9 +38,13 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 #endif
 constexpr int W16_NP = 2;                         // fp16 pieces of every matrix operand (three cross terms)
 constexpr int W16_OFF_S4 = WS_OFF_P3;             // (no third-piece tiles: the S4 tiles follow the cotangent tiles)
-constexpr int W16_LDS_USHORTS = W16_OFF_S4 + 2 * WS_P3;
+constexpr int W16_TILE_USHORTS = W16_OFF_S4 + 2 * WS_P3;          // everything ws16_clear_tiles zeroes
+constexpr int W16_MAX_NODES = 1024;               // quadrature tables in LDS: w_k at float k, s_k at float W16_MAX_NODES + k
+constexpr int W16_OFF_TAB = W16_TILE_USHORTS;
+constexpr int W16_LDS_USHORTS = W16_OFF_TAB + 2 * W16_MAX_NODES * 2;
 constexpr int W16_IMG = BT * BKS * W16_NP * FRAG; // staging image of one weight matrix (start of the launch only)
-static_assert(6 * W16_IMG <= W16_LDS_USHORTS, "the staging images must fit the tile area");
+static_assert(6 * W16_IMG <= W16_TILE_USHORTS, "the staging images must fit the tile area");
+static_assert(W16_LDS_USHORTS * 2 <= 160 * 1024, "LDS");
 
 // device scalars of a launch (workspace): filled by cc_bwd_cotmax_kernel, read by every role that scales
 struct Ws16Scal { unsigned cotmax, gfxmax, wmax, flag; };
@@ -189,11 +193,60 @@ __device__ __forceinline__ void ws16_zero_dw(ws_f32x16 (&dW)[2][2]) {
 }
 __device__ __forceinline__ void ws16_clear_tiles(unsigned short* lds16) {
     __syncthreads();
-    for (int i = threadIdx.x; i < W16_LDS_USHORTS / 8; i += blockDim.x) reinterpret_cast<u32x4*>(lds16)[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = threadIdx.x; i < W16_TILE_USHORTS / 8; i += blockDim.x) reinterpret_cast<u32x4*>(lds16)[i] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
 }
 #define W16_LOAD_B(ops, At) do { ws_load_op<4>(ops, At, At); ws_load_op<6>(ops, At, At); ws_load_op<5>(ops, At, At); ws_load_op<7>(ops, At, At); } while (0)
 #define W16_LOAD_A(ops, Dt) do { ws_load_op<0>(ops, Dt, Dt); ws_load_op<2>(ops, Dt, Dt); ws_load_op<1>(ops, Dt, Dt); ws_load_op<3>(ops, Dt, Dt); } while (0)
+
+// half of a dW product: the 32-row block HALF of delta_{l+1}^T (A) against both 32-column blocks of a_l (B); six matrix
+// instructions per tile-node.  The dW work of a tile-node is spread over FOUR waves this way (Ca: all of dW_3; Cb: the first half
+// of dW_1 and the second of dW_2; F1: the other half of dW_1; F2: the other half of dW_2) -- in round 3's layout wave Cb carried
+// two whole layers and paced the pipeline together with F3.
+struct WsOpsH { u32x4 A[W16_NP], B[2][W16_NP]; };
+template <int HALF, int PIECE>
+__device__ __forceinline__ void ws16_load_hA(WsOpsH& o, const unsigned short* Dt) {
+    const unsigned short* src = Dt + PIECE * 16 * TRS + 32 * HALF;
+    const u32x2 x = ws_tr_read(src);
+    const u32x2 y = ws_tr_read(src + 4 * TRS);
+    o.A[PIECE] = u32x4{x[0], x[1], y[0], y[1]};
+}
+template <int TAU, int PIECE>
+__device__ __forceinline__ void ws16_load_hB(WsOpsH& o, const unsigned short* At) {
+    const unsigned short* src = At + PIECE * 16 * TRS + 32 * TAU;
+    const u32x2 x = ws_tr_read(src);
+    const u32x2 y = ws_tr_read(src + 4 * TRS);
+    o.B[TAU][PIECE] = u32x4{x[0], x[1], y[0], y[1]};
+}
+__device__ __forceinline__ void ws16_load_hB_all(WsOpsH& o, const unsigned short* At) {
+    ws16_load_hB<0, 0>(o, At); ws16_load_hB<1, 0>(o, At); ws16_load_hB<0, 1>(o, At); ws16_load_hB<1, 1>(o, At);
+}
+template <int IDX>
+__device__ __forceinline__ void ws16_dwh_mfma(ws_f32x16 (&dW)[2], const WsOpsH& o) {
+    constexpr int term = IDX / 2, ti = IDX % 2;
+    constexpr int pa = term == 2 ? 1 : 0, pb = term == 1 ? 1 : 0;
+    dW[ti] = ws16_mfma32(o.A[pa], o.B[ti][pb], dW[ti]);
+}
+template <int HALF>
+__device__ __forceinline__ void ws16_write_dwh(const BwdArgs& a, float* part, int l, const ws_f32x16 (&dW)[2], int lane, float inv_sigma) {
+    const MlpDev& m = a.m;
+    const int Hin = m.width[l], Hout = m.width[l + 1];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int fo = slot_feature(32 * HALF + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3));
+            const int fi = slot_feature(32 * ti + (lane & 31));
+            if (fo < Hout) {
+                const int idx = fi < Hin ? a.poffW[l] + fo * Hin + fi : (fi == Hin ? a.poffb[l] + fo : -1);
+                if (idx >= 0) part[idx] = dW[ti][v] * inv_sigma;
+            }
+        }
+}
+// quadrature tables staged in LDS by the prologue (a scalar load per step would share the LDS counter and stall every step's
+// operand wait by an L2 latency: 250 cycles per step in round 3's F3 / B1)
+__device__ __forceinline__ float ws16_ccw(const unsigned short* lds16, int k) { return reinterpret_cast<const float*>(lds16 + W16_OFF_TAB)[k]; }
+__device__ __forceinline__ float ws16_ccs(const unsigned short* lds16, int k) { return reinterpret_cast<const float*>(lds16 + W16_OFF_TAB)[W16_MAX_NODES + k]; }
 
 // ============================================================================================================ wave Ca
 // layer 1 (a_1 of a new tile-node per step, two fp16 pieces -> tile A1) and dW_3
@@ -272,7 +325,7 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
     float tk = 0.f;
     {
         const int k = ws_node(sh, cu);
-        const float uu = a.ccs[k] + 1.f;
+        const float uu = ws16_ccs(lds16, k) + 1.f;
         tk = (k == 0) ? xv : __fadd_rn(x0v, __fmul_rn(dxv, uu) * 0.5f);
     }
     WsOps ops;
@@ -284,7 +337,7 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
         WS_T(t0);
         const WsCursor nx = live ? ws_next(sh, cu) : cu;
         const int kn = ws_node(sh, nx);
-        const float ccs_n = a.ccs[kn];
+        const float ccs_n = ws16_ccs(lds16, kn);
         const unsigned short* D4 = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + trb;
         unsigned short* const O1 = lds16 + WS_OFF_A1 + rO1 + own;
         // operands of dW_3: the a_3 half came in before the barrier, the delta_4 half (written last step) here
@@ -351,7 +404,7 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
 }
 
 // ============================================================================================================ wave Cb
-// delta_4 = dout w_out act'(a_4) (dout arrives scaled by sigma), dW_2 and dW_1
+// delta_4 = dout w_out act'(a_4) (dout arrives scaled by sigma), the first half of dW_1 and the second half of dW_2
 template <int NRL>
 __device__ __forceinline__ void ws16_role_Cb(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
@@ -374,9 +427,11 @@ __device__ __forceinline__ void ws16_role_Cb(const BwdBf16Args& args, unsigned s
             const int f = feat_of(t, r, g);
             wout[t][r] = f < HL ? m.W[L][f] : 0.f;       // (no cotangent through the constant feature's slot)
         }
-    ws_f32x16 dW2[2][2], dW1[2][2];
-    ws16_zero_dw(dW2);
-    ws16_zero_dw(dW1);
+    ws_f32x16 dW2[2], dW1[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { dW2[ti][v] = 0.f; dW1[ti][v] = 0.f; }
     unsigned q4[8][W16_NP];
     float rb0[8], rb1[8];
 #pragma unroll
@@ -385,13 +440,9 @@ __device__ __forceinline__ void ws16_role_Cb(const BwdBf16Args& args, unsigned s
     int rA2 = ws_ring0<WS_NS2, WS_TILE>(9), rA1 = ws_ring0<WS_NS1, WS_TILE>(10);
     int rD3 = ws_ring0<2, WS_TILE>(9), rD2 = ws_ring0<2, WS_TILE>(10);
     int rS4 = ws_ring0<2, WS_P3>(7), rD4 = ws_ring0<2, WS_TILE>(7);
-    WsOps o2, o1;
-    {   // (first step: the tiles are still zero)
-        const unsigned short* A2n = lds16 + WS_OFF_A2 + rA2 + trb;
-        const unsigned short* A1n = lds16 + WS_OFF_A1 + rA1 + trb;
-        W16_LOAD_B(o2, A2n);
-        W16_LOAD_B(o1, A1n);
-    }
+    WsOpsH o2, o1;
+    ws16_load_hB_all(o2, lds16 + WS_OFF_A2 + rA2 + trb);          // (first step: the tiles are still zero)
+    ws16_load_hB_all(o1, lds16 + WS_OFF_A1 + rA1 + trb);
     for (int s = 0; s < S; ++s) {
         WS_T(t0);
         // delta_4 of element s - 7 from what F3 left a step ago, as micro-operations behind the matrix instructions below
@@ -404,7 +455,7 @@ __device__ __forceinline__ void ws16_role_Cb(const BwdBf16Args& args, unsigned s
         const unsigned short* D3 = lds16 + WS_OFF_D + 2 * WS_TILE + rD3 + trb;
         const unsigned short* D2 = lds16 + WS_OFF_D + 0 * WS_TILE + rD2 + trb;
         // (the a_2 / a_1 halves of the operands came in before the barrier: only the cotangent halves, written last step, are fetched here)
-        W16_LOAD_A(o2, D3);
+        ws16_load_hA<1, 0>(o2, D3); ws16_load_hA<1, 1>(o2, D3);
         float d4[BT][4];
         auto d4_reg = [&](auto ec) __attribute__((always_inline)) {
             constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
@@ -426,9 +477,11 @@ __device__ __forceinline__ void ws16_role_Cb(const BwdBf16Args& args, unsigned s
         swp_static_for<24>([&](auto nc) {
             constexpr int nn = decltype(nc)::value;
             WS_MARK(nn, 24);
-            if constexpr (nn < 12) ws16_dw_mfma<nn>(dW2, o2);
-            else ws16_dw_mfma<nn - 12>(dW1, o1);
-            if constexpr (nn < 4) ws_load_op<nn>(o1, D2, D2);
+            // twelve matrix instructions over the 24 slots: the dW_2 half on the even slots of the first half, the dW_1 half after it
+            if constexpr (nn < 12 && nn % 2 == 0) ws16_dwh_mfma<nn / 2>(dW2, o2);
+            if constexpr (nn >= 12 && nn % 2 == 0) ws16_dwh_mfma<(nn - 12) / 2>(dW1, o1);
+            if constexpr (nn == 0) ws16_load_hA<0, 0>(o1, D2);
+            if constexpr (nn == 1) ws16_load_hA<0, 1>(o1, D2);
             // one register per slot, pair j split at slots 2j + 2 / 2j + 3, K-steps stored at 10, 11 / 18, 19
             if constexpr (nn < 16) d4_reg(std::integral_constant<int, nn>{});
             if constexpr (nn >= 2 && nn < 18 && (nn % 2) == 0) pair4(std::integral_constant<int, (nn - 2) / 2>{}, std::integral_constant<int, 0>{});
@@ -440,25 +493,23 @@ __device__ __forceinline__ void ws16_role_Cb(const BwdBf16Args& args, unsigned s
         ws_adv<WS_NS2, WS_TILE>(rA2); ws_adv<WS_NS1, WS_TILE>(rA1);
         ws_adv<2, WS_TILE>(rD3); ws_adv<2, WS_TILE>(rD2);
         ws_adv<2, WS_P3>(rS4); ws_adv<2, WS_TILE>(rD4);
-        {   // next step's a_2 / a_1 operands (tiles written six and ten steps ago)
-            const unsigned short* A2n = lds16 + WS_OFF_A2 + rA2 + trb;
-            const unsigned short* A1n = lds16 + WS_OFF_A1 + rA1 + trb;
-            W16_LOAD_B(o2, A2n);
-            W16_LOAD_B(o1, A1n);
-        }
+        // next step's a_2 / a_1 operands (tiles written six and ten steps ago)
+        ws16_load_hB_all(o2, lds16 + WS_OFF_A2 + rA2 + trb);
+        ws16_load_hB_all(o1, lds16 + WS_OFF_A1 + rA1 + trb);
         WS_T(t2);
         __syncthreads();
         WS_T(t3);
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
     WS_TIMING_OUT(S);
-    ws16_write_dw(a, part, 2, dW2, lane, inv_sigma);
-    ws16_write_dw(a, part, 1, dW1, lane, inv_sigma);
+    ws16_write_dwh<1>(a, part, 2, dW2, lane, inv_sigma);
+    ws16_write_dwh<0>(a, part, 1, dW1, lane, inv_sigma);
 }
 
 // ============================================================================================================ waves F1..F3
 // forward GEMM of hidden layer LAYER -> LAYER + 1: W_l as two fp16 pieces (64 registers) for the whole launch; per step 24 MFMAs
-// on one tile-node with the activation / split of the tile-node before behind them; F3 ends in the output layer
+// on one tile-node with the activation / split of the tile-node before behind them; F1, F2 also carry one half of a dW product
+// (F1: the second half of dW_1, F2: the first half of dW_2); F3 ends in the output layer
 template <int NRL, int LAYER>
 __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
@@ -468,12 +519,15 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
     constexpr int DP = 2 * LAYER;
     constexpr bool IS_OUT = LAYER == 3;
     constexpr int LO = LAYER < 3 ? LAYER + 1 : 3;      // layer of the activation tile this wave writes (F3 writes the S4 tile instead)
+    constexpr bool HAS_DW = LAYER < 3;                 // half a dW product: layer DWL, 32-row block DWH, element s - DD
+    constexpr int DWL = LAYER == 1 ? 1 : 2, DWH = LAYER == 1 ? 1 : 0, DD = 11 - DWL;
     const BwdArgs& a = args.b;
     const MlpDev& m = a.m;
     const int lane = threadIdx.x & 63, g = lane >> 4, p = lane & 15;
     const int HL = m.width[L], n = a.n;
     const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
     const int own = p * TRS + g * 16;
+    const int trb = (8 * (g >> 1) + (p >> 2)) * TRS + 16 * (g & 1) + 4 * (p & 3);
     const int nit = sh.nit;
     u32x4 Wf[BT][BKS][W16_NP];
     {
@@ -525,26 +579,33 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
     if (nit > 0) new_item_P();
 
     f32x4 acc[BT];
-    float actF[BT][4], delta[BT][4];                   // (delta: the tangent values of a tangent element)
+    float actF[BT][4];
 #pragma unroll
     for (int t = 0; t < BT; ++t) {
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { actF[t][r] = 0.f; delta[t][r] = 0.f; }
+        for (int r = 0; r < 4; ++r) actF[t][r] = 0.f;
     }
     unsigned qF[8][W16_NP], q4[8];
     float rf0[8], rf1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { rf0[j] = rf1[j] = 0.f; qF[j][0] = qF[j][1] = 0u; q4[j] = 0u; }
     float sd4[4] = {0.f, 0.f, 0.f, 0.f}, doutN = 0.f;
-    float sc_a = 0.f, sc_sd = 0.f, sc_ex = 0.f, sc_s1 = 0.f, sc_f = 0.f, sc_fp = 0.f;
-    const bool sig = m.out_act != UMNN_OUT_ELU_PLUS_ONE;
+    float sc_a = 0.f, sc_sd = 0.f, sc_ex = 0.f, sc_f = 0.f, sc_fp = 0.f;      // (ELU + 1 outputs only: the launcher keeps sigmoid nets on the bf16 pipeline)
 
     WS_TIMING_DECL;
     int rAin = ws_ring0<ws_a_ns(LAYER), WS_TILE>(DF);
     int rAout = ws_ring0<ws_a_ns(LO), WS_TILE>(DP), rD4 = ws_ring0<2, WS_P3>(DP);
     float ccwP = 0.f;
-    if constexpr (IS_OUT) ccwP = a.ccw[ws_node(sh, cp)];
+    if constexpr (IS_OUT) ccwP = ws16_ccw(lds16, ws_node(sh, cp));
+    ws_f32x16 dWh[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) dWh[ti][v] = 0.f;
+    int rAdw = ws_ring0<ws_a_ns(DWL), WS_TILE>(DD), rDdw = ws_ring0<2, WS_TILE>(DD);
+    WsOpsH oh;
+    if constexpr (HAS_DW) ws16_load_hB_all(oh, lds16 + ws_a_off(DWL) + rAdw + trb);
     for (int s = 0; s < S; ++s) {
         WS_T(t0);
         const bool liveP = s >= DP && cp.j < nit;
@@ -553,9 +614,10 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
         const WsCursor nxP = liveP ? ws_next(sh, cp) : cp;
         float ccw_n = 0.f;
         if constexpr (IS_OUT) {
-            ccw_n = a.ccw[ws_node(sh, nxP)];
+            ccw_n = ws16_ccw(lds16, ws_node(sh, nxP));
             if (liveP && cp.e == 0) new_item_P();
         }
+        const float nodef = (liveP && !tanP) ? 1.f : 0.f, k0f = kP == 0 ? 1.f : 0.f;
         const unsigned short* Ain = lds16 + ws_a_off(LAYER) + rAin + own;                  // a_l[s - DF]
         unsigned short* const Aout = lds16 + ws_a_off(LO) + rAout + own;                   // a_{l+1}[s - DP]
         unsigned short* const S4out = lds16 + W16_OFF_S4 + rD4;                            // F3: leading piece of a_4[s - 6], dout
@@ -564,6 +626,10 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
         for (int s2 = 0; s2 < BKS; ++s2)
 #pragma unroll
             for (int k2 = 0; k2 < W16_NP; ++k2) bf.v[s2][k2] = *reinterpret_cast<const u32x4*>(Ain + k2 * 16 * TRS + s2 * 8);
+        if constexpr (HAS_DW) {
+            const unsigned short* Ddw = lds16 + WS_OFF_D + (DWL + 1 - 2) * 2 * WS_TILE + rDdw + trb;      // delta_{DWL+1}[s - DD]
+            ws16_load_hA<DWH, 0>(oh, Ddw); ws16_load_hA<DWH, 1>(oh, Ddw);
+        }
 
         // ---- micro-operations of the vector work of element s - DP
         auto act_reg = [&](auto ec, auto tanc) __attribute__((always_inline)) {
@@ -580,8 +646,7 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
                         actF[t][r] = hidden_act_f(acc[t][r], slope);
                     }
                 } else {
-                    if constexpr (TAN) delta[t][r] = acc[t][r] * (actF[t][r] > 0.f ? 1.f : slope);
-                    else actF[t][r] = hidden_act_f(acc[t][r], slope);
+                    actF[t][r] = hidden_act_f(acc[t][r], slope);
                 }
             }
         };
@@ -597,11 +662,26 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
             *reinterpret_cast<u32x4*>(Aout + k2 * 16 * TRS + ks * 8) = u32x4{qF[4 * ks][k2], qF[4 * ks + 1][k2], qF[4 * ks + 2][k2], qF[4 * ks + 3][k2]};
         };
         // F3: output layer of element s - 6 (four partial sums: no thirteen-deep dependent chain in front of the matrix loop)
-        auto out_dot = [&](auto ec, auto tanc) __attribute__((always_inline)) {
+        auto out_dot = [&](auto ec) __attribute__((always_inline)) {
             constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
-            constexpr bool TAN = decltype(tanc)::value;
             if constexpr (e < 4) sd4[e] = 0.f;
-            if constexpr (e < NLIVE) sd4[r] = fmaf(wout[t][r], TAN ? delta[t][r] : actF[t][r], sd4[r]);
+            if constexpr (e < NLIVE) sd4[r] = fmaf(wout[t][r], actF[t][r], sd4[r]);
+        };
+        // tangent element (once per tile): the dot product of w_out with d a_L / d t = acc . act'(a_L of node 0) instead; the sign of
+        // a_L(node 0) is read back from the S4 tile this wave wrote a step ago, so that no activation value is carried from step
+        // to step (the carried copy cost ~40 register moves per step on BOTH paths)
+        auto out_dot_tangent = [&]() __attribute__((always_inline)) {
+            const unsigned short* S4prev = lds16 + W16_OFF_S4 + (rD4 ^ WS_P3) + own;
+            u32x4 sgp[BKS];
+#pragma unroll
+            for (int s2 = 0; s2 < BKS; ++s2) sgp[s2] = *reinterpret_cast<const u32x4*>(S4prev + s2 * 8);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sd4[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < BT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * t + r < NLIVE) sd4[r] = fmaf(wout[t][r], acc[t][r] * act_grad_q(sgp, t, r, slope), sd4[r]);
         };
         // the scalar part in stages, one per matrix-instruction slot (a serial chain: cross-lane sum, exp, reciprocal, selects)
         auto out_scalar = [&](auto stc) __attribute__((always_inline)) {
@@ -617,24 +697,16 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
                 auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
                 sc_sd = __uint_as_float(q[0]) + __uint_as_float(q[1]);
             }
-            if constexpr (st == 3) sc_ex = __expf(sig ? -sc_sd : sc_sd);
-            if constexpr (st == 4) sc_s1 = __builtin_amdgcn_rcpf(1.f + sc_ex);   // (sigmoid outputs only: 1 ulp; ELU+1 does not use it)
-            if constexpr (st == 5) {
-                sc_f = sig ? sc_s1 : (sc_sd > 0.f ? sc_sd + 1.f : sc_ex);
-                sc_fp = sig ? sc_s1 * (1.f - sc_s1) : (sc_sd > 0.f ? 1.f : sc_ex);
+            if constexpr (st == 3) sc_ex = __expf(sc_sd);
+            if constexpr (st == 4) {
+                sc_f = sc_sd > 0.f ? sc_sd + 1.f : sc_ex;
+                sc_fp = sc_sd > 0.f ? 1.f : sc_ex;
             }
+            if constexpr (st == 5) bad = bad || !ws16_finite(sc_sd);
             if constexpr (st == 6) {
-                const bool node = liveP && !tanP;
-                if (node && kP == 0) { fxv = sc_f; fp0 = sc_fp; }
-                if (node && kP == n) fx0v = sc_f;
-                // tangent element: the sum is w_out . d a_L / d t at node 0 -> d f / d t
-                if (tanP) dfdt = fp0 * sc_sd;
-                bad = bad || (liveP && !ws16_finite(sc_sd));
-            }
-            if constexpr (st == 7) {
-                const bool node = liveP && !tanP;
-                const float cot = fmaf(cotbase, ccwP, kP == 0 ? gfxS : 0.f) * (node ? 1.f : 0.f);
-                doutN = cot * sc_fp;                                               // (no cotangent flows back from a tangent element)
+                // (no cotangent flows back from a tangent element or a drained slot: their factor is 0; g_fx enters at node 0)
+                const float cot = fmaf(cotbase, ccwP, gfxS * k0f) * nodef;
+                doutN = cot * sc_fp;
             }
         };
         auto out_reg = [&](auto ec) __attribute__((always_inline)) {       // d w_out += dout a_L  (delta_L is formed by wave Cb)
@@ -650,16 +722,22 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
             *reinterpret_cast<u32x4*>(S4out + own + ks * 8) = u32x4{q4[4 * ks], q4[4 * ks + 1], q4[4 * ks + 2], q4[4 * ks + 3]};
         };
         WS_T(t1);
-        // ---- the activations of element s - DP first (registers only: the operand fetches above are still in flight)
-        if (tanP) {
-            swp_static_for<16>([&](auto ec) { act_reg(ec, std::true_type{}); });
-            if constexpr (IS_OUT) swp_static_for<16>([&](auto ec) { out_dot(ec, std::true_type{}); });
-        } else {
+        // ---- the activations (and F3's dot product) of element s - DP first, as one burst of vector instructions while the operand
+        // fetches above are in flight; then the GEMM of element s - DF (24 MFMAs, A operands = this wave's registers) with the rest of
+        // the vector work behind its matrix instructions.  Measured alternatives (EXPERIMENTS.md): the burst spread behind the matrix
+        // instructions too makes every F role 5-20 % longer (a vector instruction directly behind an MFMA waits out that
+        // instruction's issue passes); a second copy of the matrix loop for tangent elements costs 8 % of the kernel (the eight role
+        // loops together sit at the instruction cache's capacity).  Only these activations differ for a tangent element, so the
+        // uniform branch covers the burst alone.
+        if constexpr (IS_OUT) {
             swp_static_for<16>([&](auto ec) { act_reg(ec, std::false_type{}); });
-            if constexpr (IS_OUT) swp_static_for<16>([&](auto ec) { out_dot(ec, std::false_type{}); });
+            swp_static_for<16>([&](auto ec) { out_dot(ec); });
+            if (tanP) out_dot_tangent();
+        } else {
+            if (tanP) swp_static_for<16>([&](auto ec) { act_reg(ec, std::true_type{}); });
+            else swp_static_for<16>([&](auto ec) { act_reg(ec, std::false_type{}); });
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- the GEMM of element s - DF (24 MFMAs, A operands = this wave's registers); behind it the rest of the vector work
         {
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             swp_static_for<24>([&](auto nc) {
@@ -668,6 +746,7 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
                 constexpr int s2 = nn / 12, term = (nn % 12) / 4, t = nn % 4;
                 constexpr int wa = term == 2 ? 1 : 0, ba = term == 1 ? 1 : 0;
                 acc[t] = mfma_f16(Wf[t][s2][wa], bf.v[s2][ba], nn < 4 ? zero : acc[t]);
+                if constexpr (HAS_DW && nn % 4 == 3) ws16_dwh_mfma<nn / 4>(dWh, oh);
                 if constexpr (!IS_OUT) {
                     // the split of a_{l+1}: per K-step the four pairs stage by stage, then its two stores (20 micro-operations)
                     if constexpr (nn < 20) {
@@ -677,7 +756,7 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
                     }
                 } else {
                     // the leading piece of a_L does not wait for the scalar chain; dout and d w_out follow it
-                    if constexpr (nn < 8) out_scalar(std::integral_constant<int, nn>{});
+                    if constexpr (nn < 7) out_scalar(std::integral_constant<int, nn>{});
                     if constexpr (nn < 8) pair4(std::integral_constant<int, nn>{});
                     if constexpr (nn == 8 || nn == 9) store_s4(std::integral_constant<int, nn - 8>{});
                     if constexpr (nn == 9) *reinterpret_cast<float*>(S4out + p * TRS + 64) = doutN;
@@ -686,8 +765,13 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
-        // ---- item boundary (outside the scheduled region: uniform branch)
+        // ---- what only some elements of a tile do (uniform branches outside the scheduled region)
         if constexpr (IS_OUT) {
+            if (liveP) {
+                if (tanP) dfdt = fp0 * sc_sd;            // the sum was w_out . d a_L / d t at node 0 -> d f / d t
+                else if (kP == 0) { fxv = sc_f; fp0 = sc_fp; }
+                else if (kP == n) fx0v = sc_f;
+            }
             if (liveP && cp.e == sh.ne - 1) {
                 const long long q = (long long)(args.grp0 + ws_grp(cp)) * 16 + p;
                 if (q < a.NI && g == 0) {
@@ -700,12 +784,17 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
         ccwP = ccw_n;
         ws_adv<ws_a_ns(LAYER), WS_TILE>(rAin);
         ws_adv<ws_a_ns(LO), WS_TILE>(rAout); ws_adv<2, WS_P3>(rD4);
+        if constexpr (HAS_DW) {
+            ws_adv<ws_a_ns(DWL), WS_TILE>(rAdw); ws_adv<2, WS_TILE>(rDdw);
+            ws16_load_hB_all(oh, lds16 + ws_a_off(DWL) + rAdw + trb);      // next step's a_l operand of the dW half (an old tile)
+        }
         WS_T(t2);
         __syncthreads();
         WS_T(t3);
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
     WS_TIMING_OUT(S);
+    if constexpr (HAS_DW) ws16_write_dwh<DWH>(a, part, DWL, dWh, lane, inv_sigma);
     if constexpr (IS_OUT) {
 #pragma unroll
         for (int t = 0; t < BT; ++t)
@@ -775,7 +864,7 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
     float tkB = 0.f;
     if constexpr (IS_TAIL) {
         const int kB = ws_node(sh, cb);
-        const float uu = a.ccs[kB] + 1.f;
+        const float uu = ws16_ccs(lds16, kB) + 1.f;
         tkB = (kB == 0) ? xvB : __fadd_rn(x0vB, __fmul_rn(dxvB, uu) * 0.5f);
     }
     for (int s = 0; s < S; ++s) {
@@ -787,7 +876,7 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
         if constexpr (IS_TAIL) {
             if (liveB) nxB = ws_next(sh, cb);
             kBn = ws_node(sh, nxB);
-            ccs_n = a.ccs[kBn];
+            ccs_n = ws16_ccs(lds16, kBn);
         }
         const unsigned short* Asg = lds16 + ws_a_off(LAYER) + rAsg + own;                                  // a_l[s - DB]
         const unsigned short* Din = lds16 + WS_OFF_D + (LAYER + 1 - 2) * 2 * WS_TILE + rDin + own;         // delta_{l+1}[s - DB]
@@ -900,10 +989,17 @@ __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws16_kernel(const Bwd
     const MlpDev& m = a.m;
     const int tid = threadIdx.x;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- the weights: staged once as fp16 fragment images, then read into the owners' registers
+    // ---- the weights: staged once as fp16 fragment images, then read into the owners' registers; the quadrature tables
     for (int l = 1; l <= 3; ++l) {
         ws16_stage_image<false>(m, l, lds16 + (l - 1) * W16_IMG, tid, blockDim.x);
         ws16_stage_image<true>(m, l, lds16 + (3 + l - 1) * W16_IMG, tid, blockDim.x);
+    }
+    {
+        float* tab = reinterpret_cast<float*>(lds16 + W16_OFF_TAB);
+        for (int k = tid; k < W16_MAX_NODES; k += blockDim.x) {
+            tab[k] = k <= a.n ? a.ccw[k] : 0.f;
+            tab[W16_MAX_NODES + k] = k <= a.n ? a.ccs[k] : 0.f;
+        }
     }
     __syncthreads();
     const int role = wid & 3, upper = wid >> 2;
