@@ -19,7 +19,13 @@ import os
 import sys
 import time
 
-import torch
+# RCCL / device-tensor sharing between the ranks of a node goes through dmabuf IPC on this driver stack; the legacy mode fails with
+# "hipIpcGetMemHandle: invalid argument".  The HSA runtime reads the variable when it initialises, so it has to be in the
+# environment BEFORE torch touches the GPU: set here, ahead of `import torch` (an explicit setting wins).
+_IPC_SET_BY = "environment" if "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ else "bench.py"
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -42,8 +48,9 @@ FULL_BATCH_ROWS = 65536            # BASELINE config C3's un-sharded batch
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 2:1-sparse figure is never used)
 # sources that define the dominant forward kernel: profiles/hbm_traffic.json is only trusted while their hash matches
-TRAFFIC_SOURCES = ["umnn_amd/csrc/cc_forward_bf16.hip", "umnn_amd/csrc/cc_fwd_bf16_kernel.h", "umnn_amd/csrc/cc_fwd_shared.h",
-                   "umnn_amd/csrc/cc_common.h", "umnn_amd/csrc/cc_bf16.h", "umnn_amd/csrc/cc_forward.hip"]
+# (the translation unit and the two headers that hold the kernel's code; cc_common.h / cc_bf16.h also carry helpers of the BACKWARD
+# kernels -- hashing them made round 3's record go stale over an unrelated change)
+TRAFFIC_SOURCES = ["umnn_amd/csrc/cc_forward_bf16.hip", "umnn_amd/csrc/cc_fwd_bf16_kernel.h", "umnn_amd/csrc/cc_fwd_shared.h"]
 
 
 def kernel_source_hash():
@@ -70,7 +77,7 @@ def make_inputs(cfg, rows, device, seed):
     return x, ctx
 
 
-def cpu_baseline(cfg, model, budget_s=52.0):
+def cpu_baseline(cfg, model, budget_s=60.0):
     """Time the torch port of the reference's compute_ll with BOTH of its quadrature solvers -- the materialised
     ``ParallelNeuralIntegral`` (ParallelNeuralIntegral.py:37-65) and the node-by-node ``NeuralIntegral``
     (NeuralIntegral.py:37-66) -- on the host cores, on a bounded sample of the same workload (row chunks; the un-chunked
@@ -83,17 +90,21 @@ def cpu_baseline(cfg, model, budget_s=52.0):
     ncpu = os.cpu_count() or 1
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     blocks = TP.blocks_from_state_dict(sd, cfg["nb_flow"])
-    chunk = 128 if cfg["d"] > 8 else 1024
-    chunks = []
+    chunk_full = 128 if cfg["d"] > 8 else 1024
+    chunks_full = []
     for seed in (123, 456):
         g = torch.Generator().manual_seed(seed)
-        chunks.append((torch.randn(chunk, cfg["d"], generator=g),
-                       torch.randn(chunk, cfg["cond"], generator=g) if cfg.get("cond", 0) else None))
+        chunks_full.append((torch.randn(chunk_full, cfg["d"], generator=g),
+                            torch.randn(chunk_full, cfg["cond"], generator=g) if cfg.get("cond", 0) else None))
     solvers = {}
     old_threads = torch.get_num_threads()
     WARMUP, REPS = 3, 10
     with torch.no_grad():
-        for name, solver, share in (("sequential", "CC", 0.45), ("parallel", "CCParallel", 0.55)):
+        for name, solver, share in (("sequential", "CC", 0.42), ("parallel", "CCParallel", 0.58)):
+            # (the materialised solver is ~2x slower per row: half the rows per call, so that 3 warm-up + 10 timed calls fit its share)
+            chunk = chunk_full // 2 if (name == "parallel" and cfg["d"] > 8) else chunk_full
+            chunks = [(xx[:chunk], cc[:chunk] if cc is not None else None) for xx, cc in chunks_full]
+
             def run(i=0):
                 xx, cc = chunks[i % 2]
                 return TP.flow_compute_ll(blocks, xx, cfg["n"], solver=solver, context=cc)
@@ -131,7 +142,7 @@ def cpu_baseline(cfg, model, budget_s=52.0):
             # the all-cores setting can take minutes per call for these skinny GEMMs, and a torch call cannot be interrupted
             allc = None
             if threads != ncpu:
-                allc = _all_cores_probe(sd, cfg, solver, chunks[0], ncpu, limit_s=max(8.0, 0.25 * share * budget_s))
+                allc = _all_cores_probe(sd, cfg, solver, chunks[0], ncpu, limit_s=8.0)
             solvers[name] = {"evals_per_s": chunk / med, "threads": threads, "chunk_rows": chunk, "chunks": 2,
                              "warmup": warm, "reps": len(times), "budget_limited": len(times) < REPS or warm < WARMUP,
                              "min_ms": 1e3 * min(times), "median_ms": 1e3 * med, "max_ms": 1e3 * max(times),
@@ -141,6 +152,7 @@ def cpu_baseline(cfg, model, budget_s=52.0):
                              else "models/UMNN/NeuralIntegral.py:37-66"}
     torch.set_num_threads(old_threads)
     fast = max(solvers, key=lambda k: solvers[k]["evals_per_s"])
+    chunk = solvers[fast]["chunk_rows"]
     return {"value": solvers[fast]["evals_per_s"], "unit": "evals/s", "cores": solvers[fast]["threads"], "kind": "port",
             "solver": fast, "solvers": solvers, "host_cores": ncpu, "torch_parallel_info": torch.__config__.parallel_info().split("\n")[0:3],
             "sample": f"two {chunk}-row chunks of the same flow through oracle/torch_port.py (torch CPU port of the reference's "
@@ -176,24 +188,31 @@ def _all_cores_probe(sd, cfg, solver, chunk, ncpu, limit_s):
 
 def hbm_traffic(workload, live, extra_args):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; one counter per
-    pass; gfx950 corrections per MI355X_MICROARCH.md).  ``live``: collect now (tools/measure_traffic.py, two child runs of
-    this script under rocprofv3).  Otherwise the committed profiles/hbm_traffic.json -- trusted only while the kernel
-    sources hash to what was profiled; else null."""
+    pass; gfx950 corrections per MI355X_MICROARCH.md).  The committed profiles/hbm_traffic.json is used while the kernel's
+    sources hash to what was profiled; when they do not (or with ``live``) the two passes are collected NOW
+    (tools/measure_traffic.py: two short child runs of this script under rocprofv3, ~1 min) -- a stale number is never
+    reported, and a missing profiler leaves null with the reason."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if live:
+    why = "--live-traffic"
+    if not live:
         try:
-            from tools import measure_traffic
-            rec = measure_traffic.measure(workload, extra_args)
-            return rec.get("hbm_bytes_per_launch"), "live rocprofv3 PMC passes in this run"
-        except Exception as e:      # profiler missing / refused: report null, never a stale number
-            return None, f"live collection failed: {e}"
+            rec = json.load(open(path)).get(workload, {})
+        except Exception:
+            rec = {}
+        if rec.get("source_sha256") == kernel_source_hash():
+            return rec.get("hbm_bytes_per_launch"), f"profiles/hbm_traffic.json (kernel sources {rec.get('source_sha256')} = HEAD's)"
+        why = "profiles/hbm_traffic.json is for other kernel sources" if rec else "no committed record for this workload"
+    if os.environ.get("UMNN_BENCH_CHILD"):          # (a profiling child of this very function)
+        return None, "profiling child run"
+    import shutil
+    if not shutil.which("rocprofv3"):
+        return None, f"{why}; rocprofv3 not on PATH"
     try:
-        rec = json.load(open(path)).get(workload, {})
-    except Exception:
-        return None, "profiles/hbm_traffic.json missing"
-    if rec.get("source_sha256") != kernel_source_hash():
-        return None, "profiles/hbm_traffic.json was collected for different kernel sources (stale): re-run tools/profile_bench.sh"
-    return rec.get("hbm_bytes_per_launch"), f"profiles/hbm_traffic.json (sources {rec.get('source_sha256')})"
+        from tools import measure_traffic
+        rec = measure_traffic.measure(workload, extra_args)
+        return rec.get("hbm_bytes_per_launch"), f"measured in this run ({why}): rocprofv3 PMC passes, kernel sources {kernel_source_hash()}"
+    except Exception as e:      # profiler refused / timed out: report null, never a stale number
+        return None, f"{why}; live collection failed: {e}"
 
 
 def main():
@@ -206,7 +225,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact_fp32 and full_batch_n1 records (profiling runs)")
     ap.add_argument("--no-fused-adam", action="store_true", help="train mode: torch's foreach Adam instead of the fused one")
-    ap.add_argument("--no-telemetry", action="store_true", help="do not sample socket power / shader clock during the timed region")
+    ap.add_argument("--no-telemetry", action="store_true",
+                    help="skip the telemetry pass (socket power / shader clock are sampled over a SEPARATE run of the same steps right "
+                         "after the timed region, so the polling thread never shares the timed region with the launches)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank owns `rows` rows, the global batch grows with N.  strong: the workload's GLOBAL batch "
+                         "(bsds300: BASELINE's 65536 rows) is split over the ranks by sharding.shard_bounds, so N = 1, 2, 4, 8 time the same problem")
     ap.add_argument("--live-traffic", action="store_true",
                     help="measure roofline.traffic now with two rocprofv3 PMC child runs instead of reading profiles/")
     ap.add_argument("--mode", default="eval", choices=["eval", "train"],
@@ -225,12 +249,19 @@ def main():
 
     from umnn_amd import _lib, sharding
     import torch.distributed as dist
-    rank, world, device = sharding.init_from_env()
+    rank, world, device = sharding.init_from_env(force_group=bool(os.environ.get("UMNN_FORCE_GROUP")))
     assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs a GPU"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     cfg = dict(WORKLOADS[args.workload])
     if args.rows:
         cfg["rows"] = args.rows
+    # strong scaling: the global batch is fixed (C3: BASELINE's 65536 rows; otherwise the workload's batch) and this rank owns
+    # rows [lo, hi) of it; weak: `rows` per rank
+    global_rows = (FULL_BATCH_ROWS if args.workload == "bsds300" and not args.rows else cfg["rows"]) if args.scaling == "strong" \
+        else cfg["rows"] * world
+    if args.scaling == "strong":
+        lo, hi = sharding.shard_bounds(global_rows, rank, world)
+        cfg["rows"] = hi - lo
     lib = _lib.lib()
     if args.precision:
         _lib.set_forward_precision(args.precision)
@@ -276,20 +307,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # socket power / shader clock while the timed region runs (rank 0; a background thread polling the SMU metrics table)
-    sampler = None
-    if rank == 0 and not args.no_telemetry:
-        try:
-            from tools.telemetry import Sampler
-            sampler = Sampler(device.index or 0)
-        except Exception:
-            sampler = None
     lib.umnn_profile_enable(1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if sampler is not None:
-        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ll, _ = step()
@@ -297,7 +318,6 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    telemetry = sampler.stop() if sampler is not None else None
     fwd = _lib.profile_read(_lib.PROF_FORWARD)
     bwd = _lib.profile_read(_lib.PROF_BACKWARD)
     fin = _lib.profile_read(_lib.PROF_FINISH)
@@ -311,30 +331,60 @@ def main():
         lib.umnn_profile_enable(0)
     assert torch.isfinite(ll).all()
     kernel_name = lib.umnn_last_kernel_name_of(_lib.PROF_FORWARD if args.mode == "eval" else _lib.PROF_BACKWARD).decode()
+    # socket power / shader clock of this workload (rank 0, eval): a 50-Hz polling thread over a SEPARATE repeat of the timed steps
+    # (at least ~0.5 s of them), after the timed region -- the thread never competes with the launches that are timed.  Any failure
+    # of the telemetry source leaves null fields, never takes the line down.
+    telemetry = None
+    if rank == 0 and world == 1 and args.mode == "eval" and not args.no_telemetry:
+        try:
+            from tools.telemetry import Sampler
+            sampler = Sampler(device.index or 0)
+            reps = max(args.steps, int(0.5 / max(elapsed / args.steps, 1e-6)))
+            sampler.start()
+            try:
+                for _ in range(min(reps, 20000)):
+                    step()
+                torch.cuda.synchronize()
+            finally:
+                telemetry = sampler.stop()
+            if telemetry is not None:
+                telemetry["pass"] = f"separate pass of {min(reps, 20000)} steps after the timed region"
+        except Exception as e:
+            telemetry = {"error": f"{type(e).__name__}: {e}"}
 
-    extras = world == 1 and args.mode == "eval" and not args.no_extras
-    # for the record: the same workload with the exact-fp32 MFMA kernels (N=1 eval only; a few untimed-by-the-driver steps)
-    exact = None
-    if extras and precision != "fp32":
+    extras = world == 1 and args.mode == "eval" and not args.no_extras and args.scaling == "weak"
+
+    def side_record(mode, peak, peak_name, conditioner):
+        """The same workload, same steps / warm-up, under another arithmetic of the whole path (N = 1 eval only)."""
         import umnn_amd
-        umnn_amd.set_precision("fp32")              # forward kernels AND conditioner GEMMs in the reference's arithmetic
-        for _ in range(args.warmup):
-            eager_step()
-        lib.umnn_profile_enable(1)
-        torch.cuda.synchronize()
-        te = time.perf_counter()
-        for _ in range(args.steps):
-            eager_step()
-        torch.cuda.synchronize()
-        te = time.perf_counter() - te
-        e_ms, e_n, e_fl = _lib.profile_read(_lib.PROF_FORWARD)
-        lib.umnn_profile_enable(0)
+        umnn_amd.set_precision(mode)
+        try:
+            for _ in range(args.warmup):
+                eager_step()
+            lib.umnn_profile_enable(1)
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            for _ in range(args.steps):
+                eager_step()
+            torch.cuda.synchronize()
+            te = time.perf_counter() - te
+            e_ms, e_n, e_fl = _lib.profile_read(_lib.PROF_FORWARD)
+            lib.umnn_profile_enable(0)
+            kname = lib.umnn_last_kernel_name().decode()
+        finally:
+            umnn_amd.set_precision(precision)
         tf = e_fl / max(e_ms, 1e-9) / 1e9
-        exact = {"value": cfg["rows"] * args.steps / te, "ms_per_step": 1e3 * te / args.steps, "steps": args.steps,
-                 "warmup": args.warmup, "kernel": lib.umnn_last_kernel_name().decode(),
-                 "avg_launch_ms": e_ms / max(1, e_n), "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
-                 "frac": tf / PEAK_FP32_MFMA_TFLOPS, "conditioner": "fp32 F.linear"}
-        umnn_amd.set_precision(precision)
+        return {"value": cfg["rows"] * args.steps / te, "unit": "evals/s", "ms_per_step": 1e3 * te / args.steps, "steps": args.steps,
+                "warmup": args.warmup, "kernel": kname, "avg_launch_ms": e_ms / max(1, e_n), "achieved": tf, "peak": peak,
+                "peak_dtype": peak_name, "frac": tf / peak, "conditioner": conditioner}
+
+    # for the record: the same workload in the reference's own arithmetic (exact fp32 products on the fp32 MFMA kernels, fp32
+    # conditioner GEMMs) and in the fp32-accurate middle mode on the bf16 matrix cores (three bf16 pieces, six cross terms: ~4e-7 on F)
+    exact = bf16x6 = None
+    if extras and precision != "fp32":
+        exact = side_record("fp32", PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA", "fp32 F.linear")
+    if extras and precision == "bf16x3":
+        bf16x6 = side_record("bf16x6", PEAK_BF16_MFMA_TFLOPS, "bf16 dense MFMA", "K-concatenated bf16 GEMMs (three products)")
     # the un-sharded C3 batch on ONE GPU (65536 rows): the anchor the 8-GPU point of the sharded run is compared with
     full = None
     if extras and args.workload == "bsds300" and not args.rows and not args.graph:
@@ -368,7 +418,7 @@ def main():
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
-        value = world * cfg["rows"] * args.steps / elapsed
+        value = global_rows * args.steps / elapsed
         dom = fwd if args.mode == "eval" else bwd           # (ms, launches, algorithmic FLOPs) of the dominant kernel class
         avg_kernel_ms = dom[0] / max(1, dom[1])
         achieved = dom[2] / max(dom[0], 1e-9) / 1e9                    # TFLOP/s over those launches
@@ -396,11 +446,14 @@ def main():
             "metric": "umnn_maf_log_density_evals_per_s" if args.mode == "eval" else "umnn_maf_training_samples_per_s",
             "value": value, "unit": "evals/s" if args.mode == "eval" else "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": cfg["desc"], "rows_per_gpu": cfg["rows"], "dim": cfg["d"], "n_steps": cfg["n"],
                        "nb_flow": cfg["nb_flow"], "embedding": cfg["E"], "integrand": cfg["hd"], "made": cfg["he"],
                        "cond_in": cfg.get("cond", 0),
-                       "sharding": f"batch x{world}, no forward collective",
+                       "global_rows": global_rows,
+                       "sharding": (f"weak: {cfg['rows']} rows on each of {world} rank(s), no forward collective" if args.scaling == "weak" else
+                                    f"strong: the global batch of {global_rows} rows split over {world} rank(s) by sharding.shard_bounds "
+                                    f"(rank 0 owns {cfg['rows']}), no forward collective"),
                        "embedding_storage": args.embedding,
                        "integrals_per_s": value * cfg["d"] * cfg["nb_flow"]},
             # achieved = ALGORITHMIC fp32 FLOPs (backward = 3 x forward) / kernel time; peak = dense MFMA peak
@@ -426,11 +479,14 @@ def main():
             "ranks_seen": len(ranks), "ranks": ranks,
             "dist": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
                      "backend": dist.get_backend() if dist.is_initialized() else None},
+            "env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "set_by": _IPC_SET_BY},
         }
         if args.graph:
             out["config"]["graph"] = "step replayed as one hipGraph; roofline timings from an eager pass after the timed region"
         if exact is not None:
             out["exact_fp32"] = exact
+        if bf16x6 is not None:
+            out["bf16x6"] = bf16x6
         if full is not None:
             out["full_batch_n1"] = full
         if args.mode == "train":

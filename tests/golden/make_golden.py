@@ -243,8 +243,35 @@ def g7():
         save("g7_invf_" + name, **arrs)
 
 
+def g8():
+    """One case at a size the weight-stationary workgroup-pipeline backward takes (>= 4 tiles of 16 integrals per workgroup on 256
+    CUs: 280 x 63 = 17 640 integrals), so that a REFERENCE-produced d_theta / d_h exists at that size:
+    ParallelNeuralIntegral.apply(...).backward(g), ParallelNeuralIntegral.py:97-123."""
+    name, d, E, hid, n, B, act, wscale = "ws_d63", 63, 10, [50] * 4, 20, 280, "ELU", 1.5
+    torch.manual_seed(8000)
+    net = IntegrandNetwork(d, 1 + E, hid, 1, act_func=act)
+    with torch.no_grad():
+        for p in net.net:
+            if isinstance(p, torch.nn.Linear):
+                p.weight.mul_(wscale)
+                p.bias.mul_(wscale)
+    x, x0 = torch.randn(B, d) * 2.0, torch.randn(B, d) * 0.7
+    h, g = torch.randn(B, E * d), torch.randn(B, d)
+    arrs = dict(d=d, E=E, n=n, hidden=np.array(hid), act=act, x=x, x0=x0, h=h, g=g)
+    lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    for l, m in enumerate(lin):
+        arrs[f"W{l}"], arrs[f"b{l}"] = m.weight, m.bias
+    net.zero_grad()
+    x0r, xr, hr = x0.clone().requires_grad_(), x.clone().requires_grad_(), h.clone().requires_grad_()
+    out = ParallelNeuralIntegral.apply(x0r, xr, net, flat(net.parameters()), hr, n, False)
+    out.backward(g)
+    arrs["F_par"], arrs["dx0_par"], arrs["dx_par"], arrs["dh_par"] = out, x0r.grad, xr.grad, hr.grad
+    arrs["dtheta_par"] = flat([p.grad for p in net.parameters()])
+    save("g8_" + name, **arrs)
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7"]      # (name a subset to leave the other fixtures untouched)
+    todo = sys.argv[1:] or ["g1", "g23", "g4", "g5", "g6", "g7", "g8"]      # (name a subset to leave the other fixtures untouched)
     for name in todo:
         globals()[name]()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))

@@ -171,3 +171,72 @@ def test_one_rank_group_forced_collectives():
     pr.start()
     pr.join(120)
     assert pr.exitcode == 0 and q.get(timeout=5) == "ok"
+
+
+def _world8_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import bench
+    sharding.init_from_env(backend="gloo")
+    assert sharding.shard_bounds(65536, rank, world) == (8192 * rank, 8192 * (rank + 1))      # BASELINE C3's batch over 8 GPUs
+    model = _model()
+    with torch.no_grad():                                       # every replica starts somewhere else; broadcast fixes that
+        for p in model.parameters():
+            p.add_(0.01 * rank)
+    sharding.broadcast_parameters(model, src=0)
+    model.train()
+    torch.manual_seed(21)
+    x = torch.randn(40, 3) * 2                                  # the global batch (identical on every rank); 5 rows per rank
+    xs = sharding.shard_rows(x, rank, world).contiguous()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2)
+    step = bench.make_train_step(model, opt, xs, None, world, clip_value=0.05)     # bench.py's own step closure
+    for _ in range(2):
+        step()
+    torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, os.path.join(outdir, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_train_step_eight_ranks_replicas_stay_bit_identical():
+    """bench.py's train step on EIGHT gloo ranks (the node size the metric is quoted on): the C3 batch's shard
+    bounds are 8192-row blocks, after two optimisation steps all eight replicas hold bit-identical weights, and those match
+    single-process training on the whole batch (UCIExperiments.py:133-146: one gradient, clipped after the reduction)."""
+    import bench
+    world = 8
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_world8_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        parts = [torch.load(os.path.join(out, f"w{r}.pt")) for r in range(world)]
+    model = _model()
+    model.train()
+    torch.manual_seed(21)
+    x = torch.randn(40, 3) * 2
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2)
+    step = bench.make_train_step(model, opt, x, None, 1, clip_value=0.05)
+    for _ in range(2):
+        step()
+    ref = model.state_dict()
+    for k in ref:
+        for r in range(1, world):
+            assert torch.equal(parts[0][k], parts[r][k]), (k, r)
+        assert torch.allclose(parts[0][k], ref[k], atol=3e-6, rtol=1e-5), k
+
+
+def test_ipc_mode_is_set_before_the_gpu_runtime_can_initialise():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment before torch touches the GPU.  `import umnn_amd`
+    and `import bench` both set it when the caller has not (an explicit setting wins); sharding.init_from_env no longer does (too late)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    env["PYTHONPATH"] = root
+    for mod in ("umnn_amd", "bench"):
+        code = ("import os, sys; assert 'torch' not in sys.modules; import %s; "
+                "print('IPC', os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))" % mod)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0 and "IPC 0" in r.stdout, (mod, r.stdout, r.stderr[-500:])
+        r = subprocess.run([sys.executable, "-c", code], env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="1"), capture_output=True,
+                           text=True, timeout=300, cwd=root)
+        assert "IPC 1" in r.stdout, (mod, r.stdout)
+    import inspect
+    assert "setdefault(\"HSA_ENABLE_IPC_MODE_LEGACY\"" not in inspect.getsource(sharding.init_from_env)

@@ -374,7 +374,7 @@ def test_staged_backward_chunks_and_large_batch(dev, bwd_precision):
     assert all(torch.equal(p, q) for p, q in zip(again[1:], (dx, dh, dth)))
 
 
-def test_full_size_backward_properties_bsds300_shard(dev):
+def test_full_size_backward_properties_bsds300_shard(dev, bwd_precision):
     """BASELINE config C3 at one GPU's share (8192 x 63, n=100, 31-50^4-1), backward: (a) dh and dx of a random sample
     of rows against the oracle (they depend on their own row only), (b) shard consistency: dh/dx of two half batches
     concatenate bit-for-bit into the full batch's (the halves fall on tile boundaries) and their d_theta add up to the
@@ -391,6 +391,10 @@ def test_full_size_backward_properties_bsds300_shard(dev):
     x, h, g = torch.randn(B, d), torch.randn(B, E * d), torch.randn(B, d)
     xg, hg, gg = x.to(dev), h.to(dev), g.to(dev)
     dx0, dx, dh, dth = I.hip_backward(spec, None, xg, hg, gg, None, n)
+    # (which kernel this test exercises: the workgroup pipeline on fp16 pieces under the default arithmetic, the exact kernels under fp32)
+    from umnn_amd import _lib
+    kname = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+    assert kname == ("cc_bwd_f16<L=4,LIVE=13,WS>" if bwd_precision == "bf16x3" else "cc_bwd<T=4,NACC=3,EDGE=1,KS=13>"), kname
     rows = np.random.RandomState(2).choice(B, 24, replace=False)
     ref = O.integrate_backward(onet, np.zeros((24, d), np.float32), x.numpy()[rows], h.numpy()[rows], n, g.numpy()[rows])
     assert U.rel_err(dx.cpu().numpy()[rows], ref[1]) < TOL

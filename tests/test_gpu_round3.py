@@ -426,7 +426,7 @@ def test_weight_stationary_backward_agrees_with_the_pipelined_loop_and_fp32(case
     for key, ws, prec in (("swp", 0, "bf16x3"), ("ws", 1, "bf16x3"), ("fp32", 0, "fp32")):
         _lib.set_backward_precision(prec)
         try:
-            with _lib.options(bwd_ws=ws):
+            with _lib.options(bwd_ws=ws, bwd_ws16=0):
                 outs[key] = I.hip_backward(spec, x0, x, h, gg, gf, n, inv_f=inv_f)
                 name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
                 if key == "ws":
@@ -464,7 +464,12 @@ def test_weight_stationary_backward_is_only_taken_for_large_unsplit_batches(dev)
 
 def test_weight_stationary_backward_at_the_benchmarked_size(dev):
     """The configuration ``bench.py --mode train`` times (8192 x 63 integrals per block, n = 100, 50-wide net): every workgroup of
-    the pipeline streams ~126 tiles x 102 elements.  Against the software-pipelined loop on the same inputs, and bit-reproducible."""
+    the pipeline streams ~126 tiles x 102 elements.  Both workgroup pipelines against the software-pipelined loop on the same
+    inputs, bit-reproducible.  The bf16 pipeline (same six-term recompute as the loop) agrees to 5e-6.  The fp16-piece pipeline
+    -- the default at this size -- decides a few dozen of the 3e8 LeakyReLU kinks the other way (its pre-activations carry ~3e-7
+    of relative noise, fp32's ~1e-7): d_theta, a sum over 5e7 node evaluations, moves by < 2e-5 of its largest entry; in the
+    per-row outputs d_h and d_x (g_fx . df/dx goes through the node-0 kinks) such a decision moves ITS row by up to ~1e-3 of the
+    largest entry, so those are held to 1e-5 on all rows but a few dozen of the 8192."""
     import umnn_amd
     from umnn_amd import _lib
     from umnn_amd import integral as I
@@ -476,18 +481,24 @@ def test_weight_stationary_backward_at_the_benchmarked_size(dev):
     x, h = torch.randn(B, d, device=dev), torch.randn(B, E * d, device=dev)
     gg, gf = torch.randn(B, d, device=dev), torch.randn(B, d, device=dev)
     outs = {}
-    for ws in (0, 1):
-        with _lib.options(bwd_ws=ws):
-            outs[ws] = I.hip_backward(spec, None, x, h, gg, gf, n)
+    for key, ws, ws16, want in (("swp", 0, 0, "SWP>"), ("ws", 1, 0, "cc_bwd_bf16<L=4,LIVE=13,WS>"), ("ws16", 1, 1, "cc_bwd_f16<L=4,LIVE=13,WS>")):
+        with _lib.options(bwd_ws=ws, bwd_ws16=ws16):
+            outs[key] = I.hip_backward(spec, None, x, h, gg, gf, n)
             name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
-            assert (",WS>" in name) == bool(ws), name
-    again = I.hip_backward(spec, None, x, h, gg, gf, n)
-    assert all(torch.equal(u, v) for u, v in zip(outs[1][1:], again[1:]))
+            assert want in name, name
+            if key != "swp":
+                again = I.hip_backward(spec, None, x, h, gg, gf, n)
+                assert all(torch.equal(u, v) for u, v in zip(outs[key][1:], again[1:])), key
     for i, nm in ((1, "dx"), (2, "dh"), (3, "dtheta")):
-        a_, b_ = outs[0][i].cpu().numpy(), outs[1][i].cpu().numpy()
-        assert np.isfinite(b_).all(), nm
+        a_, b_, c_ = (outs[k][i].cpu().numpy() for k in ("swp", "ws", "ws16"))
+        assert np.isfinite(b_).all() and np.isfinite(c_).all(), nm
         # (at this size a handful of the 3e8 kink decisions differ between any two summation orders: dh is compared at 2e-5)
         assert U.scaled_err(b_, a_) < (2e-5 if nm == "dh" else 5e-6), (nm, U.scaled_err(b_, a_))
+        if nm == "dtheta":
+            assert U.scaled_err(c_, a_) < 2e-5, U.scaled_err(c_, a_)
+        else:
+            row_err = np.abs(c_ - a_).max(axis=1) / np.abs(a_).max()
+            assert (row_err > 1e-5).sum() <= 64 and row_err.max() < 5e-3, (nm, int((row_err > 1e-5).sum()), float(row_err.max()))
 
 
 @pytest.mark.parametrize("hid, with_gfx", [([100, 50, 50, 50, 50], True), ([112, 48, 60, 36, 50], False)])
@@ -561,7 +572,7 @@ def test_weight_stationary_backward_with_relu_hidden_layers(dev):
     for key, ws, prec in (("swp", 0, "bf16x3"), ("ws", 1, "bf16x3"), ("fp32", 0, "fp32")):
         _lib.set_backward_precision(prec)
         try:
-            with _lib.options(bwd_ws=ws):
+            with _lib.options(bwd_ws=ws, bwd_ws16=0):
                 outs[key] = I.hip_backward(spec, x0, x, h, gg, gf, n)
                 name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
                 assert (",WS>" in name) == (key == "ws"), name

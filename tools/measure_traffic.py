@@ -26,8 +26,8 @@ sys.path.insert(0, ROOT)
 def _pass(counter, workload, extra, outdir):
     cmd = ["timeout", "240", "rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", outdir, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-extras"] + list(extra)
-    env = dict(os.environ, TMPDIR="/tmp")
+           "--no-cpu-baseline", "--no-extras", "--no-telemetry"] + list(extra)
+    env = dict(os.environ, TMPDIR="/tmp", UMNN_BENCH_CHILD="1")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"rocprofv3 --pmc {counter} failed ({r.returncode}): {r.stderr[-400:]}")

@@ -2,6 +2,22 @@
 
 Import surface mirrors models/UMNN/__init__.py:1-6 of the reference.
 """
+import os as _os
+import sys as _sys
+
+# RCCL / device-tensor sharing between the ranks of a node goes through dmabuf IPC on this driver stack; the legacy mode fails with
+# "hipIpcGetMemHandle: invalid argument".  The HSA runtime reads the variable ONCE, when the process first touches the GPU, so the
+# default has to be in the environment before that -- i.e. here, at import (an explicit setting wins).  Importing this package
+# after the GPU is already initialised cannot change the mode any more: say so instead of failing later inside a collective.
+if "HSA_ENABLE_IPC_MODE_LEGACY" not in _os.environ:
+    _torch = _sys.modules.get("torch")
+    if _torch is not None and _torch.cuda.is_available() and _torch.cuda.is_initialized():
+        import warnings as _warnings
+        _warnings.warn("umnn_amd: HSA_ENABLE_IPC_MODE_LEGACY was not set when this process initialised the GPU; multi-process RCCL "
+                       "(torch.distributed backend 'nccl') may fail with 'hipIpcGetMemHandle: invalid argument'.  Export "
+                       "HSA_ENABLE_IPC_MODE_LEGACY=0 or import umnn_amd before the first CUDA call.", RuntimeWarning)
+    _os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+
 from .flow import UMNNMAFFlow, UMNNMAF, EmbeddingNetwork, IntegrandNetwork, ListModule
 from .monotonic import MonotonicNN, IntegrandNN
 from .made import MADE, ConditionnalMADE, MaskedLinear, invalidate_caches, set_made_fast_path, get_made_fast_path, set_made_fused

@@ -66,6 +66,7 @@ __device__ __forceinline__ unsigned h16_split_stage(float& x0, float& x1) {
 __device__ __forceinline__ unsigned h16_split_last(float x0, float x1) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, h16x2));
 }
+
 template <int NRL>
 __device__ __forceinline__ void h16_split_regs(const f32x4 (&act)[BT], BFrag<W16_NP>& bf) {
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
@@ -89,6 +90,12 @@ __device__ __forceinline__ void h16_split_regs(const f32x4 (&act)[BT], BFrag<W16
 // fragment image of W_l (rows = out features, K = in features incl. the constant-one feature / bias column) or of W_l^T
 // (rows = in features, K = out features, nothing through the constant feature) as two fp16 pieces: the index arithmetic of
 // stage_frag_image (cc_bwd_bf16_kernel.h), the pieces of this file
+// LOSCALE (forward images): the low piece is stored as (W - hi) * 2^11.  Weights of these nets are below 2^-3, so the plain
+// remainder would be an fp16 SUBNORMAL -- absolute error 2^-25 instead of 2^-23 |W|, which was the largest single term of the
+// recompute's noise (measured as LeakyReLU kink decisions that differ from the six-term bf16 recompute at the benchmarked
+// size: 624 rows of d_h against 191 for the exact-fp32 kernels); scaled, the low piece has its full 11 bits whatever |W| is.  The
+// products with it accumulate in their own accumulators, added back times 2^-11 (exact) in front of the activation.
+constexpr float W16_LOSCALE = 2048.f, W16_LOUNSCALE = 1.f / 2048.f;
 template <bool TRANSPOSED>
 __device__ __forceinline__ void ws16_stage_image(const MlpDev& m, int l, unsigned short* img, int tid, int nthreads) {
     const int Hin = m.width[l], Hout = m.width[l + 1];
@@ -113,7 +120,7 @@ __device__ __forceinline__ void ws16_stage_image(const MlpDev& m, int l, unsigne
             if (fo < Hout && fi < Hin) v = W[fo * Hin + fi];
         }
         const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)(v - (float)hi);
+        const _Float16 lo = (_Float16)((v - (float)hi) * (TRANSPOSED ? 1.f : W16_LOSCALE));
         img[(ts * W16_NP + 0) * FRAG + ln * 8 + j] = __builtin_bit_cast(unsigned short, hi);
         img[(ts * W16_NP + 1) * FRAG + ln * 8 + j] = __builtin_bit_cast(unsigned short, lo);
     }
@@ -578,11 +585,12 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
     };
     if (nit > 0) new_item_P();
 
-    f32x4 acc[BT];
+    f32x4 acc[BT], acc2[BT];                           // acc2: the products with the scaled low pieces of W_l
     float actF[BT][4];
 #pragma unroll
     for (int t = 0; t < BT; ++t) {
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) actF[t][r] = 0.f;
     }
@@ -636,6 +644,7 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
             constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4, j = e / 2;
             constexpr bool TAN = decltype(tanc)::value;
             if constexpr (e < NLIVE) {
+                acc[t][r] = fmaf(acc2[t][r], W16_LOUNSCALE, acc[t][r]);
                 if constexpr (!IS_OUT) {
                     if constexpr (TAN) {
                         // tangent element: times act'(a_{l+1}) of the element before (node 0), read off its leading piece
@@ -745,7 +754,10 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
                 WS_MARK(nn, 24);
                 constexpr int s2 = nn / 12, term = (nn % 12) / 4, t = nn % 4;
                 constexpr int wa = term == 2 ? 1 : 0, ba = term == 1 ? 1 : 0;
-                acc[t] = mfma_f16(Wf[t][s2][wa], bf.v[s2][ba], nn < 4 ? zero : acc[t]);
+                // (the products with the scaled low weight piece go to acc2.  Scaling the low ACTIVATION piece the same way was
+                // measured too: 467 -> 449 differing rows for +5 % kernel time -- not kept)
+                if constexpr (wa == 0) acc[t] = mfma_f16(Wf[t][s2][0], bf.v[s2][ba], nn < 4 ? zero : acc[t]);
+                else acc2[t] = mfma_f16(Wf[t][s2][1], bf.v[s2][0], s2 == 0 ? zero : acc2[t]);
                 if constexpr (HAS_DW && nn % 4 == 3) ws16_dwh_mfma<nn / 4>(dWh, oh);
                 if constexpr (!IS_OUT) {
                     // the split of a_{l+1}: per K-step the four pairs stage by stage, then its two stores (20 micro-operations)

@@ -17,8 +17,9 @@ def _capture_mode():
 
 def _prime_for_capture(model, x):
     """What must exist BEFORE a capture whatever ``warmup`` is: the library probe of the conditioner's GEMM route (run for the first
-    time inside a capture, hipBLASLt would initialise under capture and abort) and the quadrature tables of every block (their host
-    -> device upload is not capturable).  Warm-up runs create both; ``warmup=0`` in a fresh process does not."""
+    time inside a capture, hipBLASLt would initialise under capture and abort), the quadrature tables of every block (their host
+    -> device upload is not capturable) and ConditionnalMADE's kept-row indices (a pageable host -> device copy).  Warm-up runs
+    create all of them; ``warmup=0`` in a fresh process does not."""
     from . import made, quadrature
     with torch.no_grad():
         made._fast_path_ok(x if x.dtype == torch.float32 else x.float())
@@ -26,6 +27,8 @@ def _prime_for_capture(model, x):
         n = getattr(mod, "nb_steps", None)
         if isinstance(n, int) and n >= 1:
             quadrature.device_tables(n, x.device)
+        if isinstance(mod, made.ConditionnalMADE):
+            mod._kept_rows(x.device)
 
 
 class GraphedLL:
@@ -56,7 +59,12 @@ class GraphedLL:
             side = torch.cuda.Stream(device=self.x.device)
             side.wait_stream(torch.cuda.current_stream(self.x.device))
             with torch.cuda.stream(side):               # warm every cache (LDS caps, tables, packed weights) first
-                for _ in range(self.warmup):
+                # At least ONE eager run, whatever ``warmup`` says: the capture below may bake the conditioner's cached masked /
+                # packed weights in (capture_may_cache), and those caches must have been filled by kernels that really RAN -- a
+                # cache entry first produced inside the capture would hold nothing until the first replay, yet be found under a
+                # matching key by any eager compute_ll (or a second capture) before it (made.MaskedLinear._may_store
+                # now also refuses to store from inside any capture).
+                for _ in range(max(1, self.warmup)):
                     self._run()
             torch.cuda.current_stream(self.x.device).wait_stream(side)
             _prime_for_capture(self.model, self.x)

@@ -70,6 +70,14 @@ class MaskedLinear(nn.Linear):
         # a capture that tracks the weights' versions itself (graphs.GraphedLL re-captures when they move) may bake the caches in
         return t.is_cuda and not getattr(_capture_state, "cache_ok", False) and torch.cuda.is_current_stream_capturing()
 
+    @staticmethod
+    def _may_store(t):
+        """Nothing produced while a stream capture is recording may enter a cache: its kernels have only been recorded, the tensor
+        holds nothing until that graph is replayed, and an eager call (or a second capture) that found it under a matching key
+        would read uninitialised weights.  (A capture that may bake the caches -- graphs.GraphedLL -- fills them with an eager
+        run BEFORE it records; a miss inside the capture is then recomputed inside the graph, which is merely slower.)"""
+        return not (t.is_cuda and torch.cuda.is_current_stream_capturing())
+
     def masked_weight(self):
         if torch.is_grad_enabled() and self.weight.requires_grad:
             return self.mask * self.weight
@@ -79,7 +87,10 @@ class MaskedLinear(nn.Linear):
             return (self.mask * self.weight).detach()
         key = (self.weight._version, self.weight.data_ptr(), self.mask._version, self.mask.data_ptr())
         if self._cache is None or self._cache[0] != key:
-            self._cache = (key, (self.mask * self.weight).detach())
+            w = (self.mask * self.weight).detach()
+            if not self._may_store(self.weight):
+                return w
+            self._cache = (key, w)
         return self._cache[1]
 
     def packed_bf16(self, rows=None):
@@ -99,7 +110,7 @@ class MaskedLinear(nn.Linear):
                 pad = (-(3 * K + 2)) % 8
                 packed = torch.cat([Wh, Wh, Wl, bh[:, None], bl[:, None],
                                     torch.zeros(W.shape[0], pad, dtype=torch.bfloat16, device=W.device)], 1).contiguous()
-            if capturing:
+            if capturing or not self._may_store(self.weight):
                 return packed
             self._packed = (key, packed)
         return self._packed[1]
@@ -117,7 +128,7 @@ class MaskedLinear(nn.Linear):
                 if rows is not None:
                     W, b = W.index_select(0, rows), b.index_select(0, rows)
                 packed = (pack_fragments(W.float()), b.float().contiguous())
-            if capturing:
+            if capturing or not self._may_store(self.weight):
                 return packed
             self._frags = (key, packed)
         return self._frags[1]
@@ -442,6 +453,10 @@ class ConditionnalMADE(MADE):
         if self._keep is None or self._keep.device != device:
             k = self.nout // self.nin
             idx = (torch.arange(k).view(-1, 1) * self.nin + torch.arange(self.cond_in, self.nin).view(1, -1))
+            if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                # (a pageable host -> device copy cannot be recorded: graphs._prime_for_capture builds the indices before it captures)
+                raise RuntimeError("ConditionnalMADE: the kept-row indices must exist before a stream capture starts "
+                                   "(umnn_amd.GraphedLL / GraphedTrainStep prime them; call model(x) once eagerly otherwise)")
             self._keep = idx.reshape(-1).to(device)
         return self._keep
 

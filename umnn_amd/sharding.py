@@ -24,9 +24,8 @@ def init_from_env(backend=None, force_group=False):
     if (world > 1 or force_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        # RCCL / device-tensor sharing between the ranks of a node goes through dmabuf IPC on this driver stack; the legacy
-        # mode fails with "hipIpcGetMemHandle: invalid argument".  Only a default: an explicit setting wins.
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # (HSA_ENABLE_IPC_MODE_LEGACY=0, which RCCL needs on this driver stack, is read when the HSA runtime initialises: it is set
+        # by `import umnn_amd` / at the top of bench.py, BEFORE torch touches the GPU -- here it would be too late)
         backend = backend or os.environ.get("UMNN_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
         dist.init_process_group(backend, rank=rank, world_size=world,
                                 **({"device_id": device} if use_gpu and backend == "nccl" else {}))
