@@ -90,3 +90,27 @@ def kink_margin(net, x0, x, h, nb_steps):
         margin = min(margin, float(np.min(np.abs(z) / np.maximum(mag, 1e-300))))
         a = O._hidden(z, net64.hidden_act)
     return margin
+
+
+def kink_margin_rows(net, x0, x, h, nb_steps):
+    """kink_margin per SAMPLE ROW: [B] -- the smallest |pre-activation| / sum|terms| over every hidden unit, dimension and
+    quadrature node of that row (float64).  The per-row backward outputs (d_h, d_x with a g_fx cotangent) depend on their own
+    row only, so a row whose margin is above the rounding noise of the arithmetic under test must agree with the reference; a
+    row below it may legitimately sit on either side of a LeakyReLU kink -- in the reference's own float32 run as much as here."""
+    x0, x, h = (np.asarray(a, np.float64) for a in (x0, x, h))
+    net64 = O.Net([W.astype(np.float64) for W in net.Ws], [b.astype(np.float64) for b in net.bs], net.hidden_act, net.out_act)
+    w, s = O.cc_tables(nb_steps, np.float64)
+    B, d = x.shape
+    t, _ = O._nodes(x0, x, s, nb_steps)
+    n1 = nb_steps + 1
+    hs = np.broadcast_to(h[:, None, :], (B, n1, h.shape[1])).reshape(B * n1, -1)
+    a = O.rows_from(t.reshape(B * n1, d), hs, d)                 # rows ordered (b, k, i)
+    margin = np.full(B, np.inf)
+    for l in range(len(net64.Ws) - 1):
+        W, b = net64.Ws[l], net64.bs[l]
+        z = a @ W.T + b
+        mag = np.abs(a) @ np.abs(W).T + np.abs(b)
+        m = (np.abs(z) / np.maximum(mag, 1e-300)).reshape(B, -1).min(axis=1)
+        margin = np.minimum(margin, m)
+        a = O._hidden(z, net64.hidden_act)
+    return margin

@@ -51,6 +51,27 @@ def test_backward_matches_reference(name):
         assert U.scaled_err(flat, G[f"dtheta_{tag}"]) < 5e-5
 
 
+def test_backward_matches_reference_at_a_workgroup_pipeline_size():
+    """g8_ws_d63: the reference's custom backward at 280 x 63 integrals x 21 nodes (the smallest size the workgroup-pipeline
+    kernels take).  At 3.7e5 node evaluations two float32 runs of the same algorithm can decide a LeakyReLU kink differently, so the
+    per-row output d_h is held to the tolerance on every row whose smallest pre-activation is above float32 rounding noise
+    (float64 margins, tests/_util.kink_margin_rows) and d_theta to 1e-4; the float64 oracle must sit between the two."""
+    G = U.load("g8_ws_d63")
+    net = U.net_from_g2(G)
+    n = int(G["n"])
+    assert U.rel_err(O.integrate_parallel(net, G["x0"], G["x"], G["h"], n), G["F_par"]) < TOL
+    dx0, dx, dh, _, _, flat = O.integrate_backward(net, G["x0"], G["x"], G["h"], n, G["g"])
+    assert U.rel_err(dx0, G["dx0_par"]) < TOL and U.rel_err(dx, G["dx_par"]) < TOL
+    assert U.scaled_err(flat, G["dtheta_par"]) < 1e-4
+    err = np.abs(dh - G["dh_par"]).max(axis=1) / np.abs(G["dh_par"]).max()
+    bad = np.nonzero(err > 5e-5)[0]
+    assert len(bad) <= 3
+    if len(bad):
+        assert (U.kink_margin_rows(net, G["x0"][bad], G["x"][bad], G["h"][bad], n) < 1e-6).all()
+    margins = U.kink_margin_rows(net, G["x0"], G["x"], G["h"], n)
+    assert margins.shape == (280,) and abs(float(margins.min()) - U.kink_margin(net, G["x0"], G["x"], G["h"], n)) < 1e-12
+
+
 @pytest.mark.parametrize("name", U.g7_names())
 def test_inverse_integrand_operator_matches_reference(name):
     """inv_f=True through ParallelNeuralIntegral.apply and its backward (ParallelNeuralIntegral.py:58-59,70-72,110-123)."""
