@@ -204,6 +204,8 @@ def hbm_traffic(workload, live, extra_args):
         why = "profiles/hbm_traffic.json is for other kernel sources" if rec else "no committed record for this workload"
     if os.environ.get("UMNN_BENCH_CHILD"):          # (a profiling child of this very function)
         return None, "profiling child run"
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:  # (one profiler per node: the in-run collection belongs to the N = 1 line)
+        return None, f"{why}; not collected in a multi-rank run"
     import shutil
     if not shutil.which("rocprofv3"):
         return None, f"{why}; rocprofv3 not on PATH"

@@ -280,14 +280,18 @@ def test_in_kernel_inversion_round_trip(d, hid, E, n, nb_flow, B, dev, precision
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", RuntimeWarning)      # (exact-products modes announce the host-driven search once)
             x_inv = m.invert(z, iter=iters)
-        if precision == "bf16x3":
+        wide = max(hid) > 63
+        if precision == "bf16x3" or not wide:
+            # one launch per dimension and block.  Under "exact products" (bf16x6 / fp32) nets of up to four tiles per layer run the
+            # same in-kernel search with three bf16 pieces / six cross terms (round 4: PARTS=3 variants)
             assert _lib.lib().umnn_launch_count() - before == nb_flow * d
-            assert "cc_invert_bf16" in _lib.lib().umnn_last_kernel_name().decode()
+            name = _lib.lib().umnn_last_kernel_name().decode()
+            assert "cc_invert_bf16" in name and (("PARTS=3" in name) == (precision != "bf16x3")), name
             if hid[0] == 100 and len(hid) == 5:
-                assert "T1=7,TREST=4" in _lib.lib().umnn_last_kernel_name().decode()
+                assert "T1=7,TREST=4" in name
         else:
-            # the search kernels are bf16x3 arithmetic: under "exact products" (bf16x6 / fp32) the bracket search is driven
-            # from the host, one forward launch of that precision per round (umnn_flow_invert_dim returns UMNN_EUNSUPPORTED)
+            # wider nets have no three-piece search kernel (8 tiles x 3 pieces do not fit the register file): the bracket search
+            # is driven from the host, one forward launch of that precision per round (umnn_flow_invert_dim: UMNN_EUNSUPPORTED)
             assert _lib.lib().umnn_launch_count() - before >= nb_flow * d * iters
             assert "invert" not in _lib.lib().umnn_last_kernel_name().decode()
         assert float((x_inv - x).abs().max()) < tol * nb_flow

@@ -322,24 +322,28 @@ def test_fallbacks_off_the_hip_kernels_warn_once_and_report_their_path(dev):
                                torch.randn(8, 12, device=dev))
         assert umnn_amd.path_taken() == "aten"
     assert seen["path"] == "hip"
-    # (ii) inversion under exact-products precision
-    model = umnn_amd.UMNNMAFFlow(nb_flow=1, nb_in=3, hidden_derivative=[50] * 3, hidden_embedding=[32, 32], embedding_s=6,
-                                 nb_steps=30, solver="CCParallel").to(dev).eval()
-    z = torch.randn(64, 3, device=dev)
-    with torch.no_grad():
-        x_fast = model.invert(z, iter=10)
-    old = umnn_amd.get_forward_precision()
-    umnn_amd.set_precision("fp32")
-    try:
-        with warnings.catch_warnings(record=True) as rec:
-            warnings.simplefilter("always")
-            with torch.no_grad():
-                x_exact = model.invert(z, iter=10)
-            assert any("host-driven bracket search" in str(w.message) for w in rec)
-    finally:
-        umnn_amd.set_precision(old)
-    # both searches end within the bracket resolution 100 * (2/9)^10 ~ 3e-5 of the same root unless a candidate tie broke differently
-    assert float((x_fast - x_exact).abs().median()) < 1e-3
+    # (ii) inversion under exact-products precision: a 100-wide net has no three-piece search kernel -> host-driven search, announced;
+    # a 50-wide one does (round 4) -> in-kernel, silent
+    from umnn_amd import _lib
+    for hidw, in_kernel in ((100, False), (50, True)):
+        model = umnn_amd.UMNNMAFFlow(nb_flow=1, nb_in=3, hidden_derivative=[hidw] * 3, hidden_embedding=[32, 32], embedding_s=6,
+                                     nb_steps=30, solver="CCParallel").to(dev).eval()
+        z = torch.randn(64, 3, device=dev)
+        with torch.no_grad():
+            x_fast = model.invert(z, iter=10)
+        old = umnn_amd.get_forward_precision()
+        umnn_amd.set_precision("fp32")
+        try:
+            with warnings.catch_warnings(record=True) as rec:
+                warnings.simplefilter("always")
+                with torch.no_grad():
+                    x_exact = model.invert(z, iter=10)
+                assert any("host-driven bracket search" in str(w.message) for w in rec) == (not in_kernel)
+                assert ("PARTS=3" in _lib.lib().umnn_last_kernel_name().decode()) == in_kernel
+        finally:
+            umnn_amd.set_precision(old)
+        # both searches end within the bracket resolution 100 * (2/9)^10 ~ 3e-5 of the same root unless a candidate tie broke differently
+        assert float((x_fast - x_exact).abs().median()) < 1e-3
 
 
 def test_set_option_rejects_out_of_range_values(dev):

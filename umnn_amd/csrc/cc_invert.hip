@@ -4,13 +4,17 @@
 // dimension and round, a ParallelNeuralIntegral over [10*B, 1] rows (plus a MADE pass per dimension); here one dimension is
 // the MADE pass + ONE launch of an INV variant of cc_fwd_bf16_kernel (cc_fwd_bf16_kernel.h): tile = sample, lane p = candidate
 // p, the hoisted first-layer term computed once per sample, the argmin / new bracket a 16-lane butterfly between rounds.
-// Arithmetic: bf16x3 split products (F to ~6e-6 relative), orders of magnitude inside the search's own resolution
-// (100 * (2/9)^iter).
+// Arithmetic: bf16x3 split products by default (F to ~6e-6 relative), orders of magnitude inside the search's own resolution
+// (100 * (2/9)^iter).  Under fwd_precision = fp32 / bf16x6 ("the reference's arithmetic everywhere") nets of up to four tiles per
+// layer run the same search with THREE bf16 pieces and six cross terms (PARTS=3: fp32-level products, ~4e-7 on F -- the
+// matrix-core arithmetic of the bf16x6 forward mode; there is no fp32-MFMA form of this kernel); wider nets keep the host-driven
+// search on the forward kernels of that mode (8 tiles x 3 pieces do not fit the register file).
 #include "cc_fwd_bf16_kernel.h"
 
 typedef void (*inv_kernel_t)(const FwdBf16Args);
-struct InvVariant { int tmax, exact, nrl; inv_kernel_t fn; const char* name; };
-#define INV_VARIANT(T, EX, NR) { T, EX, NR, cc_fwd_bf16_kernel<T, 2, 1, (EX) != 0, NR, false, true>, "cc_invert_bf16<T=" #T ",EXACT=" #EX ",LIVE=" #NR ">" }
+struct InvVariant { int tmax, exact, nrl, nparts; inv_kernel_t fn; const char* name; };
+#define INV_VARIANT(T, EX, NR) { T, EX, NR, 2, cc_fwd_bf16_kernel<T, 2, 1, (EX) != 0, NR, false, true>, "cc_invert_bf16<T=" #T ",EXACT=" #EX ",LIVE=" #NR ">" }
+#define INV_VARIANT3(T, EX, NR) { T, EX, NR, 3, cc_fwd_bf16_kernel<T, 3, 1, (EX) != 0, NR, false, true>, "cc_invert_bf16<T=" #T ",PARTS=3,EXACT=" #EX ",LIVE=" #NR ">" }
 // wide first hidden layer over a narrow rest (MNISTExperiment's integrand: sampling d = 784 images is 3 920 of these launches)
 struct InvWideFirst { int t1, nrl; inv_kernel_t fn; const char* name; };
 #define INV_WIDE_FIRST(T, NR) { T, NR, cc_fwd_bf16_kernel<T, 2, 1, true, NR, false, true, 4>, "cc_invert_bf16<T1=" #T ",TREST=4,LIVE=" #NR ">" }
@@ -21,6 +25,8 @@ static const InvVariant kInvVariants[] = {
     INV_VARIANT(7, 1, 26), INV_VARIANT(7, 1, 0),       // 100-wide toy nets
     INV_VARIANT(5, 1, 0), INV_VARIANT(6, 1, 0), INV_VARIANT(8, 1, 0),
     INV_VARIANT(2, 0, 0), INV_VARIANT(4, 0, 0), INV_VARIANT(8, 0, 0),   // generic (runtime tile counts): mixed widths, e.g. 100-50-50-50-50
+    // three pieces / six cross terms (fwd_precision = fp32 | bf16x6): nets of up to four tiles per layer
+    INV_VARIANT3(4, 1, 13), INV_VARIANT3(4, 1, 0), INV_VARIANT3(2, 0, 0), INV_VARIANT3(4, 0, 0),
 };
 
 extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const float* z, const float* scaling,
@@ -37,10 +43,11 @@ extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const f
     if (!h || !z || !scaling || !cc_w || !cc_s || !x_inv) return umnn_fail(UMNN_EINVAL, "invert: null pointer");
     const int L = a.m.n_linear - 1;
     if (L < 2) return umnn_fail(UMNN_EUNSUPPORTED, "invert: the matrix-core kernels need at least two hidden layers");
-    // the search kernels exist in bf16x3 arithmetic only: under fwd_precision = fp32 / bf16x6 ("exact products everywhere") the
-    // caller keeps its host-driven search on the forward kernels of that mode instead of silently sampling with ~6e-6 integrals
-    if (umnn_options().fwd_precision != UMNN_PRECISION_BF16X3)
-        return umnn_fail(UMNN_EUNSUPPORTED, "invert: the in-kernel search is bf16x3 arithmetic; the forward precision asks for exact products");
+    // fwd_precision = fp32 / bf16x6 ("exact products everywhere"): the three-piece variants, which exist for up to four tiles per
+    // layer; wider nets keep the caller's host-driven search on the forward kernels of that mode -- never a silent ~6e-6 search
+    const int nparts = umnn_options().fwd_precision == UMNN_PRECISION_BF16X3 ? 2 : 3;
+    if (nparts == 3 && tmax > 4)
+        return umnn_fail(UMNN_EUNSUPPORTED, "invert: the fp32-level in-kernel search exists for nets of at most four tiles per layer; the forward precision asks for exact products");
     a.x0 = nullptr; a.x = nullptr; a.h = h; a.ccw = cc_w; a.ccs = cc_s;
     a.F = a.fx = a.fx0 = nullptr; a.scaling = scaling; a.z = nullptr; a.logjac = nullptr; a.logjac_in = nullptr;
     a.reverse_z = 0; a.ll = nullptr; a.row_cnt = nullptr; a.ll_first = a.ll_last = 0;
@@ -95,7 +102,7 @@ extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const f
     }
     for (int l = 1; l < L; ++l) {
         args.pl.off16[l] = off16;
-        off16 += a.m.t_out[l + 1] * (args.pl.ks32[l] * 2 * 512 + args.pl.half_in[l] * 2 * 256);
+        off16 += a.m.t_out[l + 1] * (args.pl.ks32[l] * nparts * 512 + args.pl.half_in[l] * nparts * 256);
     }
     int exact = 1, nrl = a.m.ks_in[1];
     for (int l = 1; l <= L; ++l) {
@@ -106,7 +113,7 @@ extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const f
         T = 4; exact = 1; nrl = 0;
         for (int l = 1; l <= L; ++l) { a.m.t_out[l] = 4; args.pl.ks32[l] = 2; }
         off16 = 0;
-        for (int l = 1; l < L; ++l) { args.pl.off16[l] = off16; off16 += 4 * 2 * 2 * 512; }
+        for (int l = 1; l < L; ++l) { args.pl.off16[l] = off16; off16 += 4 * 2 * nparts * 512; }
     }
     a.m.lds_off[L] = (((off16 + 1) / 2) + 3) & ~3;
     const size_t lds_bytes = (size_t)a.m.lds_off[L] * sizeof(float);
@@ -117,7 +124,7 @@ extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const f
     for (int ex = exact; ex >= 0 && !pick; --ex)
         for (int pass = 0; pass < 2 && !pick; ++pass)
             for (const InvVariant& v : kInvVariants)
-                if (v.tmax == (ex ? T : (tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8)) && v.exact == ex &&
+                if (v.tmax == (ex ? T : (tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8)) && v.exact == ex && v.nparts == nparts &&
                     (pass == 0 ? (ex && nrl && v.nrl == nrl) : v.nrl == 0)) { pick = &v; break; }
     if (!pick) return umnn_fail(UMNN_EUNSUPPORTED, "invert: no kernel variant for this shape");
     if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;

@@ -152,7 +152,10 @@ def _hip_backward_ok(spec, x, h):
     kind = _bwd_kind.get(key)
     if kind is None:
         desc, keep = _desc(spec)
-        kind = _bwd_kind[key] = _lib.lib().umnn_cc_backward_kind(ctypes.byref(desc), E)
+        kind = _lib.lib().umnn_cc_backward_kind(ctypes.byref(desc), E)
+        if kind < -1:       # an error code (invalid descriptor, umnn_prepare_mlp failure): surfaced, never rerouted as "a wide net"
+            _lib.check(kind, "umnn_cc_backward_kind")
+        _bwd_kind[key] = kind
     if kind < 0:
         _warn_once(("bwd-aten", key[0]),
                    f"umnn_amd: the HIP backward has no shape-exact kernel for integrand widths {[w for _, w in key[0]]} "
