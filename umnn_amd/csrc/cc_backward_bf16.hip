@@ -138,7 +138,7 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
                 hipStreamSynchronize(stream);
                 static double host[6 * 8192];
                 hipMemcpy(host, tbuf, sizeof(double) * 6 * nw, hipMemcpyDeviceToHost);
-                const char* role[8] = {"Ca", "F1", "F2", "F3", UMNN_WS_PAIRING ? "B3" : "Cb", "B1", "B2", UMNN_WS_PAIRING ? "Cb" : "B3"};
+                const char* role[8] = {"Ca", "F1", "F2", "F3", "Cb", "B1", "B2", "B3"};
                 for (int r = 0; r < WS_WAVES; ++r) {
                     double sm[6] = {0};
                     for (int w = r; w < nw; w += WS_WAVES) for (int j = 0; j < 6; ++j) sm[j] += host[6 * w + j];
@@ -166,28 +166,9 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
             *nwaves_out = nblocks * UMNN_WAVES_PER_BLOCK;
             a.l_lo = 1;
             if (int rc = umnn_allow_lds((const void*)sv->fn, lds_swp)) return rc;
-#ifdef UMNN_SWP_TIMING
-            static double* tbuf = nullptr;
-            const int nw = nblocks * UMNN_WAVES_PER_BLOCK;
-            if (!tbuf) hipMalloc(&tbuf, sizeof(double) * 10 * 4096);
-            hipMemsetAsync(tbuf, 0, sizeof(double) * 10 * nw, stream);
-            args.tz2 = reinterpret_cast<const float*>(tbuf);
-#endif
             umnn_prof_begin(stream);
             hipLaunchKernelGGL(sv->fn, dim3(nblocks), dim3(UMNN_BLOCK), lds_swp, stream, args);
             umnn_prof_end(stream, 3.0 * umnn_cc_forward_flops_per_integral(net, a.n) * (double)a.NI, UMNN_PROF_BACKWARD);
-#ifdef UMNN_SWP_TIMING
-            {
-                hipStreamSynchronize(stream);
-                static double host[10 * 4096];
-                hipMemcpy(host, tbuf, sizeof(double) * 10 * nw, hipMemcpyDeviceToHost);
-                double s[10] = {0};
-                for (int w = 0; w < nw; ++w) for (int j = 0; j < 10; ++j) s[j] += host[10 * w + j];
-                const double nn = s[8] > 0 ? s[8] : 1;
-                fprintf(stderr, "SWP_TIMING cycles per node (s_memtime ticks): G %.0f %.0f %.0f | D %.0f %.0f %.0f | loop %.0f | kernel per wave %.0f | nodes per wave %.0f\n",
-                        s[0] / nn, s[1] / nn, s[2] / nn, s[3] / nn, s[4] / nn, s[5] / nn, s[6] / nn, s[7] / nw, s[8] / nw);
-            }
-#endif
             umnn_note_launch(sv->name);
             return umnn_check(hipGetLastError(), "cc_bwd_bf16 (swp) launch");
         }

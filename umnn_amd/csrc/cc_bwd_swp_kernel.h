@@ -40,10 +40,10 @@
 //     The constant-one feature (bias column / unit row of the forward image) forms a closed subspace under W^T -- it only
 //     ever feeds the constant feature's own delta, whose dW rows and dc entries are discarded at write-out.
 // Measured at C3 (8192 x 63, n = 100; profiles/r03): 14.8-15.1 ms (round-2 loop) -> 13.5-13.9 ms; wave cycles per tile-node
-// 10.6 k -> 9.6 k, parked on s_waitcnt 14 % -> 10 %, matrix pipe 55 % -> 60 % busy.  DESIGN 4.2 has the other variants that
-// were measured (slots only in the dW regions: 16.2 ms; the two chains in antiphase: 15.1-15.5 ms) and where this one waits
-// (-DUMNN_SWP_TIMING: s_memtime per region -- the dW regions run at pipe speed, the GEMM regions at 1.2-1.9x their matrix time;
-// -DUMNN_SWP_STAGGER: the four waves of a workgroup started apart -- no effect).
+// 10.6 k -> 9.6 k, parked on s_waitcnt 14 % -> 10 %, matrix pipe 55 % -> 60 % busy.  EXPERIMENTS.md has the other variants that
+// were measured (slots only in the dW regions: 16.2 ms; the two chains in antiphase: 15.1-15.5 ms) and where this one waits (the dW
+// regions run at pipe speed, the GEMM regions at 1.2-1.9x their matrix time; starting the four waves apart: no effect) -- the
+// timing / experiment switches of those measurements were removed from this file in round 4.
 #pragma once
 #include <type_traits>
 #include <utility>
@@ -205,17 +205,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
     const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + wid;
     const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
     const unsigned nsp = a.ns > 1 ? (unsigned)a.ns : 1u;
-#ifdef UMNN_SWP_TIMING
-    // per-wave cycle sums of the regions of the node loop (s_memtime; a debug build: tools/bwd_region_timing.sh)
-    unsigned long long tG[3] = {0, 0, 0}, tD[3] = {0, 0, 0}, tLoop = 0, tAll0 = __builtin_amdgcn_s_memtime(), nNodes = 0;
-#endif
 
-#ifdef UMNN_SWP_STAGGER
-    // The four waves of a workgroup leave the staging barrier in lockstep and, running the same instruction stream, stay there:
-    // all four then pull weight fragments out of LDS in their GEMM regions at the same time and none does in the dW regions.
-    // Start wave w a fraction of a node period late (s_sleep counts 64-cycle units) so that the regions interleave.
-    for (int i = 0; i < wid * UMNN_SWP_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
-#endif
     for (unsigned item = wave_global; item < a.ngroups * nsp; item += nwaves) {
         const unsigned grp = item / nsp, part = item - grp * nsp;
         const int k_lo = (int)(((long long)part * (n + 1)) / nsp), k_hi = (int)(((long long)(part + 1) * (n + 1)) / nsp);
@@ -440,24 +430,11 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
         auto loadW = [&](auto layerc, auto kc, auto tc) __attribute__((always_inline)) {        // W set k = 3 s + piece, tile t
             constexpr int li = decltype(layerc)::value, kk = decltype(kc)::value, t = decltype(tc)::value;
             constexpr int s = kk / 3, piece = kk % 3;
-#ifdef UMNN_SWP_EXP_NOFRAG
-            return;
-#endif
-#ifdef UMNN_SWP_EXP_NOP2                 // timing experiment only (wrong results): no LDS read for the third piece
-            if constexpr (piece == 2) { bufW[kk & 1][t] = bufW[(kk + 1) & 1][t]; return; }
-#endif
             bufW[kk & 1][t] = *reinterpret_cast<const u32x4*>(fragF + (li - 1) * IMG + ((t * BKS + s) * NPF + piece) * FRAG);
         };
         auto loadT = [&](auto layerc, auto kc, auto tc) __attribute__((always_inline)) {        // W^T set k = 2 s + piece, tile t
             constexpr int li = decltype(layerc)::value, kk = decltype(kc)::value, t = decltype(tc)::value;
             constexpr int s = kk / 2, piece = kk % 2;
-#ifdef UMNN_SWP_EXP_NOFRAG
-            return;
-#endif
-#ifdef UMNN_SWP_EXP_TB128                // timing experiment only (wrong results): W^T fragments as one conflict-free b128 read
-            bufT[t] = *reinterpret_cast<const u32x4*>(fragF + (li - 1) * IMG + ((t * BKS + s) * NPF + piece) * FRAG);
-            return;
-#endif
             const unsigned short* lo = fragT + (li - 1) * IMG + (((2 * s + 0) * BKS + (t >> 1)) * NPF + piece) * FRAG + 4 * (t & 1);
             const unsigned short* hi = fragT + (li - 1) * IMG + (((2 * s + 1) * BKS + (t >> 1)) * NPF + piece) * FRAG + 4 * (t & 1);
             const u32x2 x0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4v __attribute__((address_space(3)))*)(lo)));
@@ -484,9 +461,6 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
         }
 
         // ---------------- pipelined node loop: B(k) with F(k+1) ----------------
-#ifdef UMNN_SWP_TIMING
-        const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
-#endif
         for (int k = k_lo; k < k_hi; ++k) {
             const bool has_next = k + 1 < k_hi;
             const int kn = has_next ? k + 1 : k;
@@ -507,9 +481,6 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
                 // buffers loaded 8..20 slots ahead of their first use (W sets k = 3s + piece -> bufW[k & 1], W^T sets
                 // k = 2s + piece -> bufT[k & 1]; W set 0 was loaded in the previous region D).  The vector work of K-step 1's
                 // split (pairs 4..7; K-step 1's MFMAs start at slot 36) rides behind the first slots.
-#ifdef UMNN_SWP_TIMING
-                const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
-#endif
                 swp_static_for<72>([&](auto nc) {
                     constexpr int nn = decltype(nc)::value, s = nn / 36, idx = nn % 36;
                     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -541,9 +512,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
                     if constexpr (nn >= 48 && nn < 52) loadW(ic, std::integral_constant<int, 5>{}, std::integral_constant<int, nn - 48>{});   // used 68..71
                     if constexpr (nn >= 56 && nn < 60) loadT(lc, std::integral_constant<int, 3>{}, std::integral_constant<int, nn - 56>{});   // used 64..67
                     // K-step 1 of this stage's operands: pairs 4..7, then delta's K-step 1 to LDS
-#ifndef UMNN_SWP_EXP_NOGVALU            // (timing experiments only: wrong results)
                     if constexpr (nn < 16) pair_op(std::integral_constant<int, 4 + nn / 4>{}, std::integral_constant<int, nn % 4>{});
-#endif
                     if constexpr (nn == 16) commit(curc, std::integral_constant<int, 1>{});
                     // operands of region D: a_l^T and its sign piece out of X, THEN a_i(k+1) into X; delta^T out of the delta slot
                     if constexpr (nn >= 60 && nn < 64) read_aT(std::integral_constant<int, nn - 60>{}, X);
@@ -562,10 +531,6 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
                 });
                 // ---- region D: dW_l += delta_{l+1} (x) a_l, one MFMA per slot; behind them S7 of this stage and K-step 0 of the
                 // NEXT stage's operands (at the last stage: the tail of node k, the output layer of node k+1, layer 1 of k+2 first)
-#ifdef UMNN_SWP_TIMING
-                const unsigned long long td0 = __builtin_amdgcn_s_memtime();
-                tG[i - 1] += td0 - tg0;
-#endif
                 swp_static_for<NDW>([&](auto nc) {
                     constexpr int nn = decltype(nc)::value;
                     // (output-row tile outermost: delta^T tile `to` is dead after its 12 slots; per accumulator the order of
@@ -596,21 +561,12 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
                     if constexpr (nn >= 40 && nn < 44) loadW(std::integral_constant<int, inext>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 40>{});
                     __builtin_amdgcn_sched_barrier(0);
                 });
-#ifdef UMNN_SWP_TIMING
-                tD[i - 1] += __builtin_amdgcn_s_memtime() - td0;
-#endif
             });
             tkB = tkF;
             tkF = tkN;
-#ifdef UMNN_SWP_TIMING
-            nNodes += 1;
-#endif
             // slot rotation: stage i stored a_i(k+1) where a_{L-i}(k) was
             if constexpr (NG >= 2) { const int tmp = so[0]; so[0] = so[NG - 1]; so[NG - 1] = tmp; }
         }
-#ifdef UMNN_SWP_TIMING
-        tLoop += __builtin_amdgcn_s_memtime() - tl0;
-#endif
 
         if (ok) {
 #pragma unroll
@@ -628,13 +584,6 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_swp_kernel(const BwdBf16
     }
 
     // ---------------- write this wave's partial d_theta (rows / columns of the dW tiles run over register slots) ----------------
-#ifdef UMNN_SWP_TIMING
-    if (args.tz2 && lane == 0) {                       // (debug build: tz2 carries the timing buffer, 10 doubles per wave)
-        double* o = reinterpret_cast<double*>(const_cast<float*>(args.tz2)) + (size_t)wave_global * 10;
-        for (int j = 0; j < 3; ++j) { o[j] = (double)tG[j]; o[3 + j] = (double)tD[j]; }
-        o[6] = (double)tLoop; o[7] = (double)(__builtin_amdgcn_s_memtime() - tAll0); o[8] = (double)nNodes; o[9] = 0.0;
-    }
-#endif
     float* part = a.partials + (size_t)wave_global * a.n_params;
 #pragma unroll
     for (int j = 0; j < NG; ++j) {

@@ -37,9 +37,11 @@
 // Measured at C3 (8192 x 63, n = 100): 12.9-13.1 ms per launch against 13.4-13.6 for the software-pipelined loop.  Per tile-node
 // 1135 vector + matrix + LDS instructions (there 1396) and 20 % fewer matrix cycles; what that saves is mostly lost to
 // synchronisation: a role wave waits at the step barrier for 28 % of a step on average, and the four long roles (F1, F2, F3, Cb:
-// one per SIMD) sit on the pair's 1152 matrix-pipe cycles plus their un-overlapped vector phases.  The scalar bookkeeping
-// (277 instructions per tile-node) is nearly free (-DUMNN_WS_EXP_NORINGS: 0.9 %).  -DUMNN_WS_TIMING times every role per step;
-// DESIGN 4.2 has the numbers and the variants that were measured.
+// one per SIMD) sit on the pair's 1152 matrix-pipe cycles plus their un-overlapped vector phases.  -DUMNN_WS_TIMING (an
+// instrumentation build: results unchanged, s_memtime per role and step) times every role; EXPERIMENTS.md has the numbers and the
+// twenty-odd variants that were measured -- their switches no longer live in this file.  Since round 4 this kernel is the
+// FALLBACK of the fp16-piece pipeline (cc_bwd_ws16_kernel.h: same pipeline, three-term recompute), the kernel of 1/f launches,
+// sigmoid outputs and mid-size batches, and the middle stage of the three-stage backward (FRONT).
 #pragma once
 #include "cc_bwd_swp_kernel.h"
 
@@ -80,20 +82,12 @@ __device__ __forceinline__ WsCursor ws_next(const WsShape& sh, WsCursor c) {
 // ring of LDS tiles: ushort offset of the current tile, advanced once per step (no division in the step loop)
 template <int NS, int STRIDE>
 __device__ __forceinline__ void ws_adv(int& off) {
-#ifdef UMNN_WS_EXP_NORINGS                 // (timing experiment only: every ring stays on its first tile, results wrong)
-    return;
-#endif
     if constexpr (NS == 2) off ^= STRIDE;               // (two-tile rings: one scalar instruction)
     else { off += STRIDE; if (off == NS * STRIDE) off = 0; }
 }
 template <int NS, int STRIDE>
 __host__ __device__ constexpr int ws_ring0(int delay) { return ((WS_BIAS - delay) % NS) * STRIDE; }
 
-#ifdef UMNN_WS_VGPR_ACC
-#define WS_VGPR_HINT(x) asm volatile("" : "+v"(x))
-#else
-#define WS_VGPR_HINT(x) (void)0
-#endif
 // companion work spread over a matrix loop: micro-operation i rides behind slot (3 i) / 2 (two of every three slots carry one)
 __host__ __device__ constexpr int ws_op_of_slot(int nn) { return ((((2 * nn + 2) / 3) * 3) / 2 == nn) ? (2 * nn + 2) / 3 : -1; }
 typedef float ws_f32x16 __attribute__((ext_vector_type(16)));
@@ -104,35 +98,7 @@ __device__ __forceinline__ u32x2 ws_tr_read(const unsigned short* src) {
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4v __attribute__((address_space(3)))*)(src)));
 }
 
-#ifndef UMNN_WS_PAIRING
-#define UMNN_WS_PAIRING 0
-#endif
-#ifdef UMNN_WS_EXP_NOBARRIER                 // timing only (results wrong): the role waves free-running
-#define WS_STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
-#else
 #define WS_STEP_SYNC() __syncthreads()
-#endif
-#ifndef UMNN_WS_SLEEP_CA                     // s_sleep units (64 cycles) wave Ca waits after the step barrier (experiment: 0)
-#define UMNN_WS_SLEEP_CA 0
-#endif
-#ifndef UMNN_WS_ITEM_PREFETCH                // 1: the next tile's x, x0 and first 32 embedding columns are requested at the top of the step that
-#define UMNN_WS_ITEM_PREFETCH 0              //    ends the current tile (ten more live registers in wave Ca: spills 48-74, 13.1 vs 12.6 ms -- off)
-#endif
-#ifndef UMNN_WS_PREFETCH_B
-#define UMNN_WS_PREFETCH_B 1         // the a_l operands of the dW products (written steps ago) are fetched BEFORE the step barrier
-#endif
-#ifndef UMNN_WS_SPREAD
-#define UMNN_WS_SPREAD 1             // companion vector work spread evenly over the matrix loops (0: front-loaded, the first schedule)
-#endif
-#ifndef UMNN_WS_DW1_IN_B1
-#define UMNN_WS_DW1_IN_B1 0         // dW_1 accumulated by wave B1 (1) or Cb (0): balances the instruction count of the SIMDs
-#endif
-#ifndef UMNN_WS_C_SPLIT
-#define UMNN_WS_C_SPLIT 0            // 1: Ca = all the vector work of the C roles (layer 1, delta_4), Cb = all three dW products (needs UMNN_WS_D4_IN_CA = 1)
-#endif
-#ifndef UMNN_WS_D4_IN_CA
-#define UMNN_WS_D4_IN_CA 0          // delta_4 = dout w_out act'(a_4) formed by wave Ca (1) or Cb (0)
-#endif
 #ifdef UMNN_WS_TIMING
 // per-role cycle sums (s_memtime): prep = operand fetches issued and waited for, work = the role's step (cut in two at slot
 // UMNN_WS_TRACE_FRAC percent of its matrix loop when that is defined: one more sample per step, a different build per cut), wait =
@@ -276,38 +242,18 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
             }
     };
     // Opening a tile: x, x0 and the tile's 16 x E embedding values from HBM, c = b_1 + W_1[:, 1:] h on the fp32 matrix pipe.  The
-    // whole workgroup waits at the step barrier while this wave does that (a timing build that never re-opens, -DUMNN_WS_EXP_NONEWITEM,
-    // is 0.6 ms faster at C3), so everything loaded at the opening is issued in ONE batch of eight K-steps before the first product:
-    // one memory latency instead of eight, 12.86 -> 12.63 ms per launch, bit-identical.  Requesting the HBM part a step ahead
-    // (UMNN_WS_ITEM_PREFETCH) costs ten registers this wave does not have.
-    constexpr int NI_CH = 8, NI_A = UMNN_WS_ITEM_PREFETCH ? 4 : 8;   // K-steps of h fetched ahead / per trip; K-steps of W_1 per trip
-    float hv_n[NI_CH], xv_n = 0.f, x0v_n = 0.f;
-#pragma unroll
-    for (int q = 0; q < NI_CH; ++q) hv_n[q] = 0.f;
-    auto item_prefetch = [&](const WsCursor& c2) __attribute__((always_inline)) {
-        if constexpr (FRONT || !UMNN_WS_ITEM_PREFETCH) return;
-        const long long q0 = (long long)(args.grp0 + ws_grp(c2)) * 16 + p;
-        const long long qq = q0 < a.NI ? q0 : a.NI - 1;
-        xv_n = io_ld(a.x, qq, a.x_bf16);
-        x0v_n = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
-        const long long bi = qq / d;
-        const IoView hb = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
-#pragma unroll
-        for (int q = 0; q < NI_CH; ++q) {
-            const int e = 4 * q + g;
-            hv_n[q] = e < E ? hb[(long long)e * d] : 0.f;
-        }
-    };
-    auto new_item = [&]() __attribute__((always_inline)) {          // (item_prefetch of the same tile went before)
+    // whole workgroup waits at the step barrier while this wave does that, so everything loaded at the opening is issued in ONE
+    // batch of eight K-steps before the first product (item_embedding_gemm): one memory latency instead of eight, 12.86 -> 12.63 ms
+    // per launch.  (Requesting the HBM part a step ahead costs ten registers this wave does not have: EXPERIMENTS.md.)
+    auto new_item = [&]() __attribute__((always_inline)) {
         if constexpr (FRONT) return;
         const long long q0 = (long long)(args.grp0 + ws_grp(cu)) * 16 + p;
         const long long qq = q0 < a.NI ? q0 : a.NI - 1;
-        if constexpr (UMNN_WS_ITEM_PREFETCH) { xv = xv_n; x0v = x0v_n; }
-        else { xv = io_ld(a.x, qq, a.x_bf16); x0v = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f; }
+        xv = io_ld(a.x, qq, a.x_bf16);
+        x0v = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
         dxv = xv - x0v;
         const long long bi = qq / d;
         const IoView hb = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
-        const float* __restrict__ W0 = m.W[0];
         const float* __restrict__ b0 = m.b[0];
 #pragma unroll
         for (int t = 0; t < BT; ++t)
@@ -316,31 +262,9 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
                 const int f = feat_of(t, r, g);
                 c[t][r] = f < H1 ? b0[f] : (f == H1 ? 1.f : 0.f);
             }
-        for (int se0 = 0; se0 < (E + 3) / 4; se0 += NI_A) {
-            float hv[NI_A], A[NI_A][BT];
-#pragma unroll
-            for (int q = 0; q < NI_A; ++q) {
-                const int e = 4 * (se0 + q) + g;
-                hv[q] = (e < E && (!UMNN_WS_ITEM_PREFETCH || se0 + q >= NI_CH)) ? hb[(long long)e * d] : 0.f;
-#pragma unroll
-                for (int t = 0; t < BT; ++t) {
-                    const int fo = fout_of(t, p);
-                    A[q][t] = (fo < H1 && e < E) ? W0[fo * (1 + E) + 1 + e] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NI_A; ++q) {
-                float hq = hv[q];
-                if constexpr (UMNN_WS_ITEM_PREFETCH) {
-#pragma unroll
-                    for (int q2 = 0; q2 < NI_CH; ++q2) hq = (se0 + q == q2) ? hv_n[q2] : hq;     // (the prefetched K-steps)
-                }
-#pragma unroll
-                for (int t = 0; t < BT; ++t) c[t] = mfma16(A[q][t], hq, c[t]);
-            }
-        }
+        item_embedding_gemm<BT, 8>(hb, m.W[0], H1, E, d, g, p, c);
     };
-    if (nit > 0) { item_prefetch(cu); new_item(); }
+    if (nit > 0) new_item();
     if constexpr (FRONT) { if (nit > 0) fetch_z(cu, zc); }
 
     float actF[BT][4];
@@ -371,19 +295,16 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         tk = (k == 0) ? xv : __fadd_rn(x0v, __fmul_rn(dxv, uu) * 0.5f);
     }
     WsOps ops;
-#if !UMNN_WS_C_SPLIT && UMNN_WS_PREFETCH_B
     {
         const unsigned short* A3n = lds16 + WS_OFF_A3 + rA3 + trb;
         ws_load_op<4>(ops, A3n, A3n); ws_load_op<6>(ops, A3n, A3n); ws_load_op<5>(ops, A3n, A3n); ws_load_op<7>(ops, A3n, A3n);
     }
-#endif
     for (int s = 0; s < S; ++s) {
         WS_T(t0);
         const WsCursor nx = live ? ws_next(sh, cu) : cu;
         const int kn = ws_node(sh, nx);
         float ccs_n = 0.f;
         if constexpr (!FRONT) ccs_n = a.ccs[kn];
-        if (live && nx.j != cu.j && nx.j < nit) item_prefetch(nx);       // this step ends the tile: the next one's HBM loads now
         if constexpr (FRONT) {
             if (live && cu.e == 0) {
 #pragma unroll
@@ -397,24 +318,8 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         const unsigned short* D4 = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + trb;
         unsigned short* const O1 = lds16 + WS_OFF_A1 + rO1 + own;
         unsigned short* const O1p3 = lds16 + WS_OFF_P3 + rO3 + own;
-#if UMNN_WS_D4_IN_CA
-        // what F3 left a step ago for element s - 7: the leading piece of a_4 (its sign) and dout
-        const unsigned short* S4 = lds16 + WS_OFF_S4 + rS4;
-        u32x4 sg4[BKS];
-#pragma unroll
-        for (int s2 = 0; s2 < BKS; ++s2) sg4[s2] = *reinterpret_cast<const u32x4*>(S4 + own + s2 * 8);
-        const float dout4 = *reinterpret_cast<const float*>(S4 + p * TRS + 64);
-#endif
-#if !UMNN_WS_C_SPLIT && UMNN_WS_PREFETCH_B
         // operands of dW_3: the a_3 half came in before the barrier, the delta_4 half (written last step) here
         ws_load_op<0>(ops, D4, A3); ws_load_op<2>(ops, D4, A3); ws_load_op<1>(ops, D4, A3); ws_load_op<3>(ops, D4, A3);
-#elif !UMNN_WS_C_SPLIT
-        // operands of dW_3 (A hi, B hi, B lo, A lo); then the layer-1 activations (registers only) while those fetches fly
-        ws_load_op<0>(ops, D4, A3); ws_load_op<2>(ops, D4, A3); ws_load_op<4>(ops, D4, A3); ws_load_op<6>(ops, D4, A3);
-        ws_load_op<5>(ops, D4, A3); ws_load_op<7>(ops, D4, A3); ws_load_op<1>(ops, D4, A3); ws_load_op<3>(ops, D4, A3);
-#else
-        (void)ops; (void)D4; (void)A3;
-#endif
         // layer 1 of element s (tangent element: w1 . act'(z_1) of node 0)
         auto layer1_reg = [&](auto ec, auto tanc) __attribute__((always_inline)) {
             constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
@@ -446,53 +351,27 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         };
         WS_T(t1);
         // (only these sixteen registers differ for a tangent element: the branch stays outside the matrix loop)
-#ifndef UMNN_WS_EXP_NOVALU_CA              // (timing experiment only: layer 1 and its split skipped, results wrong)
         if (is_tan) swp_static_for<16>([&](auto ec) { layer1_reg(ec, std::true_type{}); });
         else swp_static_for<16>([&](auto ec) { layer1_reg(ec, std::false_type{}); });
-#endif
         __builtin_amdgcn_sched_barrier(0);
         swp_static_for<12>([&](auto nc) {
             constexpr int nn = decltype(nc)::value;
             WS_MARK(nn, 12);
-#if !UMNN_WS_C_SPLIT
             ws_dw_mfma<nn>(dW, ops);
-#endif
             // the split of a_1: two pairs per slot, stage by stage; then the stores
-#ifndef UMNN_WS_EXP_NOVALU_CA
             if constexpr (nn < 4) { pairF(std::integral_constant<int, 2 * nn>{}, std::integral_constant<int, 0>{}); pairF(std::integral_constant<int, 2 * nn + 1>{}, std::integral_constant<int, 0>{}); }
             if constexpr (nn >= 1 && nn < 5) { pairF(std::integral_constant<int, 2 * (nn - 1)>{}, std::integral_constant<int, 1>{}); pairF(std::integral_constant<int, 2 * (nn - 1) + 1>{}, std::integral_constant<int, 1>{}); }
             if constexpr (nn >= 2 && nn < 6) { pairF(std::integral_constant<int, 2 * (nn - 2)>{}, std::integral_constant<int, 2>{}); pairF(std::integral_constant<int, 2 * (nn - 2) + 1>{}, std::integral_constant<int, 2>{}); }
-#endif
             if constexpr (nn >= 5 && nn < 8) store_a(std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 5>{});
             if constexpr (nn >= 8 && nn < 11) store_a(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 8>{});
             __builtin_amdgcn_sched_barrier(0);
         });
-#if UMNN_WS_D4_IN_CA
-        // delta_4 of element s - 7: delta_L = dout w_out act'(a_L), split, stored for B3 and for this wave's dW_3 of the next step
-        {
-            f32x4 d4[BT];
-#pragma unroll
-            for (int t = 0; t < BT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    d4[t][r] = 4 * t + r < NLIVE ? (dout4 * wout[t][r]) * act_grad_q(sg4, t, r, slope) : 0.f;
-            BFrag<NPB> q;
-            split_regs<NRL, NPB>(d4, q);
-            unsigned short* const D4o = lds16 + WS_OFF_D + 4 * WS_TILE + rD4w + own;
-#pragma unroll
-            for (int s2 = 0; s2 < BKS; ++s2)
-#pragma unroll
-                for (int k2 = 0; k2 < NPB; ++k2) *reinterpret_cast<u32x4*>(D4o + k2 * 16 * TRS + s2 * 8) = q.v[s2][k2];
-        }
-#endif
         // next element: its item data if it opens a new tile, its node position from the table value fetched above
         if (live) {
             const bool crossed = nx.j != cu.j;
             cu = nx;
             live = cu.j < nit;
-#ifndef UMNN_WS_EXP_NONEWITEM              // (timing experiment only: every tile reuses the first tile's item data, results wrong)
             if (crossed && live) new_item();
-#endif
             is_tan = live && ws_is_tan(sh, cu);
             if constexpr (FRONT) {
 #pragma unroll
@@ -506,23 +385,18 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         }
         ws_adv<WS_NS3, WS_TILE>(rA3); ws_adv<2, WS_TILE>(rD4);
         ws_adv<WS_NS1, WS_TILE>(rO1); ws_adv<2, WS_P3>(rO3);
-#if !UMNN_WS_C_SPLIT && UMNN_WS_PREFETCH_B
         {   // next step's a_3 operand of dW_3 (a tile written four steps ago)
             const unsigned short* A3n = lds16 + WS_OFF_A3 + rA3 + trb;
             ws_load_op<4>(ops, A3n, A3n); ws_load_op<6>(ops, A3n, A3n); ws_load_op<5>(ops, A3n, A3n); ws_load_op<7>(ops, A3n, A3n);
         }
-#endif
         ws_adv<2, WS_P3>(rS4); ws_adv<2, WS_TILE>(rD4w);
         WS_T(t2);
         WS_STEP_SYNC();
-        if constexpr (UMNN_WS_SLEEP_CA > 0) __builtin_amdgcn_s_sleep(UMNN_WS_SLEEP_CA);
         WS_T(t3);
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
     WS_TIMING_OUT(S);
-#if !UMNN_WS_C_SPLIT
     ws_write_dw(a, part, 3, dW, lane, FRONT && args.accumulate);
-#endif
 }
 
 template <int NRL, bool FRONT>
@@ -566,14 +440,12 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
     int rS4 = ws_ring0<2, WS_P3>(7), rD4 = ws_ring0<2, WS_TILE>(7);
     int rA3c = ws_ring0<WS_NS3, WS_TILE>(8), rD4c = ws_ring0<2, WS_TILE>(8);
     WsOps o2, o1;
-#if UMNN_WS_PREFETCH_B && !UMNN_WS_C_SPLIT
     {   // (first step: the tiles are still zero)
         const unsigned short* A2n = lds16 + WS_OFF_A2 + rA2 + trb;
         const unsigned short* A1n = lds16 + WS_OFF_A1 + rA1 + trb;
         ws_load_op<4>(o2, A2n, A2n); ws_load_op<6>(o2, A2n, A2n); ws_load_op<5>(o2, A2n, A2n); ws_load_op<7>(o2, A2n, A2n);
         ws_load_op<4>(o1, A1n, A1n); ws_load_op<6>(o1, A1n, A1n); ws_load_op<5>(o1, A1n, A1n); ws_load_op<7>(o1, A1n, A1n);
     }
-#endif
     ws_f32x16 dW3[2][2];
 #pragma unroll
     for (int to = 0; to < 2; ++to)
@@ -589,34 +461,15 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
         unsigned short* const D4o = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + own;
         u32x4 sg4[BKS];
         float dout = 0.f;
-#if !UMNN_WS_D4_IN_CA
 #pragma unroll
         for (int s2 = 0; s2 < BKS; ++s2) sg4[s2] = *reinterpret_cast<const u32x4*>(S4 + own + s2 * 8);
         dout = *reinterpret_cast<const float*>(S4 + p * TRS + 64);
-#endif
         const unsigned short* A2 = lds16 + WS_OFF_A2 + rA2 + trb;
         const unsigned short* A1 = lds16 + WS_OFF_A1 + rA1 + trb;
         const unsigned short* D3 = lds16 + WS_OFF_D + 2 * WS_TILE + rD3 + trb;
         const unsigned short* D2 = lds16 + WS_OFF_D + 0 * WS_TILE + rD2 + trb;
-#if UMNN_WS_C_SPLIT
-        // all three dW products here: operands of dW_3 first (o1's registers: dW_1's operands replace them during dW_2)
-        const unsigned short* A3c = lds16 + WS_OFF_A3 + rA3c + trb;
-        const unsigned short* D4c = lds16 + WS_OFF_D + 4 * WS_TILE + rD4c + trb;
-        ws_load_op<0>(o1, D4c, A3c); ws_load_op<2>(o1, D4c, A3c); ws_load_op<4>(o1, D4c, A3c); ws_load_op<6>(o1, D4c, A3c);
-        ws_load_op<5>(o1, D4c, A3c); ws_load_op<7>(o1, D4c, A3c); ws_load_op<1>(o1, D4c, A3c); ws_load_op<3>(o1, D4c, A3c);
-        swp_static_for<12>([&](auto nc) {
-            constexpr int nn = decltype(nc)::value;
-            ws_dw_mfma<nn>(dW3, o1);
-            if constexpr (nn < 8) ws_load_op<nn>(o2, D3, A2);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-#elif UMNN_WS_PREFETCH_B
         // (the a_2 / a_1 halves of the operands came in before the barrier: only the cotangent halves, written last step, are fetched here)
         ws_load_op<0>(o2, D3, A2); ws_load_op<2>(o2, D3, A2); ws_load_op<1>(o2, D3, A2); ws_load_op<3>(o2, D3, A2);
-#else
-        ws_load_op<0>(o2, D3, A2); ws_load_op<2>(o2, D3, A2); ws_load_op<4>(o2, D3, A2); ws_load_op<6>(o2, D3, A2);
-        ws_load_op<5>(o2, D3, A2); ws_load_op<7>(o2, D3, A2); ws_load_op<1>(o2, D3, A2); ws_load_op<3>(o2, D3, A2);
-#endif
         float d4[BT][4];
         auto d4_reg = [&](auto ec) __attribute__((always_inline)) {
             constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
@@ -635,60 +488,39 @@ __device__ __forceinline__ void ws_role_Cb(const BwdBf16Args& args, unsigned sho
             *reinterpret_cast<u32x4*>(D4o + k2 * 16 * TRS + ks * 8) = u32x4{q4[4 * ks][k2], q4[4 * ks + 1][k2], q4[4 * ks + 2][k2], q4[4 * ks + 3][k2]};
         };
         WS_T(t1);
-        swp_static_for<UMNN_WS_DW1_IN_B1 ? 12 : 24>([&](auto nc) {
+        swp_static_for<24>([&](auto nc) {
             constexpr int nn = decltype(nc)::value;
-            WS_MARK(nn, (UMNN_WS_DW1_IN_B1 ? 12 : 24));
-#ifndef UMNN_WS_EXP_NOMFMA_CB           // (timing experiments only: wrong results)
+            WS_MARK(nn, 24);
             if constexpr (nn < 12) ws_dw_mfma<nn>(dW2, o2);
             else ws_dw_mfma<nn - 12>(dW1, o1);
-#endif
-#if UMNN_WS_PREFETCH_B && !UMNN_WS_C_SPLIT
-            if constexpr (nn < 4 && !UMNN_WS_DW1_IN_B1) ws_load_op<nn>(o1, D2, A1);
-#else
-            if constexpr (nn < 8 && !UMNN_WS_DW1_IN_B1) ws_load_op<nn>(o1, D2, A1);
-#endif
+            if constexpr (nn < 4) ws_load_op<nn>(o1, D2, A1);
             // delta_4: two registers per slot, pair j split at slots j + 1 / j + 2, K-steps stored at 6, 7 / 10, 11
-#if !UMNN_WS_D4_IN_CA && !defined(UMNN_WS_EXP_NOD4_CB)
-#if UMNN_WS_SPREAD && !UMNN_WS_DW1_IN_B1
             // one register per slot, pair j split at slots 2j + 2 / 2j + 3, K-steps stored at 10, 11 / 18, 19 (spread over the 24 slots)
             if constexpr (nn < 16) d4_reg(std::integral_constant<int, nn>{});
             if constexpr (nn >= 2 && nn < 18 && (nn % 2) == 0) pair4(std::integral_constant<int, (nn - 2) / 2>{}, std::integral_constant<int, 0>{});
             if constexpr (nn >= 3 && nn < 19 && (nn % 2) == 1) pair4(std::integral_constant<int, (nn - 3) / 2>{}, std::integral_constant<int, 1>{});
             if constexpr (nn == 10 || nn == 11) store_d4(std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 10>{});
             if constexpr (nn == 18 || nn == 19) store_d4(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 18>{});
-#else
-            if constexpr (nn < 8) { d4_reg(std::integral_constant<int, 2 * nn>{}); d4_reg(std::integral_constant<int, 2 * nn + 1>{}); }
-            if constexpr (nn >= 1 && nn < 9) pair4(std::integral_constant<int, nn - 1>{}, std::integral_constant<int, 0>{});
-            if constexpr (nn >= 2 && nn < 10) pair4(std::integral_constant<int, nn - 2>{}, std::integral_constant<int, 1>{});
-            if constexpr (nn == 6 || nn == 7) store_d4(std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 6>{});
-            if constexpr (nn == 10 || nn == 11) store_d4(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 10>{});
-#endif
-#endif
             __builtin_amdgcn_sched_barrier(0);
         });
         ws_adv<WS_NS2, WS_TILE>(rA2); ws_adv<WS_NS1, WS_TILE>(rA1);
         ws_adv<2, WS_TILE>(rD3); ws_adv<2, WS_TILE>(rD2);
         ws_adv<2, WS_P3>(rS4); ws_adv<2, WS_TILE>(rD4);
         ws_adv<WS_NS3, WS_TILE>(rA3c); ws_adv<2, WS_TILE>(rD4c);
-#if UMNN_WS_PREFETCH_B && !UMNN_WS_C_SPLIT
         {   // next step's a_2 / a_1 operands (tiles written six and ten steps ago)
             const unsigned short* A2n = lds16 + WS_OFF_A2 + rA2 + trb;
             const unsigned short* A1n = lds16 + WS_OFF_A1 + rA1 + trb;
             ws_load_op<4>(o2, A2n, A2n); ws_load_op<6>(o2, A2n, A2n); ws_load_op<5>(o2, A2n, A2n); ws_load_op<7>(o2, A2n, A2n);
-            if constexpr (!UMNN_WS_DW1_IN_B1) { ws_load_op<4>(o1, A1n, A1n); ws_load_op<6>(o1, A1n, A1n); ws_load_op<5>(o1, A1n, A1n); ws_load_op<7>(o1, A1n, A1n); }
+            ws_load_op<4>(o1, A1n, A1n); ws_load_op<6>(o1, A1n, A1n); ws_load_op<5>(o1, A1n, A1n); ws_load_op<7>(o1, A1n, A1n);
         }
-#endif
         WS_T(t2);
         WS_STEP_SYNC();
         WS_T(t3);
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
     WS_TIMING_OUT(S);
-#if UMNN_WS_C_SPLIT
-    ws_write_dw(a, part, 3, dW3, lane, FRONT && args.accumulate);
-#endif
     ws_write_dw(a, part, 2, dW2, lane, FRONT && args.accumulate);
-    if constexpr (!UMNN_WS_DW1_IN_B1) ws_write_dw(a, part, 1, dW1, lane, FRONT && args.accumulate);
+    ws_write_dw(a, part, 1, dW1, lane, FRONT && args.accumulate);
 }
 
 // ============================================================================================================ waves F1..F3
@@ -753,9 +585,6 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
     };
     if (nit > 0) new_item_P();
 
-#ifndef UMNN_WS_ACC8
-#define UMNN_WS_ACC8 0          // 1: the two K-steps of the forward GEMM accumulate separately (eight independent MFMA chains), summed before the activation
-#endif
     f32x4 acc[BT], acc1[BT];
     float actF[BT][4], delta[BT][4];                   // (delta: the tangent values of a tangent element)
 #pragma unroll
@@ -813,9 +642,6 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
             constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4, j = e / 2;
             constexpr bool TAN = decltype(tanc)::value;
             if constexpr (e < NLIVE) {
-#if UMNN_WS_ACC8
-                acc[t][r] += acc1[t][r];
-#endif
                 if constexpr (!IS_OUT) {
                     if constexpr (TAN) {
                         // tangent element: times act'(a_{l+1}) of the element before (node 0), read off its leading bf16 piece
@@ -918,17 +744,9 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
             swp_static_for<48>([&](auto nc) {
                 constexpr int nn = decltype(nc)::value;
                 WS_MARK(nn, 48);
-#if UMNN_WS_ACC8
-                // (groups of four tiles alternate between the K-steps: a chain's next link is eight instructions away)
-                constexpr int s2 = (nn / 4) & 1, idx = 4 * (nn / 8) + (nn % 4);
-                f32x4 (&ac)[BT] = s2 ? acc1 : acc;
-                constexpr bool first = idx < 4;
-#else
                 constexpr int s2 = nn / 24, idx = nn % 24;
                 f32x4 (&ac)[BT] = acc;
                 constexpr bool first = s2 == 0 && idx < 4;
-#endif
-#ifndef UMNN_WS_EXP_NOMFMA_F            // (timing experiments only: wrong results)
                 if constexpr (idx < 12) {
                     constexpr int t = idx % 4, ba = idx / 4;
                     ac[t] = mfma_bf16(Wf[t][s2][0], bf.v[s2][ba], first ? zero : ac[t]);
@@ -939,12 +757,7 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
                     constexpr int t = idx - 20;
                     ac[t] = mfma_bf16(Wf[t][s2][2], bf.v[s2][0], ac[t]);
                 }
-#else
-                (void)first; (void)zero;
-#endif
-#ifndef UMNN_WS_EXP_NOVALU_F
                 if constexpr (!IS_OUT) {
-#if UMNN_WS_SPREAD
                     // the split of a_{l+1} spread over the whole loop (measured: front-loaded companions made the first twelve
                     // slots take 56 cycles each, the bare ones at the end 17): 30 micro-operations, one behind two of every three
                     // slots -- per K-step the four pairs stage by stage, then its three stores
@@ -954,14 +767,6 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
                         if constexpr (w < 12) pairF(std::integral_constant<int, 4 * ks + w % 4>{}, std::integral_constant<int, w / 4>{});
                         else store_a(std::integral_constant<int, ks>{}, std::integral_constant<int, w - 12>{});
                     }
-#else
-                    // pair j: rounding stages at slots 3j, 3j + 1, 3j + 2; K-step 0 stored at 12..14, K-step 1 at 24..26
-                    if constexpr (nn < 24 && (nn % 3) == 0) pairF(std::integral_constant<int, nn / 3>{}, std::integral_constant<int, 0>{});
-                    if constexpr (nn < 24 && (nn % 3) == 1) pairF(std::integral_constant<int, nn / 3>{}, std::integral_constant<int, 1>{});
-                    if constexpr (nn < 24 && (nn % 3) == 2) pairF(std::integral_constant<int, nn / 3>{}, std::integral_constant<int, 2>{});
-                    if constexpr (nn >= 12 && nn < 15) store_a(std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 12>{});
-                    if constexpr (nn >= 24 && nn < 27) store_a(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 24>{});
-#endif
                 } else {
                     // the leading piece of a_L does not wait for the scalar chain; dout and d w_out follow it
                     if constexpr (nn < 8) out_scalar(std::integral_constant<int, nn>{});
@@ -970,7 +775,6 @@ __device__ __forceinline__ void ws_role_F(const BwdBf16Args& args, unsigned shor
                     if constexpr (nn == 9) *reinterpret_cast<float*>(S4out + p * TRS + 64) = doutN;
                     if constexpr (nn >= 10 && nn < 18) { out_reg(std::integral_constant<int, 2 * (nn - 10)>{}); out_reg(std::integral_constant<int, 2 * (nn - 10) + 1>{}); }
                 }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -1039,15 +843,6 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
     f32x4 dW1x[BT], dcs[BT];
 #pragma unroll
     for (int t = 0; t < BT; ++t) { dW1x[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    constexpr bool HAS_DW = IS_TAIL && UMNN_WS_DW1_IN_B1;   // B1 also accumulates dW_1 += delta_2 (x) a_1 (same element as its GEMM)
-    const int trb = (8 * (g >> 1) + (p >> 2)) * TRS + 16 * (g & 1) + 4 * (p & 3);
-    ws_f32x16 dWb[2][2];
-#pragma unroll
-    for (int to = 0; to < 2; ++to)
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) dWb[to][ti][v] = 0.f;
     WsCursor cb{0, 0};
     float xvB = 0.f, x0vB = 0.f, dxvB = 0.f;
     auto new_item_B = [&]() __attribute__((always_inline)) {
@@ -1091,12 +886,6 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
             for (int k2 = 0; k2 < NPB; ++k2) bd.v[s2][k2] = *reinterpret_cast<const u32x4*>(Din + k2 * 16 * TRS + s2 * 8);
 #pragma unroll
         for (int s2 = 0; s2 < BKS; ++s2) sg[s2] = *reinterpret_cast<const u32x4*>(Asg + s2 * 8);
-        WsOps ob;
-        if constexpr (HAS_DW) {
-            const unsigned short* Dt = Din - own + trb, *At = Asg - own + trb;      // the same two tiles, transposing reads
-            ws_load_op<0>(ob, Dt, At); ws_load_op<2>(ob, Dt, At); ws_load_op<4>(ob, Dt, At); ws_load_op<6>(ob, Dt, At);
-            ws_load_op<5>(ob, Dt, At); ws_load_op<7>(ob, Dt, At); ws_load_op<1>(ob, Dt, At); ws_load_op<3>(ob, Dt, At);
-        }
         WS_T(t1);
         // ---- W_l^T GEMM (24 MFMAs, A operands = this wave's registers)
         f32x4 nd[BT];
@@ -1113,7 +902,6 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
             }
         }
         WS_MARK_HERE();                                   // (B waves: the cut is always after the GEMM)
-        if constexpr (HAS_DW) swp_static_for<12>([&](auto nc) { ws_dw_mfma<decltype(nc)::value>(dWb, ob); });
         // ---- delta_l = (W_l^T delta_{l+1}) . act'(a_l); B1: the tail of the node; B2, B3: split and store for the wave below
         f32x4 dl[BT];
 #pragma unroll
@@ -1181,7 +969,6 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
     WS_TIMING_OUT(S);
-    if constexpr (HAS_DW) ws_write_dw(a, part, 1, dWb, lane, FRONT && args.accumulate);
     if constexpr (IS_TAIL && !FRONT) {
 #pragma unroll
         for (int t = 0; t < BT; ++t)
@@ -1197,8 +984,8 @@ __device__ __forceinline__ void ws_role_B(const BwdBf16Args& args, unsigned shor
 }
 
 // wave -> role.  Waves w and w + 4 share a SIMD.  Default pairing: Ca + Cb, F1 + B1, F2 + B2, F3 + B3 -- every SIMD gets the same
-// matrix-pipe time (1152 cycles per step); the other pairings measured (UMNN_WS_PAIRING = 1..3) balance instruction counts better
-// and lose 1-2 ms to matrix-pipe contention.
+// matrix-pipe time (1152 cycles per step); the other pairings measured (EXPERIMENTS.md) balance instruction counts better and lose 1-2 ms to
+// matrix-pipe contention.
 template <int NRL, bool FRONT = false>
 __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws_kernel(const BwdBf16Args args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1230,26 +1017,9 @@ __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws_kernel(const BwdBf
         else if (role == 2) ws_role_F<NRL, 2, FRONT>(args, lds16, S, sh, part);
         else ws_role_F<NRL, 3, FRONT>(args, lds16, S, sh, part);
     } else {
-#if UMNN_WS_PAIRING == 0
         if (role == 0) ws_role_Cb<NRL, FRONT>(args, lds16, S, sh, part);
         else if (role == 1) ws_role_B<NRL, 1, FRONT>(args, lds16, S, sh, part);
         else if (role == 2) ws_role_B<NRL, 2, FRONT>(args, lds16, S, sh, part);
         else ws_role_B<NRL, 3, FRONT>(args, lds16, S, sh, part);
-#elif UMNN_WS_PAIRING == 1
-        if (role == 0) ws_role_B<NRL, 3, FRONT>(args, lds16, S, sh, part);
-        else if (role == 1) ws_role_B<NRL, 1, FRONT>(args, lds16, S, sh, part);
-        else if (role == 2) ws_role_B<NRL, 2, FRONT>(args, lds16, S, sh, part);
-        else ws_role_Cb<NRL, FRONT>(args, lds16, S, sh, part);
-#elif UMNN_WS_PAIRING == 2
-        if (role == 0) ws_role_B<NRL, 1, FRONT>(args, lds16, S, sh, part);
-        else if (role == 1) ws_role_B<NRL, 3, FRONT>(args, lds16, S, sh, part);
-        else if (role == 2) ws_role_B<NRL, 2, FRONT>(args, lds16, S, sh, part);
-        else ws_role_Cb<NRL, FRONT>(args, lds16, S, sh, part);
-#else
-        if (role == 0) ws_role_B<NRL, 2, FRONT>(args, lds16, S, sh, part);
-        else if (role == 1) ws_role_B<NRL, 1, FRONT>(args, lds16, S, sh, part);
-        else if (role == 2) ws_role_Cb<NRL, FRONT>(args, lds16, S, sh, part);
-        else ws_role_B<NRL, 3, FRONT>(args, lds16, S, sh, part);
-#endif
     }
 }
