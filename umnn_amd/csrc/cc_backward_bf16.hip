@@ -90,8 +90,8 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
                 args.scal = a.scal;
                 umnn_prof_begin(stream);
                 if (int rc = umnn_check(hipMemsetAsync(a.scal, 0, sizeof(Ws16Scal), stream), "memset launch scalars")) return rc;
-                const long long want = (a.NI + 255) / 256;
-                const unsigned nbm = (unsigned)(want < 4LL * nblocks_max ? want : 4LL * nblocks_max);
+                const long long want = (a.NI + 1023) / 1024;             // (>= 4 integrals per thread; at most one workgroup per CU)
+                const unsigned nbm = (unsigned)(want < (long long)nblocks_max ? want : (long long)nblocks_max);
                 hipLaunchKernelGGL(cc_bwd_cotmax_kernel, dim3(nbm), dim3(256), 0, stream, a, reinterpret_cast<Ws16Scal*>(a.scal));
 #ifdef UMNN_WS_TIMING
                 static double* tbuf16 = nullptr;

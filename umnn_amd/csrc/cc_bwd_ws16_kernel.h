@@ -143,6 +143,7 @@ __device__ __forceinline__ bool ws16_finite(float v) { return __builtin_fabsf(v)
 // max |g (x - x0) / 2|, max |g_fx| over the integrals and max |w_k| over the nodes, as the bit patterns of non-negative floats
 // (which order like unsigned integers): order-independent, so the result -- and with it sigma -- is deterministic
 __global__ __launch_bounds__(256) void cc_bwd_cotmax_kernel(const BwdArgs a, Ws16Scal* sc) {
+    __shared__ float red[3][4];
     float m0 = 0.f, m1 = 0.f, m2 = 0.f;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < a.NI; q += (long long)gridDim.x * blockDim.x) {
         const float xv = io_ld(a.x, q, a.x_bf16), x0v = a.x0 ? io_ld(a.x0, q, a.x_bf16) : 0.f;
@@ -157,7 +158,13 @@ __global__ __launch_bounds__(256) void cc_bwd_cotmax_kernel(const BwdArgs a, Ws1
         m1 = fmaxf(m1, __shfl_xor(m1, o));
         m2 = fmaxf(m2, __shfl_xor(m2, o));
     }
-    if ((threadIdx.x & 63) == 0) {
+    // one atomic per workgroup and scalar (the first version issued one per WAVE: 12 k same-address atomics = 96 us per call)
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m0; red[1][threadIdx.x >> 6] = m1; red[2][threadIdx.x >> 6] = m2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m0 = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        m1 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        m2 = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
         // (a non-finite cotangent has the largest bit pattern: sigma falls back to 1 and the run ends in the flag)
         atomicMax(&sc->cotmax, __float_as_uint(m0));
         if (a.gfx) atomicMax(&sc->gfxmax, __float_as_uint(m1));
