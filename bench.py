@@ -245,7 +245,7 @@ def main():
     ap.add_argument("--embedding", default="fp32", choices=["fp32", "bf16"],
                     help="storage of the [B, E*d] embedding between conditioner and quadrature kernels (bf16: configuration C4's "
                          "storage mode -- the kernels load bf16, arithmetic stays fp32; reported in config.embedding_storage)")
-    ap.add_argument("--precision", default="", choices=["", "fp32", "bf16x3", "bf16x6"],
+    ap.add_argument("--precision", default="", choices=["", "fp32", "bf16x3", "bf16x6", "f16x3"],
                     help="forward arithmetic (default: the library default, bf16x3)")
     args = ap.parse_args()
 
@@ -382,11 +382,14 @@ def main():
 
     # for the record: the same workload in the reference's own arithmetic (exact fp32 products on the fp32 MFMA kernels, fp32
     # conditioner GEMMs) and in the fp32-accurate middle mode on the bf16 matrix cores (three bf16 pieces, six cross terms: ~4e-7 on F)
-    exact = bf16x6 = None
+    exact = bf16x6 = f16x3 = None
     if extras and precision != "fp32":
         exact = side_record("fp32", PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA", "fp32 F.linear")
     if extras and precision == "bf16x3":
         bf16x6 = side_record("bf16x6", PEAK_BF16_MFMA_TFLOPS, "bf16 dense MFMA", "K-concatenated bf16 GEMMs (three products)")
+        # ... and on two fp16 pieces / three cross terms: the same fp32-level accuracy at the two-piece cost (fp16 exponent range:
+        # an opt-in mode, umnn_amd.set_precision("f16x3"))
+        f16x3 = side_record("f16x3", PEAK_BF16_MFMA_TFLOPS, "fp16 dense MFMA (same rate as bf16)", "K-concatenated bf16 GEMMs (three products)")
     # the un-sharded C3 batch on ONE GPU (65536 rows): the anchor the 8-GPU point of the sharded run is compared with
     full = None
     if extras and args.workload == "bsds300" and not args.rows and not args.graph:
@@ -426,7 +429,7 @@ def main():
         achieved = dom[2] / max(dom[0], 1e-9) / 1e9                    # TFLOP/s over those launches
         traffic, traffic_src = (None, "eval mode only") if args.mode != "eval" else \
             hbm_traffic(args.workload, args.live_traffic, ["--precision", precision] if args.precision else [])
-        on_bf16 = "bf16" in kernel_name
+        on_bf16 = "bf16" in kernel_name or "f16" in kernel_name
         peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
         # FLOPs the matrix pipe actually executes per launch in the bf16-split FORWARD kernels: per hidden->hidden layer
         # ceil((H_out+1)/16) output tiles x ceil(ceil((H_in+1)/16)/2) K-steps x 3|6 cross terms of 16x16x32 MFMAs
@@ -442,7 +445,8 @@ def main():
             tiles = -(-cfg["rows"] * cfg["d"] // 16)
             executed = per_tile_node * 16384.0 * tiles * (cfg["n"] + 1) / max(avg_kernel_ms, 1e-9) / 1e9
         dtype = {"fp32": "f32", "bf16x3": "f32 via bf16x3-split MFMA (fp32 accumulate)",
-                 "bf16x6": "f32 via bf16x6-split MFMA (fp32 accumulate)"}[precision] if on_bf16 or precision == "fp32" \
+                 "bf16x6": "f32 via bf16x6-split MFMA (fp32 accumulate)",
+                 "f16x3": "f32 via f16x3-split MFMA (fp32 accumulate)"}[precision] if on_bf16 or precision == "fp32" \
             else "f32"
         out = {
             "metric": "umnn_maf_log_density_evals_per_s" if args.mode == "eval" else "umnn_maf_training_samples_per_s",
@@ -489,6 +493,8 @@ def main():
             out["exact_fp32"] = exact
         if bf16x6 is not None:
             out["bf16x6"] = bf16x6
+        if f16x3 is not None:
+            out["f16x3"] = f16x3
         if full is not None:
             out["full_batch_n1"] = full
         if args.mode == "train":

@@ -195,6 +195,7 @@ int umnn_cc_forward_timed(const umnn_mlp* net, const float* x0, const float* x, 
 #define UMNN_PRECISION_FP32 0
 #define UMNN_PRECISION_BF16X3 1
 #define UMNN_PRECISION_BF16X6 2
+#define UMNN_PRECISION_F16X3 3   /* two fp16 pieces, three cross terms: fp32-level accuracy at the two-piece cost; fp16 range (overflow -> NaN) */
 int umnn_set_forward_precision(int mode);
 int umnn_get_forward_precision(void);
 /* Same for the backward kernels: UMNN_PRECISION_FP32 or UMNN_PRECISION_BF16X3 (default; env UMNN_BWD_PRECISION =

@@ -91,9 +91,9 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 def test_set_option_validates_ranges_without_gpu():
     """umnn_set_option accepts exactly the values load_env accepts: anything else is UMNN_EINVAL and leaves
     the option untouched; the documented values round-trip."""
-    for name, good, bad in (("fwd_p", (1, 2, -1), (0, 3)), ("fwd_ns", (1, 2, 4, -1), (3, 8)), ("fwd_precision", (0, 1, 2), (-1, 3, 7)),
+    for name, good, bad in (("fwd_p", (1, 2, -1), (0, 3)), ("fwd_ns", (1, 2, 4, -1), (3, 8)), ("fwd_precision", (0, 1, 2, 3), (-1, 4, 7)),
                             ("bwd_precision", (0, 1), (2,)), ("bwd_ns", (1, 32, -1), (0, 33, 64)), ("fwd_pipe", (0, 1, 2), (3, -1)),
-                            ("bwd_swp", (0, 1), (2, -1)), ("fwd_tail", (0, 1, -1), (2,))):
+                            ("bwd_swp", (0, 1), (2, -1)), ("fwd_tail", (0, 1, -1), (2,)), ("bwd_ws16", (0, 1, 2), (3, -1))):
         old = _lib.get_option(name)
         try:
             for v in good:

@@ -23,9 +23,9 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(autouse=True, params=["bf16x3", "bf16x6", "fp32"])
+@pytest.fixture(autouse=True, params=["bf16x3", "bf16x6", "fp32", "f16x3"])
 def precision(request):
-    """Every forward-parity test runs under all three arithmetic modes of the forward kernels (same tolerance)."""
+    """Every forward-parity test runs under all four arithmetic modes of the forward kernels (same tolerance)."""
     import umnn_amd
     old = umnn_amd.get_forward_precision()
     umnn_amd.set_forward_precision(request.param)
@@ -77,7 +77,8 @@ def test_forward_matches_golden_and_oracle(name, dev, precision):
     assert U.rel_err(F.cpu().numpy(), F64) < (4e-5 if precision == "bf16x3" else 2e-5)
     kname = _lib.lib().umnn_last_kernel_name().decode()
     if precision != "fp32" and len(G["hidden"]) >= 2 and max(int(v) for v in G["hidden"]) <= 63:
-        assert "cc_fwd_bf16" in kname and ("PARTS=2" if precision == "bf16x3" else "PARTS=3") in kname
+        family = "cc_fwd_f16" if precision == "f16x3" else "cc_fwd_bf16"
+        assert family in kname and ("PARTS=3" if precision == "bf16x6" else "PARTS=2") in kname
     if precision == "fp32":
         assert "bf16" not in kname
 
@@ -414,8 +415,8 @@ def test_pipelined_and_plain_bf16x3_kernels_agree_bit_for_bit(dev, opts):
     import umnn_amd
     from umnn_amd import integral as I, _lib, IntegrandNetwork
     from umnn_amd.nets import mlp_spec
-    if umnn_amd.get_forward_precision() != "bf16x3":
-        pytest.skip("the pipelined loop exists for bf16x3 only")
+    if umnn_amd.get_forward_precision() not in ("bf16x3", "f16x3"):
+        pytest.skip("the pipelined loop exists for the two-piece modes only (bf16x3, f16x3)")
     torch.manual_seed(5)
     net = IntegrandNetwork(7, 31, [50, 50, 50, 50], 1).to(dev)
     x = torch.randn(300, 7, device=dev) * 2
@@ -443,8 +444,8 @@ def test_pipelined_kernel_shapes_against_oracle(hid, relu, sigmoid, inv_f, n, NS
     import umnn_amd
     from umnn_amd import integral as I, _lib
     from umnn_amd.nets import MlpSpec
-    if umnn_amd.get_forward_precision() != "bf16x3":
-        pytest.skip("the pipelined loop exists for bf16x3 only")
+    if umnn_amd.get_forward_precision() not in ("bf16x3", "f16x3"):
+        pytest.skip("the pipelined loop exists for the two-piece modes only (bf16x3, f16x3)")
     opts(fwd_p=2, fwd_ns=NS)
     B, d, E = 23, 5, 7
     rng = np.random.RandomState(len(hid) * 17 + n)
@@ -593,8 +594,8 @@ def test_exact_wide_variants_against_oracle(hid, T, dev):
     import umnn_amd
     from umnn_amd import integral as I, _lib
     from umnn_amd.nets import MlpSpec
-    if umnn_amd.get_forward_precision() != "bf16x3":
-        pytest.skip("exact wide variants exist for bf16x3")
+    if umnn_amd.get_forward_precision() not in ("bf16x3", "f16x3"):
+        pytest.skip("exact wide variants exist for the two-piece modes (bf16x3, f16x3)")
     B, d, E, n = 21, 3, 6, 25
     rng = np.random.RandomState(T * 7 + len(hid))
     sizes = [1 + E] + hid + [1]
@@ -627,8 +628,8 @@ def test_pipelined_forward_does_not_depend_on_what_ran_before(hid, dev):
     import umnn_amd
     from umnn_amd import integral as I, IntegrandNetwork, _lib
     from umnn_amd.nets import mlp_spec
-    if umnn_amd.get_forward_precision() != "bf16x3":
-        pytest.skip("the pipelined loop exists for bf16x3 only")
+    if umnn_amd.get_forward_precision() not in ("bf16x3", "f16x3"):
+        pytest.skip("the pipelined loop exists for the two-piece modes only (bf16x3, f16x3)")
     torch.manual_seed(8)
     net = IntegrandNetwork(8, 31, hid, 1).to(dev)
     spec = mlp_spec(net)

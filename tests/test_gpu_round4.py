@@ -251,3 +251,79 @@ def test_eager_calls_after_an_unreplayed_capture_read_valid_caches(workload, dev
     assert torch.equal(got, eb)
     gb = umnn_amd.GraphedLL(model, xb, context=cb, warmup=0)          # a second capture before the first graph ever ran
     assert torch.equal(gb()[0], eb) and torch.equal(ga()[0], ea)
+
+
+def test_f16x3_forward_is_fp32_level_at_the_cost_of_bf16x3(dev):
+    """set_precision("f16x3"): the forward kernels of cc_fwd_bf16_kernel.h compiled on fp16 pieces (cc_forward_f16.hip) -- two 11-bit
+    pieces, three cross terms.  On the golden cases and on the benchmarked launch (8192 x 63, n = 100, sampled rows) F and f(x) are
+    within 3e-6 of the float64 oracle (bf16x3: up to ~2e-5; exact fp32 kernels: ~5e-7), on the same software-pipelined kernel."""
+    import umnn_amd
+    from umnn_amd import integral as I, _lib
+    from umnn_amd.nets import mlp_spec
+    old = umnn_amd.get_forward_precision()
+    try:
+        errs = {}
+        for mode in ("f16x3", "bf16x3"):
+            umnn_amd.set_forward_precision(mode)
+            worst = 0.0
+            for name in ("g2_bsds_d63_w2", "g2_power_d6_w2", "g2_vae_d64", "g2_toy_d2_w2"):
+                G = U.load(name)
+                spec = mlp_spec(build_integrand(G, dev))
+                F, fx, _ = I.hip_forward(spec, t(G["x0"], dev), t(G["x"], dev), t(G["h"], dev), int(G["n"]))
+                net64 = U.net_from_g2(G, np.float64)
+                F64 = O.integrate_parallel(net64, *(G[k].astype(np.float64) for k in ("x0", "x", "h")), int(G["n"]))
+                f64 = O.integrand(net64, G["x"].astype(np.float64), G["h"].astype(np.float64))
+                worst = max(worst, U.rel_err(F.cpu().numpy(), F64), U.rel_err(fx.cpu().numpy(), f64))
+            errs[mode] = worst
+        assert errs["f16x3"] < 3e-6 and errs["f16x3"] < 0.5 * errs["bf16x3"], errs
+        # the benchmarked launch
+        umnn_amd.set_forward_precision("f16x3")
+        torch.manual_seed(0)
+        B, d, E, n = 8192, 63, 30, 100
+        net = umnn_amd.IntegrandNetwork(d, 1 + E, [50] * 4, 1)
+        lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+        onet = O.Net([m.weight.detach().numpy().astype(np.float64) for m in lin], [m.bias.detach().numpy().astype(np.float64) for m in lin],
+                     O.LEAKY, O.ELU1)
+        net.to(dev)
+        x, h = torch.randn(B, d), torch.randn(B, E * d)
+        F, fx, _ = I.hip_forward(mlp_spec(net), None, x.to(dev), h.to(dev), n)
+        assert _lib.lib().umnn_last_kernel_name().decode() == "cc_fwd_f16<T=4,PARTS=2,P=2,EXACT=1,LIVE=13,PIPE>"
+        rows = np.random.RandomState(4).choice(B, 24, replace=False)
+        xr, hr = x.numpy()[rows].astype(np.float64), h.numpy()[rows].astype(np.float64)
+        assert U.rel_err(F.cpu().numpy()[rows], O.integrate_parallel(onet, np.zeros_like(xr), xr, hr, n)) < 3e-6
+        assert U.rel_err(fx.cpu().numpy()[rows], O.integrand(onet, xr, hr)) < 3e-6
+    finally:
+        umnn_amd.set_forward_precision(old)
+
+
+def test_f16x3_forward_overflow_is_nan_never_a_wrong_number(dev):
+    """fp16 pieces have fp16's exponent range: hidden activations beyond +-65504 overflow the leading piece.  The kernels detect
+    that in the output-layer sum and return NaN for the affected integrals (ELU + 1 would otherwise map a -inf sum to a finite 0);
+    the default bf16x3 arithmetic has fp32's range and stays finite on the same inputs.  (The other end of the range: a weight below
+    2^-14 = 6e-5 has a subnormal leading piece -- absolute error 2^-25 per weight; harmless for nets whose weights are O(1e-2), and
+    part of why the mode is opt-in.)"""
+    import umnn_amd
+    from umnn_amd import integral as I
+    from umnn_amd.nets import mlp_spec
+    torch.manual_seed(2)
+    net = umnn_amd.IntegrandNetwork(6, 31, [50] * 4, 1).to(dev)
+    spec = mlp_spec(net)
+    x, h = torch.randn(500, 6, device=dev), torch.randn(500, 180, device=dev)
+    x[:12] *= 3e6                      # a dozen rows whose first-layer activations reach ~1e5 .. 1e6 along the quadrature nodes
+    old = umnn_amd.get_forward_precision()
+    try:
+        umnn_amd.set_forward_precision("bf16x3")
+        Fb, fb, _ = I.hip_forward(spec, None, x, h, 30)
+        umnn_amd.set_forward_precision("fp32")
+        Fe, _, _ = I.hip_forward(spec, None, x, h, 30)
+        umnn_amd.set_forward_precision("f16x3")
+        Ff, ff, _ = I.hip_forward(spec, None, x, h, 30)
+    finally:
+        umnn_amd.set_forward_precision(old)
+    assert torch.isfinite(Fb).all() and torch.isfinite(fb).all() and torch.isfinite(Fe).all()
+    bad = ~torch.isfinite(Ff)
+    assert bad[:12].any() and not bad[12:].any(), "rows 0..11 drive |a_1| beyond 65504: fp16 pieces must overflow there and only there"
+    ok = ~bad
+    # wherever f16x3 returned a number, it is the right number: closer to the exact-fp32 kernels than the default arithmetic is
+    rel = lambda A: float(((A - Fe).abs()[ok] / Fe.abs().clamp(min=1.0)[ok]).max())
+    assert rel(Ff) < 1e-4 and rel(Ff) <= rel(Fb), (rel(Ff), rel(Fb))

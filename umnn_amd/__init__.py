@@ -35,10 +35,14 @@ def set_precision(name):
     'fp32'   : exact fp32 products everywhere (fp32 MFMA kernels forward and backward, fp32 conditioner GEMMs) -- the
                reference's arithmetic, ~2.4x slower forward.
     'bf16x6' : hidden GEMMs on the bf16 matrix cores with 6 cross terms (fp32-level accuracy, ~4e-7 on F).
-    'bf16x3' : the library default -- 3 cross terms (F to ~6e-6, every parity test passes at 1e-4), conditioner
+    'f16x3'  : hidden GEMMs of the forward kernels on TWO fp16 pieces / 3 cross terms (fp32-level accuracy, ~4e-7 on F, at the
+               speed of 'bf16x3').  fp16's exponent range: hidden activations beyond +-65504 overflow; that is detected and makes
+               the affected integrals NaN (never a wrong finite value) -- which is why it is not the default.
+    'bf16x3' : the library default -- 3 cross terms on bf16 pieces (F to ~6e-6, every parity test passes at 1e-4), conditioner
                inference GEMMs as K-concatenated bf16 GEMMs (3e-6 of the output range).
-    The backward kernels know 'fp32' and 'bf16x3' (6-term recompute + 3-term delta / dW); 'bf16x6' selects 'bf16x3' there."""
-    if name not in ("fp32", "bf16x3", "bf16x6"):
+    The backward kernels know 'fp32' and 'bf16x3' (fp32-level recompute + 3-term delta / dW; on fp16 pieces at large batch);
+    'bf16x6' and 'f16x3' select 'bf16x3' there."""
+    if name not in ("fp32", "bf16x3", "bf16x6", "f16x3"):
         raise ValueError(name)
     set_forward_precision(name)
     set_backward_precision("fp32" if name == "fp32" else "bf16x3")

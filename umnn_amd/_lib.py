@@ -103,7 +103,7 @@ class MadeNet(ctypes.Structure):
     _fields_ = [("n_layers", ctypes.c_int), ("widths", ctypes.c_int * (MADE_MAX_LAYERS + 1)),
                 ("W", ctypes.c_void_p * MADE_MAX_LAYERS), ("b", ctypes.c_void_p * MADE_MAX_LAYERS)]
 
-PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
 PROF_FORWARD, PROF_BACKWARD, PROF_FINISH = 0, 1, 2
 
 
@@ -149,7 +149,8 @@ def check(rc, what):
 
 
 def set_forward_precision(name):
-    """'fp32' (exact fp32 MFMA), 'bf16x3' (default: bf16 split, 3 cross terms) or 'bf16x6' (fp32-level accuracy)."""
+    """'fp32' (exact fp32 MFMA), 'bf16x3' (default: bf16 split, 3 cross terms), 'bf16x6' (three bf16 pieces: fp32-level accuracy) or
+    'f16x3' (two fp16 pieces, three cross terms: fp32-level accuracy at the cost of bf16x3, fp16 range -- overflow gives NaN)."""
     check(lib().umnn_set_forward_precision(PRECISIONS[name]), "umnn_set_forward_precision")
 
 

@@ -86,6 +86,7 @@ static void load_env(UmnnOptions& o) {
     if (const char* ev = getenv("UMNN_FWD_PRECISION")) {
         if (!strcmp(ev, "fp32")) fp = UMNN_PRECISION_FP32;
         else if (!strcmp(ev, "bf16x6")) fp = UMNN_PRECISION_BF16X6;
+        else if (!strcmp(ev, "f16x3")) fp = UMNN_PRECISION_F16X3;
     }
     if (const char* ev = getenv("UMNN_BWD_PRECISION")) bp = !strcmp(ev, "fp32") ? UMNN_PRECISION_FP32 : UMNN_PRECISION_BF16X3;
     o.fwd_precision = fp; o.bwd_precision = bp;
@@ -128,7 +129,7 @@ static std::atomic<int>* option_slot(const char* name) {
 }
 // the same per-option ranges load_env accepts (anything else would reach the launchers as "no such variant")
 static bool option_value_ok(const char* name, int v) {
-    if (!strcmp(name, "fwd_precision")) return v >= UMNN_PRECISION_FP32 && v <= UMNN_PRECISION_BF16X6;
+    if (!strcmp(name, "fwd_precision")) return v >= UMNN_PRECISION_FP32 && v <= UMNN_PRECISION_F16X3;
     if (!strcmp(name, "bwd_precision")) return v == UMNN_PRECISION_FP32 || v == UMNN_PRECISION_BF16X3;
     if (!strcmp(name, "fwd_p")) return v == -1 || v == 1 || v == 2;
     if (!strcmp(name, "fwd_ns")) return v == -1 || v == 1 || v == 2 || v == 4;
@@ -156,7 +157,7 @@ extern "C" int umnn_get_option(const char* name, int* value) {
     return 0;
 }
 extern "C" int umnn_set_forward_precision(int mode) {
-    if (mode < UMNN_PRECISION_FP32 || mode > UMNN_PRECISION_BF16X6) return umnn_fail(UMNN_EINVAL, "unknown precision mode");
+    if (mode < UMNN_PRECISION_FP32 || mode > UMNN_PRECISION_F16X3) return umnn_fail(UMNN_EINVAL, "unknown precision mode");
     umnn_options().fwd_precision = mode;
     return 0;
 }

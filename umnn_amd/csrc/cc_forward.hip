@@ -235,6 +235,7 @@ static const FwdVariant kFwdVariants[] = {
 };
 
 int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps, hipStream_t stream);
+int umnn_launch_forward_f16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps, hipStream_t stream);     // cc_forward_f16.hip
 
 static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, const float* h,
                           const float* scaling, const float* cc_w, const float* cc_s, int nb_steps,
@@ -281,6 +282,12 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
     const int prec = opt.fwd_precision;
     if (prec != UMNN_PRECISION_FP32 && a.m.n_linear - 1 >= 2) {
         a.ns = ns;
+        // f16x3: two fp16 pieces, three cross terms (fp32-level).  Shapes that family does not cover fall through to the three-piece
+        // bf16 kernels (the same accuracy class), then to fp32 MFMA -- never to the two-piece bf16 arithmetic.
+        if (prec == UMNN_PRECISION_F16X3) {
+            const int rc16 = umnn_launch_forward_f16(a, net, 2, P, ns, nb_steps, stream);
+            if (rc16 != UMNN_EUNSUPPORTED) return rc16;
+        }
         const int rc = umnn_launch_forward_bf16(a, net, prec == UMNN_PRECISION_BF16X3 ? 2 : 3, P, ns, nb_steps, stream);
         if (rc != UMNN_EUNSUPPORTED) return rc;
     }

@@ -1,6 +1,16 @@
 // Forward quadrature on the bf16 matrix cores: variant table and launcher (the kernel template, with its layout notes,
 // lives in cc_fwd_bf16_kernel.h and is shared with the inversion variants of cc_invert.hip).
 #include "cc_fwd_bf16_kernel.h"
+using namespace UMNN_FWD_NS;
+// (this file is compiled twice: as is -- bf16 pieces, umnn_launch_forward_bf16 -- and through cc_forward_f16.hip with
+// -DUMNN_FWD_PIECE_F16 -- fp16 pieces, umnn_launch_forward_f16, kernel names cc_fwd_f16<...>)
+#ifdef UMNN_FWD_PIECE_F16
+#define FWD_KNAME "cc_fwd_f16"
+#define FWD_LAUNCH umnn_launch_forward_f16
+#else
+#define FWD_KNAME "cc_fwd_bf16"
+#define FWD_LAUNCH umnn_launch_forward_bf16
+#endif
 
 // ------------------------------------------------------------------------------------------
 typedef void (*fwd_bf16_kernel_t)(const FwdBf16Args);
@@ -9,18 +19,22 @@ struct Bf16Variant { int tmax, nparts, p, exact, nrl, pipe; fwd_bf16_kernel_t fn
 // 31-100-50-50-50-50-1.  Shape-exact: layer 1's GEMM contracts over T1 tiles, the others over four.
 // LIVE=13: every later layer 48..51 wide -- 13 live registers per lane and the merged five-K-step layout from layer 2 on.
 struct Bf16WideFirst { int t1, nrl, p; fwd_bf16_kernel_t fn; const char* name; };
-#define BF16_WIDE_FIRST(T, NR, PP) { T, NR, PP, cc_fwd_bf16_kernel<T, 2, PP, true, NR, false, false, 4>, "cc_fwd_bf16<T1=" #T ",TREST=4,PARTS=2,P=" #PP ",EXACT=1,LIVE=" #NR ">" }
+#define BF16_WIDE_FIRST(T, NR, PP) { T, NR, PP, cc_fwd_bf16_kernel<T, 2, PP, true, NR, false, false, 4>, FWD_KNAME "<T1=" #T ",TREST=4,PARTS=2,P=" #PP ",EXACT=1,LIVE=" #NR ">" }
 static const Bf16WideFirst kBf16WideFirst[] = { BF16_WIDE_FIRST(5, 13, 1), BF16_WIDE_FIRST(6, 13, 1), BF16_WIDE_FIRST(7, 13, 1), BF16_WIDE_FIRST(8, 13, 1),
                                                 BF16_WIDE_FIRST(5, 0, 1), BF16_WIDE_FIRST(6, 0, 1), BF16_WIDE_FIRST(7, 0, 1), BF16_WIDE_FIRST(8, 0, 1) };
 // (two point tiles per wave, P = 2: 260 registers = one wave per SIMD, 0.63 ms against 0.49 ms at the MNIST shape -- not instantiated)
-#define BF16_VARIANT(T, NP, PP, EX, NR) { T, NP, PP, EX, NR, 0, cc_fwd_bf16_kernel<T, NP, PP, (EX) != 0, NR>, "cc_fwd_bf16<T=" #T ",PARTS=" #NP ",P=" #PP ",EXACT=" #EX ",LIVE=" #NR ">" }
-#define BF16_PIPE_VARIANT(NP, PP, NR) { 4, NP, PP, 1, NR, 1, cc_fwd_bf16_kernel<4, NP, PP, true, NR, true>, "cc_fwd_bf16<T=4,PARTS=" #NP ",P=" #PP ",EXACT=1,LIVE=" #NR ",PIPE>" }
+#define BF16_VARIANT(T, NP, PP, EX, NR) { T, NP, PP, EX, NR, 0, cc_fwd_bf16_kernel<T, NP, PP, (EX) != 0, NR>, FWD_KNAME "<T=" #T ",PARTS=" #NP ",P=" #PP ",EXACT=" #EX ",LIVE=" #NR ">" }
+#define BF16_PIPE_VARIANT(NP, PP, NR) { 4, NP, PP, 1, NR, 1, cc_fwd_bf16_kernel<4, NP, PP, true, NR, true>, FWD_KNAME "<T=4,PARTS=" #NP ",P=" #PP ",EXACT=1,LIVE=" #NR ",PIPE>" }
 static const Bf16Variant kBf16Variants[] = {
     BF16_PIPE_VARIANT(2, 2, 13), BF16_PIPE_VARIANT(2, 2, 0),   // software-pipelined node loop (>= 2 hidden layers, bf16x3)
-    BF16_VARIANT(4, 2, 1, 1, 13), BF16_VARIANT(4, 2, 2, 1, 13), BF16_VARIANT(4, 3, 1, 1, 13), BF16_VARIANT(4, 3, 2, 1, 13),   // widths 48..51
-    BF16_VARIANT(4, 2, 1, 1, 0), BF16_VARIANT(4, 2, 2, 1, 0), BF16_VARIANT(4, 3, 1, 1, 0), BF16_VARIANT(4, 3, 2, 1, 0),       // widths 52..62
-    BF16_VARIANT(2, 2, 1, 0, 0), BF16_VARIANT(2, 2, 2, 0, 0), BF16_VARIANT(2, 3, 1, 0, 0), BF16_VARIANT(2, 3, 2, 0, 0),
-    BF16_VARIANT(4, 2, 1, 0, 0), BF16_VARIANT(4, 2, 2, 0, 0), BF16_VARIANT(4, 3, 1, 0, 0), BF16_VARIANT(4, 3, 2, 0, 0),
+    BF16_VARIANT(4, 2, 1, 1, 13), BF16_VARIANT(4, 2, 2, 1, 13),   // widths 48..51
+    BF16_VARIANT(4, 2, 1, 1, 0), BF16_VARIANT(4, 2, 2, 1, 0),     // widths 52..62
+    BF16_VARIANT(2, 2, 1, 0, 0), BF16_VARIANT(2, 2, 2, 0, 0),
+    BF16_VARIANT(4, 2, 1, 0, 0), BF16_VARIANT(4, 2, 2, 0, 0),
+#ifndef UMNN_FWD_PIECE_F16          // three pieces / six cross terms (bf16x6): pointless on fp16 pieces, whose two already carry 22 bits
+    BF16_VARIANT(4, 3, 1, 1, 13), BF16_VARIANT(4, 3, 2, 1, 13), BF16_VARIANT(4, 3, 1, 1, 0), BF16_VARIANT(4, 3, 2, 1, 0),
+    BF16_VARIANT(2, 3, 1, 0, 0), BF16_VARIANT(2, 3, 2, 0, 0), BF16_VARIANT(4, 3, 1, 0, 0), BF16_VARIANT(4, 3, 2, 0, 0),
+#endif
     BF16_VARIANT(7, 2, 1, 1, 26), BF16_VARIANT(7, 2, 1, 1, 0),   // widths 96..111 (100-wide toy / MonotonicNN nets): 3 K-steps + a half one
     BF16_VARIANT(5, 2, 1, 1, 0), BF16_VARIANT(6, 2, 1, 1, 0), BF16_VARIANT(8, 2, 1, 1, 0),   // widths 64..79, 80..95, 112..127
     BF16_VARIANT(8, 2, 1, 0, 0), BF16_VARIANT(8, 2, 2, 0, 0),   // (8 tiles x 3 parts does not fit the register file: fp32 kernels instead)
@@ -30,7 +44,7 @@ int umnn_launch_forward_p32(FwdArgs& a, const umnn_mlp* net, int nb_steps, hipSt
 
 // Returns 0 and launches, UMNN_EUNSUPPORTED (without setting the error text's prefix) if the shape does not fit
 // this kernel family (caller then uses the fp32-MFMA kernels), or another error code.
-int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps,
+int FWD_LAUNCH(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps,
                              hipStream_t stream) {
     const int L = a.m.n_linear - 1;
     const UmnnOptions& opt = umnn_options();
@@ -124,10 +138,12 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
     const bool want_pipe = opt.fwd_pipe != 0 && L >= 2;
     // the 32x32x16 formulation of the flagship shape: opt-in (UMNN_FWD_PIPE=2 / option fwd_pipe = 2).  Same wall time as the
     // default at C3 with 10 % fewer cycles -- the chip clocks it lower (the kernel is power-bound)
+#ifndef UMNN_FWD_PIECE_F16
     if (opt.fwd_pipe == 2 && exact && T == 4 && nparts == 2 && nrl == 13) {
         const int rc = umnn_launch_forward_p32(a, net, nb_steps, stream);
         if (rc != UMNN_EUNSUPPORTED) return rc;
     }
+#endif
     // the pipelined loop needs two point tiles per wave and pays off as soon as that still leaves a wave per SIMD
     // (measured at the POWER and VAE shapes: P=2, NS=1 beats every P=1 split by 6-7 %)
     if (want_pipe && exact && T == 4 && nparts == 2 && !p_forced && !ns_forced &&

@@ -18,6 +18,7 @@
 // streamed (each is used by one or two consecutive instructions: no fragment cache in registers).
 #include "cc_bf16.h"
 #include "cc_fwd_bf16_kernel.h"
+using namespace UMNN_FWD_NS;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

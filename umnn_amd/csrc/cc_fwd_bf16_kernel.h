@@ -26,6 +26,64 @@
 #include "cc_fwd_shared.h"
 #include "cc_host.h"
 
+// ---- the 16-bit PIECE type of this translation unit.  The kernels below are written once; cc_forward_bf16.hip / cc_invert.hip /
+// cc_forward_p32.hip compile them with bf16 pieces (namespace fwd_bf16: 8 significand bits per piece, fp32's exponent range),
+// cc_forward_f16.hip with fp16 pieces (-DUMNN_FWD_PIECE_F16, namespace fwd_f16: 11 bits per piece -- two pieces / three cross
+// terms are then fp32-level, ~4e-7 on F instead of ~6e-6 -- but fp16's exponent range: a hidden activation beyond +-65504 overflows
+// its leading piece; that is detected in the output-layer sum and turns the integral into NaN, never into a wrong finite number).
+#ifdef UMNN_FWD_PIECE_F16
+#define UMNN_FWD_NS fwd_f16
+#else
+#define UMNN_FWD_NS fwd_bf16
+#endif
+namespace UMNN_FWD_NS {
+#ifdef UMNN_FWD_PIECE_F16
+typedef _Float16 pc_x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pc_x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 pc_x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned PC_MINUS_ONE = 0xBC00u;
+constexpr bool PC_F16 = true;
+__device__ __forceinline__ f32x4 pc_mfma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pc_x8, a), __builtin_bit_cast(pc_x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 pc_mfma_k16(u32x2 a, u32x2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(pc_x4, a), __builtin_bit_cast(pc_x4, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned pc_cvt_pk(float x0, float x1) {      // v_cvt_pk_f16_f32: round to nearest even
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, pc_x2));
+}
+__device__ __forceinline__ float pc_lo_f32(unsigned bits) { return (float)__builtin_bit_cast(pc_x2, bits)[0]; }
+__device__ __forceinline__ float pc_hi_f32(unsigned bits) { return (float)__builtin_bit_cast(pc_x2, bits)[1]; }
+#else
+constexpr unsigned PC_MINUS_ONE = 0xBF80u;
+constexpr bool PC_F16 = false;
+__device__ __forceinline__ f32x4 pc_mfma(u32x4 a, u32x4 b, f32x4 c) { return mfma_bf16(a, b, c); }
+__device__ __forceinline__ f32x4 pc_mfma_k16(u32x2 a, u32x2 b, f32x4 c) { return mfma_bf16_k16(a, b, c); }
+__device__ __forceinline__ unsigned pc_cvt_pk(float x0, float x1) {      // v_cvt_pk_bf16_f32: round to nearest even
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+}
+__device__ __forceinline__ float pc_lo_f32(unsigned bits) { return __uint_as_float(bits << 16); }
+__device__ __forceinline__ float pc_hi_f32(unsigned bits) { return __uint_as_float(bits & 0xffff0000u); }
+#endif
+// output activation.  fp16 pieces: an overflowed piece (|a| >= 65520) is +-inf and reaches the output-layer sum as inf / NaN; ELU + 1
+// would map -inf to a finite 0, so a non-finite sum is made a NaN outright (bf16 pieces share fp32's range: nothing to guard)
+__device__ __forceinline__ float pc_out_act(float sd, int kind) {
+    const float f = out_act_f(sd, kind);
+    if constexpr (PC_F16) return __builtin_fabsf(sd) < __builtin_inff() ? f : __builtin_nanf("");
+    return f;
+}
+// (x0, x1) -> packed pairs of the NPARTS pieces (piece k of x0 in the low half of out[k], of x1 in the high half): each piece the
+// round-to-nearest value of the running remainder (same arithmetic as split_pair of cc_bf16.h for bf16 pieces)
+template <int NPARTS>
+__device__ __forceinline__ void pc_split_pair(float x0, float x1, unsigned (&out)[NPARTS]) {
+#pragma unroll
+    for (int k = 0; k < NPARTS; ++k) {
+        const unsigned bits = pc_cvt_pk(x0, x1);
+        out[k] = bits;
+        if (k + 1 < NPARTS) { x0 -= pc_lo_f32(bits); x1 -= pc_hi_f32(bits); }
+    }
+}
+
 // Stage the pre-split, pre-permuted weight fragments.  img16 index: ((t'*ks + s)*NPARTS + part)*512 + lane*8 + j.
 // half_in[l] != 0: the input layer has an odd tile count; ks counts its FULL K-steps (tile pairs) only and the last
 // tile follows as half fragments (64 lanes x 4 bf16, for the K = 16 MFMA) at ((t'*NPARTS + part)*256 + lane*4 + j)
@@ -66,7 +124,7 @@ __device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 unsigned q[NPARTS];
-                split_pair<NPARTS>(v[2 * e], v[2 * e + 1], q);
+                pc_split_pair<NPARTS>(v[2 * e], v[2 * e + 1], q);
 #pragma unroll
                 for (int part = 0; part < NPARTS; ++part) pk[part][e] = q[part];
             }
@@ -102,8 +160,8 @@ __device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks
                 const int ln = idx & 63, t = idx >> 6;
                 const int fo = fout_of(t, ln & 15), g = ln >> 4;
                 unsigned q0[NPARTS], q1[NPARTS];
-                split_pair<NPARTS>(wv(fo, feat_of(2 * ks, 0, g)), wv(fo, feat_of(2 * ks, 1, g)), q0);
-                split_pair<NPARTS>(wv(fo, feat_of(2 * ks, 2, g)), wv(fo, feat_of(2 * ks, 3, g)), q1);
+                pc_split_pair<NPARTS>(wv(fo, feat_of(2 * ks, 0, g)), wv(fo, feat_of(2 * ks, 1, g)), q0);
+                pc_split_pair<NPARTS>(wv(fo, feat_of(2 * ks, 2, g)), wv(fo, feat_of(2 * ks, 3, g)), q1);
 #pragma unroll
                 for (int part = 0; part < NPARTS; ++part)
                     *reinterpret_cast<u32x2*>(himg + (t * NPARTS + part) * 256 + ln * 4) = u32x2{q0[part], q1[part]};
@@ -284,7 +342,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
             u32x4 sel[2];
             {
                 const unsigned rho = lane & 15, slot = rho & 3;
-                const unsigned v = ((unsigned)(lane >> 4) == (rho >> 2)) ? (0xBF80u << (16 * (slot & 1))) : 0u;   // bf16(-1)
+                const unsigned v = ((unsigned)(lane >> 4) == (rho >> 2)) ? (PC_MINUS_ONE << (16 * (slot & 1))) : 0u;   // -1 as a piece
                 sel[0] = u32x4{slot < 2 ? v : 0u, slot < 2 ? 0u : v, 0u, 0u};
                 sel[1] = u32x4{0u, 0u, slot < 2 ? v : 0u, slot < 2 ? 0u : v};
             }
@@ -310,8 +368,8 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 constexpr int term = MERGE ? (i / 4) % 3 : (i / 4) % 3;
                 constexpr int wa = (MERGE && ks == 1) ? i / 4 - 3 : (term == 2 ? 1 : 0);
                 constexpr int ba = (MERGE && ks == 1) ? i / 4 - 3 : (term == 1 ? 1 : 0);
-                if constexpr (i < 4) acc[t] = mfma_bf16(wf[t][ks][wa], bfin[ks][ba], f32x4{0.f, 0.f, 0.f, 0.f});
-                else acc[t] = mfma_bf16(wf[t][ks][wa], bfin[ks][ba], acc[t]);
+                if constexpr (i < 4) acc[t] = pc_mfma(wf[t][ks][wa], bfin[ks][ba], f32x4{0.f, 0.f, 0.f, 0.f});
+                else acc[t] = pc_mfma(wf[t][ks][wa], bfin[ks][ba], acc[t]);
             };
             // in the second tile's section: once a fragment has been used for the last time, fetch the same
             // fragment of the layer that runs next into its registers
@@ -361,44 +419,44 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                 }
                 if constexpr (QCVT >= 0) {                        // leading pieces of tiles 2q and 2q+1: the whole quad at once
                     constexpr int ta = 2 * QCVT, tb = 2 * QCVT + 1;
-                    const bf16x2 a0 = __builtin_convertvector(f32x2{z[ta][0], z[ta][1]}, bf16x2);
-                    const bf16x2 a1 = __builtin_convertvector(f32x2{z[ta][2], z[ta][3]}, bf16x2);
-                    const bf16x2 b0 = __builtin_convertvector(f32x2{z[tb][0], z[tb][1]}, bf16x2);
-                    const bf16x2 b1 = __builtin_convertvector(f32x2{z[tb][2], z[tb][3]}, bf16x2);
-                    bfout[QCVT][0] = u32x4{__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1),
-                                           __builtin_bit_cast(unsigned, b0), __builtin_bit_cast(unsigned, b1)};
+                    const unsigned a0 = pc_cvt_pk(z[ta][0], z[ta][1]);
+                    const unsigned a1 = pc_cvt_pk(z[ta][2], z[ta][3]);
+                    const unsigned b0 = pc_cvt_pk(z[tb][0], z[tb][1]);
+                    const unsigned b1 = pc_cvt_pk(z[tb][2], z[tb][3]);
+                    bfout[QCVT][0] = u32x4{a0, a1,
+                                           b0, b1};
                 }
                 if constexpr (QSEL >= 0) {
-                    z[2 * QSEL] = mfma_bf16(sel[0], bfout[QSEL][0], z[2 * QSEL]);          // exact remainders
-                    z[2 * QSEL + 1] = mfma_bf16(sel[1], bfout[QSEL][0], z[2 * QSEL + 1]);
+                    z[2 * QSEL] = pc_mfma(sel[0], bfout[QSEL][0], z[2 * QSEL]);          // exact remainders
+                    z[2 * QSEL + 1] = pc_mfma(sel[1], bfout[QSEL][0], z[2 * QSEL + 1]);
                 }
                 if constexpr (t_hi >= 0) {
-                    const bf16x2 h0 = __builtin_convertvector(f32x2{z[t_hi][0], z[t_hi][1]}, bf16x2);
-                    const bf16x2 h1 = __builtin_convertvector(f32x2{z[t_hi][2], z[t_hi][3]}, bf16x2);
-                    bfout[t_hi / 2][0][2 * (t_hi % 2)] = __builtin_bit_cast(unsigned, h0);
-                    bfout[t_hi / 2][0][2 * (t_hi % 2) + 1] = __builtin_bit_cast(unsigned, h1);
+                    const unsigned h0 = pc_cvt_pk(z[t_hi][0], z[t_hi][1]);
+                    const unsigned h1 = pc_cvt_pk(z[t_hi][2], z[t_hi][3]);
+                    bfout[t_hi / 2][0][2 * (t_hi % 2)] = h0;
+                    bfout[t_hi / 2][0][2 * (t_hi % 2) + 1] = h1;
                     if constexpr (MERGE && t_hi == 2) {           // tile 2's leading pieces also close the last K-step
-                        bfout[1][1][2] = __builtin_bit_cast(unsigned, h0);
-                        bfout[1][1][3] = __builtin_bit_cast(unsigned, h1);
+                        bfout[1][1][2] = h0;
+                        bfout[1][1][3] = h1;
                     }
-                    z[t_hi] = mfma_bf16(sel[t_hi % 2], bfout[t_hi / 2][0], z[t_hi]);          // exact remainders
+                    z[t_hi] = pc_mfma(sel[t_hi % 2], bfout[t_hi / 2][0], z[t_hi]);          // exact remainders
                 }
                 if constexpr (t_lo >= 0) {
-                    const bf16x2 l0 = __builtin_convertvector(f32x2{z[t_lo][0], z[t_lo][1]}, bf16x2);
-                    const bf16x2 l1 = __builtin_convertvector(f32x2{z[t_lo][2], z[t_lo][3]}, bf16x2);
-                    bfout[t_lo / 2][1][2 * (t_lo % 2)] = __builtin_bit_cast(unsigned, l0);
-                    bfout[t_lo / 2][1][2 * (t_lo % 2) + 1] = __builtin_bit_cast(unsigned, l1);
+                    const unsigned l0 = pc_cvt_pk(z[t_lo][0], z[t_lo][1]);
+                    const unsigned l1 = pc_cvt_pk(z[t_lo][2], z[t_lo][3]);
+                    bfout[t_lo / 2][1][2 * (t_lo % 2)] = l0;
+                    bfout[t_lo / 2][1][2 * (t_lo % 2) + 1] = l1;
                 }
                 if constexpr (i == T3A) {                        // tile 3 has one live register: split it on the VALU
                     if constexpr (FIRST) z[3][0] = fmaf(w1x[3][0], tkv, cv[3][0]);
                     rem_a = PRE ? z[3][0] : hidden_act_f(z[3][0], slope);
-                    const bf16x2 h = __builtin_convertvector(f32x2{rem_a, 0.f}, bf16x2);
-                    rem_hi = __builtin_bit_cast(unsigned, h);
+                    const unsigned h = pc_cvt_pk(rem_a, 0.f);
+                    rem_hi = h;
                     bfout[1][0][3] = rem_hi;                     // k-slots 6,7: (hi, 0)
                 }
                 if constexpr (i == T3B) {
-                    const bf16x2 l = __builtin_convertvector(f32x2{rem_a - __uint_as_float(rem_hi << 16), 0.f}, bf16x2);
-                    bfout[1][0][2] = rem_hi | (__builtin_bit_cast(unsigned, l) << 16);      // k-slots 4,5: (hi, lo)
+                    const unsigned l = pc_cvt_pk(rem_a - pc_lo_f32(rem_hi), 0.f);
+                    bfout[1][0][2] = rem_hi | (l << 16);      // k-slots 4,5: (hi, lo)
                 }
             };
 
@@ -479,7 +537,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
                     const float sr = group_allreduce(pt == 0 ? sd0 : sd1);
-                    const float f = out_act_f(sr, m.out_act);
+                    const float f = pc_out_act(sr, m.out_act);
                     Facc[pt] = fmaf(wk, maybe_inverse(f, a.inv_f), Facc[pt]);
                     if (k == 0) fxv[pt] = f;
                     if (k == n) fx0v[pt] = f;
@@ -541,10 +599,10 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                         unsigned q0[NPARTS], q1[NPARTS], q2[NPARTS], q3[NPARTS];
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) q0[k2] = q1[k2] = q2[k2] = q3[k2] = 0u;
-                        if (8 * s + 0 < NIN) split_pair<NPARTS>(act[pt][2 * s][0], act[pt][2 * s][1], q0);
-                        if (8 * s + 2 < NIN) split_pair<NPARTS>(act[pt][2 * s][2], act[pt][2 * s][3], q1);
-                        if (8 * s + 4 < NIN) split_pair<NPARTS>(act[pt][2 * s + 1][0], act[pt][2 * s + 1][1], q2);
-                        if (8 * s + 6 < NIN) split_pair<NPARTS>(act[pt][2 * s + 1][2], act[pt][2 * s + 1][3], q3);
+                        if (8 * s + 0 < NIN) pc_split_pair<NPARTS>(act[pt][2 * s][0], act[pt][2 * s][1], q0);
+                        if (8 * s + 2 < NIN) pc_split_pair<NPARTS>(act[pt][2 * s][2], act[pt][2 * s][3], q1);
+                        if (8 * s + 4 < NIN) pc_split_pair<NPARTS>(act[pt][2 * s + 1][0], act[pt][2 * s + 1][1], q2);
+                        if (8 * s + 6 < NIN) pc_split_pair<NPARTS>(act[pt][2 * s + 1][2], act[pt][2 * s + 1][3], q3);
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) bf[pt][s][k2] = u32x4{q0[k2], q1[k2], q2[k2], q3[k2]};
                         if constexpr (MERGEL) {
@@ -562,8 +620,8 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                         unsigned q0[NPARTS], q1[NPARTS];
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) q0[k2] = q1[k2] = 0u;
-                        if (4 * (KT - 1) + 0 < NIN) split_pair<NPARTS>(act[pt][KT - 1][0], act[pt][KT - 1][1], q0);
-                        if (4 * (KT - 1) + 2 < NIN) split_pair<NPARTS>(act[pt][KT - 1][2], act[pt][KT - 1][3], q1);
+                        if (4 * (KT - 1) + 0 < NIN) pc_split_pair<NPARTS>(act[pt][KT - 1][0], act[pt][KT - 1][1], q0);
+                        if (4 * (KT - 1) + 2 < NIN) pc_split_pair<NPARTS>(act[pt][KT - 1][2], act[pt][KT - 1][3], q1);
 #pragma unroll
                         for (int k2 = 0; k2 < NPARTS; ++k2) hb[pt][k2] = u32x2{q0[k2], q1[k2]};
                     }
@@ -596,7 +654,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                                     if (EXACT || t < to) {
 #pragma unroll
                                         for (int pt = 0; pt < P; ++pt)
-                                            acc[pt][t] = mfma_bf16(wf[t][wa], bf[pt][s][ba], acc[pt][t]);
+                                            acc[pt][t] = pc_mfma(wf[t][wa], bf[pt][s][ba], acc[pt][t]);
                                     }
                             }
                     }
@@ -618,7 +676,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                             for (int t = 0; t < OT; ++t)
 #pragma unroll
                                 for (int pt = 0; pt < P; ++pt)
-                                    acc[pt][t] = mfma_bf16_k16(wh[t][wa], hb[pt][ba], acc[pt][t]);
+                                    acc[pt][t] = pc_mfma_k16(wh[t][wa], hb[pt][ba], acc[pt][t]);
                         }
                 }
 #pragma unroll
@@ -645,7 +703,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     for (int r = 0; r < 4; ++r)
                         if (4 * t + r < (TREST > 0 ? NREST : NLIVE)) s = fmaf(wout[t][r], act[pt][t][r], s);
                 s = group_allreduce(s);
-                const float f = out_act_f(s, m.out_act);
+                const float f = pc_out_act(s, m.out_act);
                 Facc[pt] = fmaf(wk, maybe_inverse(f, a.inv_f), Facc[pt]);
                 if (k == 0) fxv[pt] = f;
                 if (k == n) fx0v[pt] = f;
@@ -681,3 +739,4 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
     if constexpr (!INV) fwd_epilogue<P>(a, lds, Facc, fxv, fx0v, ok, qv, dxv, live, part, ns, wid, g, p);
 }
 
+}  // namespace UMNN_FWD_NS

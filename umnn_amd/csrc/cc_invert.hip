@@ -10,6 +10,7 @@
 // matrix-core arithmetic of the bf16x6 forward mode; there is no fp32-MFMA form of this kernel); wider nets keep the host-driven
 // search on the forward kernels of that mode (8 tiles x 3 pieces do not fit the register file).
 #include "cc_fwd_bf16_kernel.h"
+using namespace UMNN_FWD_NS;
 
 typedef void (*inv_kernel_t)(const FwdBf16Args);
 struct InvVariant { int tmax, exact, nrl, nparts; inv_kernel_t fn; const char* name; };
@@ -45,7 +46,7 @@ extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const f
     if (L < 2) return umnn_fail(UMNN_EUNSUPPORTED, "invert: the matrix-core kernels need at least two hidden layers");
     // fwd_precision = fp32 / bf16x6 ("exact products everywhere"): the three-piece variants, which exist for up to four tiles per
     // layer; wider nets keep the caller's host-driven search on the forward kernels of that mode -- never a silent ~6e-6 search
-    const int nparts = umnn_options().fwd_precision == UMNN_PRECISION_BF16X3 ? 2 : 3;
+    const int nparts = umnn_options().fwd_precision == UMNN_PRECISION_BF16X3 ? 2 : 3;      // (f16x3 counts as an exact-products mode here)
     if (nparts == 3 && tmax > 4)
         return umnn_fail(UMNN_EUNSUPPORTED, "invert: the fp32-level in-kernel search exists for nets of at most four tiles per layer; the forward precision asks for exact products");
     a.x0 = nullptr; a.x = nullptr; a.h = h; a.ccw = cc_w; a.ccs = cc_s;
