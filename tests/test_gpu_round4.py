@@ -194,6 +194,68 @@ def test_fp16_piece_pipeline_falls_back_when_a_piece_overflows(dev):
     assert not torch.equal(c[3], e[3]) and U.scaled_err(c[3].cpu().numpy(), e[3].cpu().numpy()) < 3e-4
 
 
+@pytest.mark.parametrize("hid, with_gfx", [([100, 50, 50, 50, 50], True), ([112, 48, 60, 36, 50], False)])
+def test_fp16_piece_pipeline_as_the_middle_stage_of_the_three_stage_backward(hid, with_gfx, dev):
+    """MNISTExperiment's shape (31-100-50^4-1, d = 784): the middle stage of the three-stage backward (cc_backward_front.hip) on
+    fp16 pieces -- z_2 from HBM into wave Ca, delta_2 un-scaled back to HBM from wave B1, single-chunk calls.  Forced here (the
+    default starts at 2^21 node evaluations); against the bf16 pipeline on the same inputs row by row, and against the exact-fp32
+    kernels; bit-reproducible; the overflow fallback rewrites delta_2 before the front-backward kernel reads it."""
+    import umnn_amd
+    from umnn_amd import _lib
+    from umnn_amd import integral as I
+    from umnn_amd.nets import mlp_spec
+    B, d, E, n = 40, 784, 30, 12
+    torch.manual_seed(11)
+    net = umnn_amd.IntegrandNetwork(d, 1 + E, hid, 1).to(dev)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.mul_(1.5)
+    spec = mlp_spec(net)
+    x, x0 = torch.randn(B, d, device=dev) * 2, torch.randn(B, d, device=dev) * 0.3
+    h, gg = torch.randn(B, E * d, device=dev), torch.randn(B, d, device=dev)
+    gf = torch.randn(B, d, device=dev) if with_gfx else None
+    outs = {}
+    for key, w16, prec in (("bf16", 0, "bf16x3"), ("f16", 2, "bf16x3"), ("fp32", 0, "fp32")):
+        _lib.set_backward_precision(prec)
+        try:
+            with _lib.options(bwd_ws=1, bwd_ws16=w16):
+                outs[key] = I.hip_backward(spec, x0, x, h, gg, gf, n)
+                name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+                if key == "f16":
+                    assert name.startswith("cc_bwd_f16") and "WS,FRONT" in name, name
+                    again = I.hip_backward(spec, x0, x, h, gg, gf, n)
+                    assert all(torch.equal(u, v) for u, v in zip(outs[key], again))
+                elif key == "bf16":
+                    assert name.startswith("cc_bwd_bf16") and "WS,FRONT" in name, name
+        finally:
+            _lib.set_backward_precision("bf16x3")
+    for i, nm in enumerate(("dx0", "dx", "dh", "dtheta")):
+        a_, b_, r_ = (outs[k][i].cpu().numpy() for k in ("bf16", "f16", "fp32"))
+        assert np.isfinite(b_).all(), nm
+        if nm == "dtheta":
+            assert U.scaled_err(b_, a_) < 3e-4 and U.scaled_err(b_, r_) < 3e-4, (U.scaled_err(b_, a_), U.scaled_err(b_, r_))
+        else:
+            # per integral (d_h: [B][E][d]): the median at rounding level, a handful of the 31360 integrals on the other side of a
+            # LeakyReLU kink (the module docstring; each integral decides 13 x 250 of them)
+            per = np.abs(b_ - a_).reshape(B, -1, d).max(axis=1).ravel() / np.abs(a_).max()
+            assert np.median(per) < 5e-6 and (per > 1e-4).sum() <= (0 if nm == "dx0" else 12), (nm, float(np.median(per)), int((per > 1e-4).sum()))
+            assert U.scaled_err(b_, r_) < (3e-3 if nm == "dh" else 2e-4), (nm, U.scaled_err(b_, r_))
+    # overflow in the middle stage: |z_2| ~ 1e5 is beyond the fp16 range
+    net2 = umnn_amd.IntegrandNetwork(d, 1 + E, hid, 1).to(dev)
+    lin = [m for m in net2.net if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        lin[1].weight.mul_(3e4)
+        lin[2].weight.mul_(1e-4)
+    spec2 = mlp_spec(net2)
+    with _lib.options(bwd_ws=1, bwd_ws16=2):
+        a = I.hip_backward(spec2, x0, x, h, gg, gf, n)
+        assert _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode().startswith("cc_bwd_f16")
+    with _lib.options(bwd_ws=1, bwd_ws16=0):
+        b = I.hip_backward(spec2, x0, x, h, gg, gf, n)
+    for u, v in zip(a, b):
+        assert torch.isfinite(u).all() and torch.equal(u, v)
+
+
 def test_fp16_piece_pipeline_scales_tiny_and_huge_cotangents(dev):
     """The cotangent scale is a per-launch power of two: gradients are homogeneous in g to the last bit."""
     import umnn_amd

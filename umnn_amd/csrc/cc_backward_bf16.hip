@@ -38,6 +38,41 @@ static const BwdWsVariant kBwdWs16Variants[] = {
     { 0, cc_bwd_ws16_kernel<0>, "cc_bwd_f16<L=4,LIVE=0,WS>" },
 };
 
+// ---- the fp16 pipeline as the middle stage of the three-stage backward (cc_backward_front.hip calls these three)
+static const BwdWsVariant kBwdWs16FrontVariants[] = {
+    { 13, cc_bwd_ws16_kernel<13, true>, "cc_bwd_f16<L=4,LIVE=13,WS,FRONT>" },
+    { 0, cc_bwd_ws16_kernel<0, true>, "cc_bwd_f16<L=4,LIVE=0,WS,FRONT>" },
+};
+static_assert(offsetof(Ws16Scal, flag) == 3 * sizeof(unsigned), "cc_backward_front.hip addresses the flag as scal + 3");
+// *name = the variant's kernel name if the launch can use it (nullptr otherwise); the size rule is the caller's
+int umnn_ws16_front_eligible(const BwdArgs& base, int nrl, const char** name) {
+    *name = nullptr;
+    if (base.inv_f || !base.scal || base.m.out_act != UMNN_OUT_ELU_PLUS_ONE || base.n + 1 > W16_MAX_NODES) return 0;
+    for (const BwdWsVariant& c : kBwdWs16FrontVariants)
+        if (c.nrl == nrl) {
+            if (int rc = umnn_allow_lds((const void*)c.fn, (size_t)W16_LDS_USHORTS * sizeof(unsigned short))) return rc;
+            *name = c.name;
+            break;
+        }
+    return 0;
+}
+// the launch scalars (cotangent scale) of a call, once, ahead of its stages
+int umnn_ws16_front_prepare(const BwdArgs& base, int nblocks_max, hipStream_t stream) {
+    if (int rc = umnn_check(hipMemsetAsync(base.scal, 0, sizeof(Ws16Scal), stream), "memset launch scalars")) return rc;
+    const long long want = (base.NI + 1023) / 1024;
+    const unsigned nbm = (unsigned)(want < (long long)nblocks_max ? want : (long long)nblocks_max);
+    hipLaunchKernelGGL(cc_bwd_cotmax_kernel, dim3(nbm), dim3(256), 0, stream, base, reinterpret_cast<Ws16Scal*>(base.scal));
+    return 0;
+}
+int umnn_ws16_front_launch(const BwdBf16Args& mid, int nrl, int nblocks, hipStream_t stream) {
+    for (const BwdWsVariant& c : kBwdWs16FrontVariants)
+        if (c.nrl == nrl) {
+            hipLaunchKernelGGL(c.fn, dim3(nblocks), dim3(64 * WS_WAVES), (size_t)W16_LDS_USHORTS * sizeof(unsigned short), stream, mid);
+            return 0;
+        }
+    return UMNN_EUNSUPPORTED;
+}
+
 // Plans and launches the main backward pass with the bf16 kernels.  Returns UMNN_EUNSUPPORTED when the shape is
 // outside this family (caller falls back to the fp32 kernels).
 int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblocks_max, int* nwaves_out,

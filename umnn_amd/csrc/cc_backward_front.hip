@@ -471,6 +471,12 @@ static const MidVariant kMidWsVariants[] = {
     { 4, 13, cc_bwd_ws_kernel<13, true>, "cc_bwd_bf16<L=4,LIVE=13,WS,FRONT>" },
     { 4, 0, cc_bwd_ws_kernel<0, true>, "cc_bwd_bf16<L=4,LIVE=0,WS,FRONT>" },
 };
+// the same on fp16 pieces (cc_bwd_ws16_kernel.h, instantiated in cc_backward_bf16.hip under that file's scheduling flags):
+// single-chunk calls only -- its d_theta slices are written, not accumulated, so that the bf16 pipeline queued behind it as the
+// overflow fallback can rewrite them
+int umnn_ws16_front_eligible(const BwdArgs& base, int nrl, const char** name);
+int umnn_ws16_front_prepare(const BwdArgs& base, int nblocks_max, hipStream_t stream);
+int umnn_ws16_front_launch(const BwdBf16Args& mid, int nrl, int nblocks, hipStream_t stream);
 
 // Does this net belong to the family?  hidden layer 1: 5..8 tiles; hidden layers 2..L: three or four tiles at most (zero-padded
 // to four), 2..4 of them.
@@ -553,6 +559,15 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
     const size_t lds_ws = (size_t)WS_LDS_USHORTS * sizeof(unsigned short);
     if (wv) { if (int rc = umnn_allow_lds((const void*)wv->fn, lds_ws)) return rc; }
     bool used_ws = false;
+    // fp16 pieces for the middle stage: the rule of umnn_launch_backward_bf16 (bwd_ws16 = 1: large launches only; here from 2^21 node
+    // evaluations, the middle stage recomputes one layer less than the whole-net pipeline; 2: whenever eligible), one chunk
+    const char* hv = nullptr;
+    {
+        const int w16 = umnn_options().bwd_ws16;
+        const bool size_ok = w16 == 2 || (w16 == 1 && base.NI * (long long)(n + 1) >= (1LL << 21));
+        if (wv && size_ok && chunk == tiles && tiles >= 4LL * nblocks_max)
+            if (int rc = umnn_ws16_front_eligible(base, nrl, &hv)) return rc;
+    }
 
     FrontArgs fa;
     fa.b = base;
@@ -561,6 +576,7 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
     mid.b.l_lo = 1;
     fa.nl2 = mid.nl2 = nl2;
     umnn_prof_begin(stream);
+    if (hv) { if (int rc = umnn_ws16_front_prepare(base, nblocks_max, stream)) return rc; }
     for (long long t0 = 0; t0 < tiles; t0 += chunk) {
         const long long nt = tiles - t0 < chunk ? tiles - t0 : chunk;
         float* z2 = (float*)scratch;
@@ -572,7 +588,14 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
         fa.z2 = z2; fa.d2 = d2; fa.tz2 = tz2; fa.grp0 = (unsigned)t0; fa.b.ngroups = (unsigned)nt; fa.accumulate = t0 > 0;
         mid.z2 = z2; mid.d2 = d2; mid.tz2 = tz2; mid.grp0 = (unsigned)t0; mid.b.ngroups = (unsigned)nt; mid.accumulate = t0 > 0;
         hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
-        if (wv && nt >= 4LL * nblocks_max) {
+        if (hv) {
+            // (the fp16 pipeline, then the bf16 pipeline behind it that only runs if a piece overflowed: same outputs, rewritten)
+            mid.scal = base.scal; mid.only_if = nullptr;
+            if (int rc = umnn_ws16_front_launch(mid, nrl, nblocks_max, stream)) return rc;
+            mid.only_if = base.scal + 3;                         // (Ws16Scal::flag)
+            hipLaunchKernelGGL(wv->fn, dim3(nblocks_max), dim3(64 * WS_WAVES), lds_ws, stream, mid);
+            used_ws = true;
+        } else if (wv && nt >= 4LL * nblocks_max) {
             hipLaunchKernelGGL(wv->fn, dim3(nblocks_max), dim3(64 * WS_WAVES), lds_ws, stream, mid);
             used_ws = true;
         } else {
@@ -581,6 +604,6 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
         hipLaunchKernelGGL(fv->bwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_c, stream, fa);
     }
     umnn_prof_end(stream, 3.0 * umnn_cc_forward_flops_per_integral(net, n) * (double)base.NI, UMNN_PROF_BACKWARD);
-    umnn_note_launch(used_ws ? wv->name : mv->name);
+    umnn_note_launch(hv ? hv : used_ws ? wv->name : mv->name);
     return umnn_check(hipGetLastError(), "cc_bwd front launch");
 }

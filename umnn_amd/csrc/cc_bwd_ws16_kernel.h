@@ -26,7 +26,10 @@
 // overflowing piece is +-inf, which reaches the output-layer sum of wave F3 (activations) or the dc sum of wave B1 (cotangents)
 // as inf / NaN; both are checked (one compare per step / per tile) and raise a device flag, and the launcher queues the bf16
 // kernel of cc_bwd_ws_kernel.h right behind this one with "run only if the flag is set": same outputs, rewritten.  inv_f launches
-// (cotangent x -1/f^2, unbounded) and the FRONT middle stage stay on the bf16 kernel.
+// (cotangent x -1/f^2, unbounded) stay on the bf16 kernel.
+// FRONT = the middle stage of the three-stage backward (cc_backward_front.hip; MNISTExperiment's 31-100-50^4-1): wave Ca takes
+// z_2 from HBM instead of computing layer 1, wave B1 writes delta_2 (un-scaled) back instead of dc / dW_1; single-chunk calls
+// only, because d_theta slices are written here and the fallback must be able to rewrite them (1.26 -> 1.15 ms per MNIST block).
 #pragma once
 #include "cc_bwd_ws_kernel.h"
 
@@ -264,7 +267,7 @@ __device__ __forceinline__ float ws16_ccs(const unsigned short* lds16, int k) { 
 
 // ============================================================================================================ wave Ca
 // layer 1 (a_1 of a new tile-node per step, two fp16 pieces -> tile A1) and dW_3
-template <int NRL>
+template <int NRL, bool FRONT>
 __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
     constexpr int NPAIR = (NLIVE + 1) / 2;
@@ -288,7 +291,7 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int f = feat_of(t, r, g);
-                w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
+                w1x[t][r] = (!FRONT && f < H1) ? W0[f * (1 + E)] : 0.f;
             }
     }
     ws_f32x16 dW[2][2];
@@ -301,7 +304,30 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
     for (int t = 0; t < BT; ++t) c[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // Opening a tile: x, x0, the tile's 16 x E embedding values from HBM, c = b_1 + W_1[:, 1:] h on the fp32 matrix pipe; all loads
     // of eight K-steps issued before the first product (item_embedding_gemm)
+    // FRONT (middle stage of the three-stage backward, cc_backward_front.hip): "layer 1" is the front kernel's z_2 out of HBM,
+    // [tile][node][register][lane], fetched one element ahead.  zc = the current element's values (the tangent element: d z_2 / d t
+    // at node 0), zn = the next element's, z0 = z_2 of node 0 of the current tile (the tangent element needs its signs).
+    const int nl2 = NRL > 0 ? NRL : args.nl2;
+    float zc[BT][4], zn[BT][4], z0[BT][4];
+#pragma unroll
+    for (int t = 0; t < BT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { zc[t][r] = 0.f; zn[t][r] = 0.f; z0[t][r] = 0.f; }
+    auto fetch_z = [&](const WsCursor& c2, float (&dst)[BT][4]) __attribute__((always_inline)) {
+        const size_t tile0 = (size_t)ws_grp(c2) * (size_t)(a.n + 1) * nl2 * 64 + lane;
+        const bool tan = ws_is_tan(sh, c2);
+        const size_t base = tan ? (size_t)ws_grp(c2) * nl2 * 64 + lane : tile0 + (size_t)ws_node(sh, c2) * nl2 * 64;
+        const float* __restrict__ src = tan ? args.tz2 : args.z2;
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 4 * t + r, jj = j < nl2 ? j : nl2 - 1;       // (unconditional loads: index clamped, value masked)
+                if (j < NLIVE) { const float v = src[base + (size_t)jj * 64]; dst[t][r] = j < nl2 ? v : 0.f; }
+            }
+    };
     auto new_item = [&]() __attribute__((always_inline)) {
+        if constexpr (FRONT) return;
         const long long q0 = (long long)(args.grp0 + ws_grp(cu)) * 16 + p;
         const long long qq = q0 < a.NI ? q0 : a.NI - 1;
         xv = io_ld(a.x, qq, a.x_bf16);
@@ -320,6 +346,7 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
         item_embedding_gemm<BT, 8>(hb, m.W[0], H1, E, d, g, p, c);
     };
     if (nit > 0) new_item();
+    if constexpr (FRONT) { if (nit > 0) fetch_z(cu, zc); }
 
     float actF[BT][4];
     unsigned qF[8][W16_NP];
@@ -337,7 +364,7 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
     bool live = cu.j < nit;
     bool is_tan = live && ws_is_tan(sh, cu);
     float tk = 0.f;
-    {
+    if constexpr (!FRONT) {
         const int k = ws_node(sh, cu);
         const float uu = ws16_ccs(lds16, k) + 1.f;
         tk = (k == 0) ? xv : __fadd_rn(x0v, __fmul_rn(dxv, uu) * 0.5f);
@@ -352,6 +379,15 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
         const WsCursor nx = live ? ws_next(sh, cu) : cu;
         const int kn = ws_node(sh, nx);
         const float ccs_n = ws16_ccs(lds16, kn);
+        if constexpr (FRONT) {
+            if (live && cu.e == 0) {
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z0[t][r] = zc[t][r];
+            }
+            if (live && nx.j < nit) fetch_z(nx, zn);
+        }
         const unsigned short* D4 = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + trb;
         unsigned short* const O1 = lds16 + WS_OFF_A1 + rO1 + own;
         // operands of dW_3: the a_3 half came in before the barrier, the delta_4 half (written last step) here
@@ -361,9 +397,14 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
             constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
             constexpr bool TAN = decltype(tanc)::value;
             if constexpr (e < NLIVE) {
-                const float z = fmaf(w1x[t][r], tk, c[t][r]);
-                if constexpr (TAN) actF[t][r] = w1x[t][r] * (z > 0.f ? 1.f : slope);
-                else actF[t][r] = hidden_act_f(z, slope);
+                if constexpr (FRONT) {
+                    if constexpr (TAN) actF[t][r] = zc[t][r] * (z0[t][r] > 0.f ? 1.f : slope);
+                    else actF[t][r] = hidden_act_f(zc[t][r], slope);
+                } else {
+                    const float z = fmaf(w1x[t][r], tk, c[t][r]);
+                    if constexpr (TAN) actF[t][r] = w1x[t][r] * (z > 0.f ? 1.f : slope);
+                    else actF[t][r] = hidden_act_f(z, slope);
+                }
             }
         };
         auto pairF = [&](auto jc, auto stc) __attribute__((always_inline)) {
@@ -399,8 +440,15 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
             live = cu.j < nit;
             if (crossed && live) new_item();
             is_tan = live && ws_is_tan(sh, cu);
-            const float uu = ccs_n + 1.f;
-            tk = (kn == 0) ? xv : __fadd_rn(x0v, __fmul_rn(dxv, uu) * 0.5f);
+            if constexpr (FRONT) {
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zc[t][r] = zn[t][r];
+            } else {
+                const float uu = ccs_n + 1.f;
+                tk = (kn == 0) ? xv : __fadd_rn(x0v, __fmul_rn(dxv, uu) * 0.5f);
+            }
         }
         ws_adv<WS_NS3, WS_TILE>(rA3); ws_adv<2, WS_TILE>(rD4);
         ws_adv<WS_NS1, WS_TILE>(rO1);
@@ -835,7 +883,7 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
 // ============================================================================================================ waves B1..B3
 // W_l^T (two fp16 pieces, 64 registers): per step 24 MFMAs, then delta_l = (W_l^T delta_{l+1}) . act'(a_l), split, stored for the
 // next wave down.  B1 ends in the tail (dc, dW1[:,0]), un-scaled on the way out.
-template <int NRL, int LAYER>
+template <int NRL, int LAYER, bool FRONT>
 __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
     constexpr int DB = 11 - LAYER;                     // element s - DB: W_l^T GEMM, then its vector work, in the same step
@@ -868,7 +916,7 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
     WsCursor cb{0, 0};
     float xvB = 0.f, x0vB = 0.f, dxvB = 0.f;
     auto new_item_B = [&]() __attribute__((always_inline)) {
-        if constexpr (IS_TAIL) {
+        if constexpr (IS_TAIL && !FRONT) {
             const long long q = (long long)(args.grp0 + ws_grp(cb)) * 16 + p;
             const long long qq = q < a.NI ? q : a.NI - 1;
             xvB = io_ld(a.x, qq, a.x_bf16);
@@ -881,7 +929,7 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
     WS_TIMING_DECL;
     int rAsg = ws_ring0<ws_a_ns(LAYER), WS_TILE>(DB), rDin = ws_ring0<2, WS_TILE>(DB), rDout = ws_ring0<2, WS_TILE>(DB);
     float tkB = 0.f;
-    if constexpr (IS_TAIL) {
+    if constexpr (IS_TAIL && !FRONT) {
         const int kB = ws_node(sh, cb);
         const float uu = ws16_ccs(lds16, kB) + 1.f;
         tkB = (kB == 0) ? xvB : __fadd_rn(x0vB, __fmul_rn(dxvB, uu) * 0.5f);
@@ -932,7 +980,7 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
             for (int r = 0; r < 4; ++r) {
                 if (4 * t + r < NLIVE) {
                     dl[t][r] = nd[t][r] * act_grad_q(sg, t, r, slope);
-                    if constexpr (IS_TAIL) {
+                    if constexpr (IS_TAIL && !FRONT) {
                         dcs[t][r] += dl[t][r];
                         dW1x[t][r] = fmaf(dl[t][r], tkB, dW1x[t][r]);
                     }
@@ -948,7 +996,23 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
 #pragma unroll
                 for (int k2 = 0; k2 < W16_NP; ++k2) *reinterpret_cast<u32x4*>(Dout + k2 * 16 * TRS + s2 * 8) = q.v[s2][k2];
         }
-        if constexpr (IS_TAIL) {
+        if constexpr (IS_TAIL && FRONT) {
+            // middle stage: delta_2 = dL/dz_2 of this node goes back to HBM for the front-backward kernel (not for the tangent
+            // element), un-scaled; a non-finite value (an overflowed cotangent piece) raises the flag
+            if (liveB && !ws_is_tan(sh, cb)) {
+                const int nl2 = NRL > 0 ? NRL : args.nl2;
+                const size_t base = ((size_t)ws_grp(cb) * (size_t)(a.n + 1) + (size_t)ws_node(sh, cb)) * nl2 * 64 + lane;
+                float chk = 0.f;
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * t + r < NLIVE && 4 * t + r < nl2) { args.d2[base + (size_t)(4 * t + r) * 64] = dl[t][r] * inv_sigma; chk = fmaf(dl[t][r], 0.f, chk); }
+                bad = bad || !(chk == 0.f);
+            }
+            if (liveB) cb = nxB;
+        }
+        if constexpr (IS_TAIL && !FRONT) {
             if (liveB && cb.e == sh.ne - 1) {
                 const long long q = (long long)(args.grp0 + ws_grp(cb)) * 16 + p;
                 float chk = 0.f;
@@ -984,7 +1048,10 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
         WS_TIMING_ACC(t0, t1, t2, t3);
     }
     WS_TIMING_OUT(S);
-    if constexpr (IS_TAIL) {
+    if constexpr (IS_TAIL && FRONT) {
+        if (__any(bad) && lane == 0) atomicOr(&reinterpret_cast<Ws16Scal*>(args.scal)->flag, 1u);
+    }
+    if constexpr (IS_TAIL && !FRONT) {
 #pragma unroll
         for (int t = 0; t < BT; ++t)
 #pragma unroll
@@ -1000,7 +1067,7 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
 }
 
 // wave -> role.  Waves w and w + 4 share a SIMD: Ca + Cb, F1 + B1, F2 + B2, F3 + B3.
-template <int NRL>
+template <int NRL, bool FRONT = false>
 __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws16_kernel(const BwdBf16Args args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
@@ -1027,16 +1094,18 @@ __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws16_kernel(const Bwd
     sh.ne = a.n + 1 + sh.tan0;
     sh.nit = blockIdx.x < a.ngroups ? (int)((a.ngroups - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
     const int S = sh.nit * sh.ne + WS_DEPTH;
-    float* part = a.partials + (size_t)blockIdx.x * a.n_params;          // one d_theta slice per workgroup
+    // one d_theta slice per workgroup (as the middle stage of the three-stage backward: the first of the workgroup's four -- the
+    // front kernels use all four; single-chunk launches only, so every slice entry is written, never accumulated)
+    float* part = a.partials + (size_t)blockIdx.x * (FRONT ? UMNN_WAVES_PER_BLOCK : 1) * a.n_params;
     if (!upper) {
-        if (role == 0) ws16_role_Ca<NRL>(args, lds16, S, sh, part);
+        if (role == 0) ws16_role_Ca<NRL, FRONT>(args, lds16, S, sh, part);
         else if (role == 1) ws16_role_F<NRL, 1>(args, lds16, S, sh, part);
         else if (role == 2) ws16_role_F<NRL, 2>(args, lds16, S, sh, part);
         else ws16_role_F<NRL, 3>(args, lds16, S, sh, part);
     } else {
         if (role == 0) ws16_role_Cb<NRL>(args, lds16, S, sh, part);
-        else if (role == 1) ws16_role_B<NRL, 1>(args, lds16, S, sh, part);
-        else if (role == 2) ws16_role_B<NRL, 2>(args, lds16, S, sh, part);
-        else ws16_role_B<NRL, 3>(args, lds16, S, sh, part);
+        else if (role == 1) ws16_role_B<NRL, 1, FRONT>(args, lds16, S, sh, part);
+        else if (role == 2) ws16_role_B<NRL, 2, FRONT>(args, lds16, S, sh, part);
+        else ws16_role_B<NRL, 3, FRONT>(args, lds16, S, sh, part);
     }
 }
