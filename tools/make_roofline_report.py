@@ -105,8 +105,9 @@ for tag, title in (("bsds300", "C3 BSDS300-shaped eval (8192 x 63 integrals per 
     if tag.endswith("_train"):
         if tag.startswith("mnist"):     # three kernels per chunk share the backward's work: report each with its own counters
             for part, ttl in (("cc_front_fwd_kernel", "stage A: front forward (a1, z2 -> HBM)"),
-                              ("cc_bwd_ws_kernel" if any("cc_bwd_ws_kernel" in r["Name"] for r in stats) else "cc_bwd_bf16_kernel",
-                               "stage B: flagship kernel on the net from hidden layer 2 on (FRONT; since round 3 the workgroup pipeline)"),
+                              (next((k for k in ("cc_bwd_ws16_kernel", "cc_bwd_ws_kernel") if any(k in r["Name"] for r in stats)), "cc_bwd_bf16_kernel"),
+                               "stage B: flagship kernel on the net from hidden layer 2 on (FRONT; the workgroup pipeline, round 4: on fp16 pieces -- "
+                               "the cc_bwd_ws_kernel launches next to it are the queued overflow fallback returning at once)"),
                               ("cc_front_bwd_kernel", "stage C: front backward (dG1, delta_1)")):
                 e = kernel_entry(stats, pmc, part, fl)
                 e["algorithmic_flops_per_launch"] = None
@@ -115,7 +116,8 @@ for tag, title in (("bsds300", "C3 BSDS300-shaped eval (8192 x 63 integrals per 
                 lines += [r for r in rows if "algorithmic FLOPs" not in r]
         else:
             # (round 3: the software-pipelined loop is its own kernel symbol; older profiles have cc_bwd_bf16_kernel)
-            name = next((k for k in ("cc_bwd_ws_kernel", "cc_bwd_swp_kernel") if any(k in r["Name"] for r in stats)), "cc_bwd_bf16_kernel")
+            # (round 4: cc_bwd_ws16_kernel, with the bf16 cc_bwd_ws_kernel queued behind it as the overflow fallback that returns at once)
+            name = next((k for k in ("cc_bwd_ws16_kernel", "cc_bwd_ws_kernel", "cc_bwd_swp_kernel") if any(k in r["Name"] for r in stats)), "cc_bwd_bf16_kernel")
             e = kernel_entry(stats, pmc, name, 3 * fl)
             report[tag]["backward"] = e
             lines += table("backward quadrature kernel (algorithmic FLOPs = 3 x forward: two gradient GEMMs per forward GEMM + the recompute)", e)
