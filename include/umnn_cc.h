@@ -203,7 +203,7 @@ int umnn_get_forward_precision(void);
  * such a net are zero-padded to four 16-feature tiles); other shapes always run the fp32 kernels. */
 /* Which kernel family umnn_cc_backward would run for this net: 1 shape-exact kernels (one pass; or, for a first hidden layer
  * of 5..8 sixteen-feature tiles over 2..4 narrower ones such as MNISTExperiment's 100-50-50-50-50, the three-stage kernels
- * of cc_backward_front.hip, bf16x3 arithmetic only; or, for unequal hidden widths of 64..127, the shape-exact fp32 kernels of
+ * of cc_backward_front.hip -- under UMNN_PRECISION_FP32 their build with six bf16 cross terms in every product, fp32-level; or, for unequal hidden widths of 64..127, the shape-exact fp32 kernels of
  * the 5- / 7- / 8-tile family that holds the widest layer, the narrower layers zero-padded virtually), 0 generic kernels with
  * at most four tiles per layer, -1 generic kernels with more tiles (deep wide nets whose zero-padded weight images exceed the
  * LDS: they spill registers and are ~100x slower -- the shipped host code sends such nets to the materialised ATen chain on the

@@ -66,9 +66,15 @@ def test_inverse_integrand_backward_matches_golden(name, dev, bwd_precision):
     out.backward(t(G["g"], dev))
     torch.cuda.synchronize()
     from umnn_amd.nets import mlp_spec
-    if I._hip_backward_ok(mlp_spec(net), x, h):      # (fp32 mode sends the 100-50-50-50-50 net's gradient to the ATen chain by policy)
-        assert umnn_amd.path_taken() == "hip" and _lib.lib().umnn_launch_count() >= before + 3
-        assert "cc_bwd" in _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+    # (round 4: every fixture's net has HIP kernels in both modes -- fp32 mode runs the 100-50-50-50-50 net on the six-term build
+    # of the three-stage kernels, cc_backward_front_p3.hip)
+    assert I._hip_backward_ok(mlp_spec(net), x, h)
+    assert umnn_amd.path_taken() == "hip" and umnn_amd.backward_path_taken() == "hip"
+    assert _lib.lib().umnn_launch_count() >= before + 3
+    kname = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+    assert "cc_bwd" in kname
+    if "mnist" in name:
+        assert "FRONT" in kname and kname.startswith("cc_bwd_bf16x6" if bwd_precision == "fp32" else "cc_bwd_bf16<"), kname
     dth = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
     assert U.rel_err(out.detach().cpu().numpy(), G["F_inv"]) < TOL
     assert U.rel_err(x0.grad.cpu().numpy(), G["dx0"]) < TOL and U.rel_err(x.grad.cpu().numpy(), G["dx"]) < TOL
@@ -291,7 +297,8 @@ def test_mixed_wide_nets_backward_routes_match_the_oracle(hid, dev, monkeypatch,
     g = torch.randn(B, d, device=dev)
     ref = O.integrate_backward(onet, x0.cpu().numpy(), x.cpu().numpy(), h.cpu().numpy(), n, g.cpu().numpy())
     ref_dh, ref_dtheta = ref[2], ref[5]
-    staged = bwd_precision == "bf16x3" and hid[0] > 63 and max(hid[1:]) <= 63
+    # (three-stage kernels: both precisions since round 4 -- fp32 mode runs their six-term build, cc_backward_front_p3.hip)
+    staged = hid[0] > 63 and max(hid[1:]) <= 63
     # zero-padded onto the 5- / 7- / 8-tile shape-exact fp32 family (pad_to_exact_family) -- where the padded weight images fit
     # the LDS: the four- and five-hidden-layer nets of this list do not (3 x 68 KB, 4 x 45 KB) and keep the ATen chain
     padded = not staged and len(hid) <= 3
@@ -312,7 +319,8 @@ def test_mixed_wide_nets_backward_routes_match_the_oracle(hid, dev, monkeypatch,
             name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
             assert "KS=17" in name or "KS=26" in name or "KS=32" in name, name
         if staged:
-            assert "FRONT" in _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+            name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+            assert "FRONT" in name and name.startswith("cc_bwd_bf16x6" if bwd_precision == "fp32" else "cc_bwd_bf16<"), name
         dtheta = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
         assert np.abs(dtheta - ref_dtheta).max() <= 1e-4 * np.abs(ref_dtheta).max()
         assert np.abs(hr.grad.cpu().numpy() - ref_dh).max() <= 1e-4 * np.abs(ref_dh).max()

@@ -244,8 +244,8 @@ def test_fp16_piece_pipeline_as_the_middle_stage_of_the_three_stage_backward(hid
     net2 = umnn_amd.IntegrandNetwork(d, 1 + E, hid, 1).to(dev)
     lin = [m for m in net2.net if isinstance(m, torch.nn.Linear)]
     with torch.no_grad():
-        lin[1].weight.mul_(3e4)
-        lin[2].weight.mul_(1e-4)
+        lin[1].weight.mul_(3e5)
+        lin[2].weight.mul_(1e-5)
     spec2 = mlp_spec(net2)
     with _lib.options(bwd_ws=1, bwd_ws16=2):
         a = I.hip_backward(spec2, x0, x, h, gg, gf, n)
@@ -254,6 +254,69 @@ def test_fp16_piece_pipeline_as_the_middle_stage_of_the_three_stage_backward(hid
         b = I.hip_backward(spec2, x0, x, h, gg, gf, n)
     for u, v in zip(a, b):
         assert torch.isfinite(u).all() and torch.equal(u, v)
+
+
+@pytest.mark.parametrize("hid, with_gfx, n", [([100, 50, 50, 50, 50], True, 12), ([112, 48, 60, 36], False, 9), ([96, 50, 50], True, 6)])
+def test_three_stage_backward_under_fp32_precision_is_the_six_term_build(hid, with_gfx, n, dev):
+    """set_backward_precision('fp32') keeps nets with a wide first hidden layer on HIP kernels -- the three-stage
+    backward compiled with three bf16 pieces / six cross terms in every product (cc_backward_front_p3.hip) -- instead of leaving
+    the library for an ATen chain.  Against the oracle in float64 on a few rows, against the default (three-term) build, chunked
+    (a small scratch) against un-chunked, and through autograd with backward_path_taken() == 'hip'."""
+    import umnn_amd
+    from umnn_amd import _lib
+    from umnn_amd import integral as I
+    from umnn_amd.nets import mlp_spec
+    B, d, E = 24, 37, 30
+    torch.manual_seed(7 + len(hid))
+    net = umnn_amd.IntegrandNetwork(d, 1 + E, hid, 1)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.mul_(1.4)
+    lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    onet = O.Net([m.weight.detach().numpy() for m in lin], [m.bias.detach().numpy() for m in lin], O.LEAKY, O.ELU1)
+    net.to(dev)
+    spec = mlp_spec(net)
+    x, x0 = torch.randn(B, d) * 2, torch.randn(B, d) * 0.3
+    h, gg = torch.randn(B, E * d), torch.randn(B, d)
+    gf = torch.randn(B, d) if with_gfx else None
+    args = (spec, x0.to(dev), x.to(dev), h.to(dev), gg.to(dev), None if gf is None else gf.to(dev), n)
+    outs = {}
+    for prec in ("bf16x3", "fp32"):
+        _lib.set_backward_precision(prec)
+        try:
+            I._bwd_kind.clear()
+            assert I._hip_backward_ok(spec, args[2], args[3])
+            outs[prec] = I.hip_backward(*args)
+            name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+            assert "FRONT" in name and name.startswith("cc_bwd_bf16x6" if prec == "fp32" else "cc_bwd_bf16<"), name
+            again = I.hip_backward(*args)
+            assert all(torch.equal(u, v) for u, v in zip(outs[prec], again))
+        finally:
+            _lib.set_backward_precision("bf16x3")
+    ref = _oracle_backward_chunked(onet, x0.numpy(), x.numpy(), h.numpy(), n, gg.numpy(), None if gf is None else gf.numpy(), chunk=8)
+    margins = U.kink_margin_rows(onet, x0.numpy(), x.numpy(), h.numpy(), n)
+    for i, nm in enumerate(("dx0", "dx", "dh", "dtheta")):
+        a_, b_ = outs["bf16x3"][i].cpu().numpy(), outs["fp32"][i].cpu().numpy()
+        assert np.isfinite(b_).all(), nm
+        if nm in ("dx", "dh"):
+            _rows_agree_or_sit_on_a_kink(b_, ref[i], onet, x0.numpy(), x.numpy(), h.numpy(), n, 1e-6, 2, nm)
+        else:
+            assert U.scaled_err(b_, ref[i]) < (TOL if margins.min() > 1e-6 or nm == "dx0" else 5e-4), (nm, U.scaled_err(b_, ref[i]))
+        assert U.scaled_err(b_, a_) < (3e-3 if nm == "dh" else 3e-4), (nm, U.scaled_err(b_, a_))
+    # through autograd, fp32 mode: the HIP path, announced by nothing
+    import warnings
+    _lib.set_backward_precision("fp32")
+    try:
+        xs = args[2].clone().requires_grad_()
+        hs = args[3].clone().requires_grad_()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            F = umnn_amd.ParallelNeuralIntegral.apply(args[1], xs, net, umnn_amd.flow._flatten(net.parameters()), hs, n)
+            F.backward(args[4])
+        assert umnn_amd.backward_path_taken() == "hip"
+        assert U.scaled_err(hs.grad.cpu().numpy(), outs["fp32"][2].cpu().numpy()) < 1e-6 or gf is not None
+    finally:
+        _lib.set_backward_precision("bf16x3")
 
 
 def test_fp16_piece_pipeline_scales_tiny_and_huge_cotangents(dev):

@@ -715,7 +715,7 @@ static int plan_backward_impl(const umnn_mlp* net, long long B, int d, int E, Bw
     BwdArgs& a = pl->a;
     const int L = a.m.n_linear - 1;
     // (the three-stage kernels of cc_backward_front.hip take their shape first: they read the unpadded tile counts)
-    const bool front = umnn_options().bwd_precision == UMNN_PRECISION_BF16X3 && umnn_backward_front_shape(a.m);
+    const bool front = umnn_backward_front_shape(a.m);
     *padded = (!front && allow_pad) ? pad_to_exact_family(a.m, &tmax, &ksu) : 0;
     pl->tmax = pick_tmax_bwd(tmax, ksu);
     pl->ksu = (ksu && tmax == pl->tmax) ? ksu : 0;
@@ -770,8 +770,7 @@ static int plan_backward_impl(const umnn_mlp* net, long long B, int d, int E, Bw
     pl->ws_p0 = o; o += (long long)pl->nparts0 * H1 * (E + 1) * 4; o = (o + 255) & ~255LL;
     pl->ws_scal = o; o += 256;
     pl->ws_front = o;
-    // (only the bf16x3 staged kernels use it: under bwd_precision = fp32 the reservation would be a dead 2 GiB per call)
-    pl->ws_front_bytes = (umnn_options().bwd_precision == UMNN_PRECISION_BF16X3 && umnn_backward_front_shape(a.m) && pl->wpb == 4)
+    pl->ws_front_bytes = (umnn_backward_front_shape(a.m) && pl->wpb == 4)
                              ? umnn_backward_front_scratch_bytes(a.m, a.NI) : 0;
     o += pl->ws_front_bytes; o = (o + 255) & ~255LL;
     pl->ws_total = o;
@@ -799,8 +798,8 @@ extern "C" int umnn_cc_backward_kind(const umnn_mlp* net, int E) {
     int tmax = 0, ksu = 0;
     if (int rc = umnn_prepare_mlp(net, E, &m, &tmax, &ksu)) return rc < -1 ? rc : -2;
     // wide first hidden layer + narrow rest (MNISTExperiment's 100-50-50-50-50): the three-stage kernels of
-    // cc_backward_front.hip (bf16 arithmetic only)
-    if (umnn_backward_front_shape(m) && umnn_options().bwd_precision == UMNN_PRECISION_BF16X3) return 1;
+    // cc_backward_front.hip (bwd_precision = fp32: their six-term build, cc_backward_front_p3.hip)
+    if (umnn_backward_front_shape(m)) return 1;
     {   // unequal widths of 5..8 tiles run zero-padded on a shape-exact family, if the padded weight images fit the LDS
         BwdPlan pl;
         int padded = 0;
@@ -860,9 +859,11 @@ extern "C" int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const
     bool done = false;
     int ns_used = pl.ns > nb_steps + 1 ? nb_steps + 1 : pl.ns;
     a.ns = ns_used;
-    if (umnn_options().bwd_precision == UMNN_PRECISION_BF16X3 && pl.ws_front_bytes > 0) {
+    if (pl.ws_front_bytes > 0) {
         a.ns = 1;
-        const int rc = umnn_launch_backward_front(a, net, pl.nblocks, ws + pl.ws_front, pl.ws_front_bytes, stream);
+        const int rc = umnn_options().bwd_precision == UMNN_PRECISION_BF16X3
+                           ? umnn_launch_backward_front(a, net, pl.nblocks, ws + pl.ws_front, pl.ws_front_bytes, stream)
+                           : umnn_launch_backward_front_p3(a, net, pl.nblocks, ws + pl.ws_front, pl.ws_front_bytes, stream);
         if (rc == 0) { done = true; ns_used = 1; }
         else if (rc != UMNN_EUNSUPPORTED) return rc;
         else a.ns = ns_used;

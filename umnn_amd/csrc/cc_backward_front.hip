@@ -22,9 +22,16 @@
 // Scratch: 2 x (n+1) x ceil((H2+1)/4) x 256 B per tile (339 KB at n = 50); tiles are processed in chunks that fit the
 // scratch the workspace provides (2 GiB), every wave's d_theta slice accumulating across chunks.  HBM traffic per
 // tile-node 4 x 3.3 KB against ~5 us of matrix work: three orders of magnitude below the bandwidth roof.
+//
+// This file builds twice: as it is (two bf16 pieces in the delta chain and the dW products: bwd_precision = bf16x3), and through
+// cc_backward_front_p3.hip with UMNN_BWD_NPB = 3 (three pieces / six cross terms everywhere: fp32-level, what bwd_precision = fp32
+// gets for this family -- no workgroup pipeline there, the one-pass middle kernel).
 #include "cc_bwd_bf16_kernel.h"
+#if UMNN_BWD_NPB == 2
 #include "cc_bwd_ws_kernel.h"
+#endif
 
+namespace UMNN_BWD_NS {
 struct FrontArgs {
     BwdArgs b;              // the FULL net
     float* z2;
@@ -452,6 +459,8 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
         }
 }
 
+}  // namespace UMNN_BWD_NS
+
 // ------------------------------------------------------------------------------------------ host side
 typedef void (*front_kernel_t)(const FrontArgs);
 typedef void (*mid_kernel_t)(const BwdBf16Args);
@@ -462,15 +471,21 @@ static const FrontVariant kFrontVariants[] = {
     FRONT_VARIANT(5, 0), FRONT_VARIANT(6, 0), FRONT_VARIANT(7, 0), FRONT_VARIANT(8, 0),
 };
 struct MidVariant { int lh, nrl; mid_kernel_t fn; const char* name; };
+#if UMNN_BWD_NPB == 2
 #define MID_VARIANT(LHH, NR) { LHH, NR, cc_bwd_bf16_kernel<LHH, true, NR, true>, "cc_bwd_bf16<L=" #LHH ",EDGE=1,LIVE=" #NR ",FRONT>" }
+#else
+#define MID_VARIANT(LHH, NR) { LHH, NR, cc_bwd_bf16_kernel<LHH, true, NR, true>, "cc_bwd_bf16x6<L=" #LHH ",EDGE=1,LIVE=" #NR ",FRONT>" }
+#endif
 static const MidVariant kMidVariants[] = { MID_VARIANT(4, 13), MID_VARIANT(3, 13), MID_VARIANT(2, 13),
                                            MID_VARIANT(4, 0), MID_VARIANT(3, 0), MID_VARIANT(2, 0) };
 // the middle stage as a weight-stationary workgroup pipeline (cc_bwd_ws_kernel.h): four hidden layers after the cut, chunks
 // of at least four tiles per workgroup
+#if UMNN_BWD_NPB == 2
 static const MidVariant kMidWsVariants[] = {
     { 4, 13, cc_bwd_ws_kernel<13, true>, "cc_bwd_bf16<L=4,LIVE=13,WS,FRONT>" },
     { 4, 0, cc_bwd_ws_kernel<0, true>, "cc_bwd_bf16<L=4,LIVE=0,WS,FRONT>" },
 };
+#endif
 // the same on fp16 pieces (cc_bwd_ws16_kernel.h, instantiated in cc_backward_bf16.hip under that file's scheduling flags):
 // single-chunk calls only -- its d_theta slices are written, not accumulated, so that the bf16 pipeline queued behind it as the
 // overflow fallback can rewrite them
@@ -480,6 +495,7 @@ int umnn_ws16_front_launch(const BwdBf16Args& mid, int nrl, int nblocks, hipStre
 
 // Does this net belong to the family?  hidden layer 1: 5..8 tiles; hidden layers 2..L: three or four tiles at most (zero-padded
 // to four), 2..4 of them.
+#if UMNN_BWD_NPB == 2
 int umnn_backward_front_shape(const MlpDev& m) {
     const int L = m.n_linear - 1;
     if (L < 3 || L > 5) return 0;
@@ -497,9 +513,14 @@ long long umnn_backward_front_scratch_bytes(const MlpDev& m, long long NI) {
     const long long want = tiles * per_tile, cap = 2LL << 30;
     return want < cap ? want : cap;
 }
+#define UMNN_FRONT_LAUNCH umnn_launch_backward_front
+#else
+int umnn_backward_front_shape(const MlpDev& m);
+#define UMNN_FRONT_LAUNCH umnn_launch_backward_front_p3
+#endif
 
 // Runs the three stages chunk by chunk.  `base` is the fully populated BwdArgs of umnn_cc_backward (partials zeroed).
-int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nblocks_max, void* scratch, long long scratch_bytes,
+int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max, void* scratch, long long scratch_bytes,
                                hipStream_t stream) {
     const MlpDev& m = base.m;
     const int L = m.n_linear - 1, n = base.n;
@@ -545,7 +566,12 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
     for (int l = 1; l < LH; ++l) { mid.off_fwd[l] = off16; off16 += BT * BKS * NPF * FRAG; }
     for (int l = 1; l < LH; ++l) { mid.off_tr[l] = off16; off16 += BT * BKS * NPB * FRAG; }
     mid.off_trtile = off16;
-    off16 += UMNN_WAVES_PER_BLOCK * NPB * 16 * TRS;
+    // (waves per workgroup of the one-pass middle kernel: four, or as many as leave room for their transpose tiles next to the weight
+    // images -- the six-term build with four hidden layers after the cut holds two; the grid grows by the same factor, so the
+    // d_theta slices stay one per wave of the plan)
+    int wpb_mid = UMNN_WAVES_PER_BLOCK;
+    while (wpb_mid > 1 && (size_t)(off16 + wpb_mid * NPB * 16 * TRS) * sizeof(unsigned short) > 160 * 1024) wpb_mid >>= 1;
+    off16 += wpb_mid * NPB * 16 * TRS;
     const size_t lds_mid = (size_t)off16 * sizeof(unsigned short);
     const size_t lds_a = ((size_t)BT * (T1 / 2) * NPF * FRAG + (T1 & 1 ? BT * NPF * 256 : 0)) * sizeof(unsigned short);
     const size_t lds_c = (size_t)T1 * BKS * NPB * FRAG * sizeof(unsigned short);
@@ -554,10 +580,13 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
     if (int rc = umnn_allow_lds((const void*)mv->fn, lds_mid)) return rc;
     if (int rc = umnn_allow_lds((const void*)fv->bwd, lds_c)) return rc;
     const MidVariant* wv = nullptr;
+    size_t lds_ws = 0;
+#if UMNN_BWD_NPB == 2
     if (umnn_options().bwd_ws && LH == 4)
         for (const MidVariant& v : kMidWsVariants) if (v.nrl == nrl) { wv = &v; break; }
-    const size_t lds_ws = (size_t)WS_LDS_USHORTS * sizeof(unsigned short);
+    lds_ws = (size_t)WS_LDS_USHORTS * sizeof(unsigned short);
     if (wv) { if (int rc = umnn_allow_lds((const void*)wv->fn, lds_ws)) return rc; }
+#endif
     bool used_ws = false;
     // fp16 pieces for the middle stage: the rule of umnn_launch_backward_bf16 (bwd_ws16 = 1: large launches only; here from 2^21 node
     // evaluations, the middle stage recomputes one layer less than the whole-net pipeline; 2: whenever eligible), one chunk
@@ -588,6 +617,7 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
         fa.z2 = z2; fa.d2 = d2; fa.tz2 = tz2; fa.grp0 = (unsigned)t0; fa.b.ngroups = (unsigned)nt; fa.accumulate = t0 > 0;
         mid.z2 = z2; mid.d2 = d2; mid.tz2 = tz2; mid.grp0 = (unsigned)t0; mid.b.ngroups = (unsigned)nt; mid.accumulate = t0 > 0;
         hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
+#if UMNN_BWD_NPB == 2
         if (hv) {
             // (the fp16 pipeline, then the bf16 pipeline behind it that only runs if a piece overflowed: same outputs, rewritten)
             mid.scal = base.scal; mid.only_if = nullptr;
@@ -598,8 +628,10 @@ int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nbl
         } else if (wv && nt >= 4LL * nblocks_max) {
             hipLaunchKernelGGL(wv->fn, dim3(nblocks_max), dim3(64 * WS_WAVES), lds_ws, stream, mid);
             used_ws = true;
-        } else {
-            hipLaunchKernelGGL(mv->fn, dim3(nblocks), dim3(UMNN_BLOCK), lds_mid, stream, mid);
+        } else
+#endif
+        {
+            hipLaunchKernelGGL(mv->fn, dim3(nblocks * (UMNN_WAVES_PER_BLOCK / wpb_mid)), dim3(64 * wpb_mid), lds_mid, stream, mid);
         }
         hipLaunchKernelGGL(fv->bwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_c, stream, fa);
     }

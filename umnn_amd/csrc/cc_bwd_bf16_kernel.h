@@ -23,8 +23,20 @@
 constexpr int BT = 4;            // tiles of 16 features per hidden layer
 constexpr int BKS = 2;           // K-steps of 32 features
 constexpr int FRAG = 512;        // ushorts per fragment (64 lanes x 8)
-constexpr int NPF = 3;           // bf16 pieces in the forward recompute (6 cross terms)
-constexpr int NPB = 2;           // bf16 pieces in the delta chain and the dW product (3 cross terms)
+// Pieces of the delta chain and the dW products: 2 (three cross terms, the default) or, for translation units built with
+// -DUMNN_BWD_NPB=3 / a wrapper that defines it (cc_backward_front_p3.hip: the three-stage backward under bwd_precision = fp32),
+// 3 (six cross terms, fp32-level like the recompute).  Everything below the argument structs lives in a namespace named after
+// the piece count, so that both builds link into one library.
+#ifndef UMNN_BWD_NPB
+#define UMNN_BWD_NPB 2
+#endif
+#if UMNN_BWD_NPB == 3
+#define UMNN_BWD_NS bwd_p3
+#elif UMNN_BWD_NPB == 2
+#define UMNN_BWD_NS bwd_p2
+#else
+#error "UMNN_BWD_NPB: 2 or 3"
+#endif
 
 struct BwdBf16Args {
     BwdArgs b;
@@ -44,6 +56,10 @@ struct BwdBf16Args {
     unsigned* scal;                  // launch scalars of the fp16-piece pipeline (Ws16Scal, cc_bwd_ws16_kernel.h); nullable
     const unsigned* only_if;         // non-null: the kernel runs only if *only_if != 0 (the queued fallback behind the fp16-piece pipeline)
 };
+
+namespace UMNN_BWD_NS {
+constexpr int NPF = 3;           // bf16 pieces in the forward recompute (6 cross terms)
+constexpr int NPB = UMNN_BWD_NPB; // bf16 pieces in the delta chain and the dW product (3 or 6 cross terms)
 
 // fragment (tile t, K-step s, piece) of W (TRANSPOSED = false: rows = out features, K = in features incl. the
 // constant-one feature / bias column) or of W^T (rows = in features, K = out features; no bias/constant entries:
@@ -531,3 +547,5 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_bwd_bf16_kernel(const BwdBf1
     }
 }
 
+}  // namespace UMNN_BWD_NS
+using namespace UMNN_BWD_NS;

@@ -43,3 +43,6 @@ int umnn_backward_front_shape(const MlpDev& m);
 long long umnn_backward_front_scratch_bytes(const MlpDev& m, long long NI);
 int umnn_launch_backward_front(const BwdArgs& base, const umnn_mlp* net, int nblocks_max, void* scratch, long long scratch_bytes,
                                hipStream_t stream);
+// (the same with three pieces in every product: cc_backward_front_p3.hip, bwd_precision = fp32)
+int umnn_launch_backward_front_p3(const BwdArgs& base, const umnn_mlp* net, int nblocks_max, void* scratch, long long scratch_bytes,
+                                  hipStream_t stream);

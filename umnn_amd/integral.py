@@ -144,7 +144,7 @@ def _hip_backward_ok(spec, x, h):
     nets whose zero-padded weight images exceed the LDS (four or more hidden layers above 103 units, five above 63) --
     unequal widths up to 127 otherwise run the shape-exact fp32 kernels zero-padded (cc_backward.hip pad_to_exact_family),
     and a wide FIRST hidden layer over a narrow rest (MNISTExperiment's 100-50-50-50-50) has the three-stage kernels of
-    cc_backward_front.hip.  ``UMNN_BWD_WIDE=hip`` forces the HIP kernels anyway."""
+    cc_backward_front.hip (both backward precisions since round 4).  ``UMNN_BWD_WIDE=hip`` forces the HIP kernels anyway."""
     if _BWD_WIDE["hip"]:
         return True
     E = h.shape[1] // x.shape[1]
