@@ -220,18 +220,22 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
 #pragma unroll
     for (int t = 0; t < BT; ++t) c[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // FRONT (middle stage of the three-stage backward, cc_backward_front.hip): "layer 1" is the front kernel's z_2 out of HBM,
-    // [tile][node][register][lane]; fetched one element ahead.  zc = the current element's values (the tangent element: d z_2 / d t
-    // at node 0), zn = the next element's, z0 = z_2 of node 0 of the current tile (the tangent element needs its signs).
+    // [tile][node][register][lane].  z0 = z_2 of node 0 of the current tile (the tangent element -- d z_2 / d t at node 0 -- needs
+    // its signs).  The elements alternate between two register sets, the step loop is unrolled by two, and the set an element has
+    // just been read from is at once the target of the element two steps on -- loads in flight across the step barrier; see
+    // ws16_role_Ca (cc_bwd_ws16_kernel.h) for the measurement behind this.
     const int nl2 = NRL > 0 ? NRL : args.nl2;
-    float zc[BT][4], zn[BT][4], z0[BT][4];
+    float zs[2][BT][4], z0[BT][4];
 #pragma unroll
     for (int t = 0; t < BT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { zc[t][r] = 0.f; zn[t][r] = 0.f; z0[t][r] = 0.f; }
+        for (int r = 0; r < 4; ++r) { zs[0][t][r] = 0.f; zs[1][t][r] = 0.f; z0[t][r] = 0.f; }
     auto fetch_z = [&](const WsCursor& c2, float (&dst)[BT][4]) __attribute__((always_inline)) {
+        const bool there = c2.j < nit;                                      // (past the last element: the start of the buffer)
         const size_t tile0 = (size_t)ws_grp(c2) * (size_t)(a.n + 1) * nl2 * 64 + lane;
-        const bool tan = ws_is_tan(sh, c2);
-        const size_t base = tan ? (size_t)ws_grp(c2) * nl2 * 64 + lane : tile0 + (size_t)ws_node(sh, c2) * nl2 * 64;
+        const bool tan = there && ws_is_tan(sh, c2);
+        const size_t base = !there ? (size_t)lane
+                                   : (tan ? (size_t)ws_grp(c2) * nl2 * 64 + lane : tile0 + (size_t)ws_node(sh, c2) * nl2 * 64);
         const float* __restrict__ src = tan ? args.tz2 : args.z2;
 #pragma unroll
         for (int t = 0; t < BT; ++t)
@@ -265,7 +269,11 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         item_embedding_gemm<BT, 8>(hb, m.W[0], H1, E, d, g, p, c);
     };
     if (nit > 0) new_item();
-    if constexpr (FRONT) { if (nit > 0) fetch_z(cu, zc); }
+    WsCursor cf = cu;                                   // (FRONT) the element the next fetch brings in
+    if constexpr (FRONT) {
+        fetch_z(cf, zs[0]); cf = ws_next(sh, cf);
+        fetch_z(cf, zs[1]); cf = ws_next(sh, cf);
+    }
 
     float actF[BT][4];
     unsigned qF[8][NPF];
@@ -299,7 +307,9 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         const unsigned short* A3n = lds16 + WS_OFF_A3 + rA3 + trb;
         ws_load_op<4>(ops, A3n, A3n); ws_load_op<6>(ops, A3n, A3n); ws_load_op<5>(ops, A3n, A3n); ws_load_op<7>(ops, A3n, A3n);
     }
-    for (int s = 0; s < S; ++s) {
+    auto step = [&](auto parc) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(parc)::value;      // (FRONT) the register set of this step's element
+        float (&zc)[BT][4] = zs[PAR];
         WS_T(t0);
         const WsCursor nx = live ? ws_next(sh, cu) : cu;
         const int kn = ws_node(sh, nx);
@@ -312,7 +322,6 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
 #pragma unroll
                     for (int r = 0; r < 4; ++r) z0[t][r] = zc[t][r];
             }
-            if (live && nx.j < nit) fetch_z(nx, zn);
         }
         const unsigned short* A3 = lds16 + WS_OFF_A3 + rA3 + trb;
         const unsigned short* D4 = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + trb;
@@ -353,6 +362,11 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         // (only these sixteen registers differ for a tangent element: the branch stays outside the matrix loop)
         if (is_tan) swp_static_for<16>([&](auto ec) { layer1_reg(ec, std::true_type{}); });
         else swp_static_for<16>([&](auto ec) { layer1_reg(ec, std::false_type{}); });
+        if constexpr (FRONT) {
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_z(cf, zc);                            // this set has been read: element s + 2 into it
+            cf = ws_next(sh, cf);
+        }
         __builtin_amdgcn_sched_barrier(0);
         swp_static_for<12>([&](auto nc) {
             constexpr int nn = decltype(nc)::value;
@@ -373,12 +387,7 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
             live = cu.j < nit;
             if (crossed && live) new_item();
             is_tan = live && ws_is_tan(sh, cu);
-            if constexpr (FRONT) {
-#pragma unroll
-                for (int t = 0; t < BT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) zc[t][r] = zn[t][r];
-            } else {
+            if constexpr (!FRONT) {
                 const float uu = ccs_n + 1.f;
                 tk = (kn == 0) ? xv : __fadd_rn(x0v, __fmul_rn(dxv, uu) * 0.5f);
             }
@@ -394,6 +403,14 @@ __device__ __forceinline__ void ws_role_Ca(const BwdBf16Args& args, unsigned sho
         WS_STEP_SYNC();
         WS_T(t3);
         WS_TIMING_ACC(t0, t1, t2, t3);
+    };
+    if constexpr (FRONT) {
+        for (int s = 0; s < S; s += 2) {
+            step(std::integral_constant<int, 0>{});
+            if (s + 1 < S) step(std::integral_constant<int, 1>{});
+        }
+    } else {
+        for (int s = 0; s < S; ++s) step(std::integral_constant<int, 0>{});
     }
     WS_TIMING_OUT(S);
     ws_write_dw(a, part, 3, dW, lane, FRONT && args.accumulate);
