@@ -61,7 +61,7 @@ int umnn_ws16_front_prepare(const BwdArgs& base, int nblocks_max, hipStream_t st
     if (int rc = umnn_check(hipMemsetAsync(base.scal, 0, sizeof(Ws16Scal), stream), "memset launch scalars")) return rc;
     const long long want = (base.NI + 1023) / 1024;
     const unsigned nbm = (unsigned)(want < (long long)nblocks_max ? want : (long long)nblocks_max);
-    hipLaunchKernelGGL(cc_bwd_cotmax_kernel, dim3(nbm), dim3(256), 0, stream, base, reinterpret_cast<Ws16Scal*>(base.scal));
+    hipLaunchKernelGGL(cc_bwd_cotmax_kernel<>, dim3(nbm), dim3(256), 0, stream, base, reinterpret_cast<Ws16Scal*>(base.scal));
     return 0;
 }
 int umnn_ws16_front_launch(const BwdBf16Args& mid, int nrl, int nblocks, hipStream_t stream) {
@@ -127,7 +127,7 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
                 if (int rc = umnn_check(hipMemsetAsync(a.scal, 0, sizeof(Ws16Scal), stream), "memset launch scalars")) return rc;
                 const long long want = (a.NI + 1023) / 1024;             // (>= 4 integrals per thread; at most one workgroup per CU)
                 const unsigned nbm = (unsigned)(want < (long long)nblocks_max ? want : (long long)nblocks_max);
-                hipLaunchKernelGGL(cc_bwd_cotmax_kernel, dim3(nbm), dim3(256), 0, stream, a, reinterpret_cast<Ws16Scal*>(a.scal));
+                hipLaunchKernelGGL(cc_bwd_cotmax_kernel<>, dim3(nbm), dim3(256), 0, stream, a, reinterpret_cast<Ws16Scal*>(a.scal));
 #ifdef UMNN_WS_TIMING
                 static double* tbuf16 = nullptr;
                 const int nw16 = nblocks * WS_WAVES;

@@ -28,7 +28,7 @@
 // gets for this family -- no workgroup pipeline there, the one-pass middle kernel).
 #include "cc_bwd_bf16_kernel.h"
 #if UMNN_BWD_NPB == 2
-#include "cc_bwd_ws_kernel.h"
+#include "cc_bwd_ws16_kernel.h"      // (the workgroup pipelines; the fp16 helpers of stage A on fp16 pieces)
 #endif
 
 namespace UMNN_BWD_NS {
@@ -40,6 +40,7 @@ struct FrontArgs {
     unsigned grp0;          // first tile of the chunk; b.ngroups = tiles in the chunk
     int nl2;                // live registers of hidden layer 2
     int accumulate;
+    const unsigned* only_if;    // non-null: stage A runs only if *only_if != 0 (queued behind its fp16 build as the overflow fallback)
 };
 
 // fragment image of G1 = W[1] (hidden 1 -> hidden 2).  TRANSPOSED = false: rows = hidden-2 features (BT tiles, incl. the
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_fwd_kernel(const Front
     const int E = a.E, d = a.d, n = a.n, nl2 = NL2 > 0 ? NL2 : fa.nl2;
     const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
     unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
+    if (fa.only_if && *fa.only_if == 0) return;      // queued as the fallback of the fp16 build: nothing overflowed
     stage_g1_image<T1, false, NPF>(m, lds16, tid, blockDim.x);
     __syncthreads();
 
@@ -247,6 +249,182 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_fwd_kernel(const Front
         }
     }
 }
+
+#if UMNN_BWD_NPB == 2
+// ---------------------------------------------------------------------------------------------- stage A on fp16 pieces
+// The same stage with G1 and a_1 as two fp16 pieces each (cc_bwd_ws16_kernel.h on why three cross terms of 11-bit pieces are
+// fp32-level): 42 matrix instructions per tile-node instead of 84, a four-instruction split per pair instead of eight.  The low
+// piece of G1 is stored times 2^11 (W16_LOSCALE: a plain remainder of a weight below 2^-3 would be subnormal), its products in
+// their own accumulators.  Used together with the fp16 middle stage only: an activation beyond the fp16 range makes z_2 inf / NaN,
+// the middle stage's checks see that and raise the launch flag, and the launcher has the bf16 builds of BOTH stages queued
+// behind them with "run only if the flag is set".
+template <int T1>
+__device__ __forceinline__ void stage_g1_image16(const MlpDev& m, unsigned short* img, int tid, int nthreads) {
+    constexpr int KSF = T1 / 2;
+    const int Hin = m.width[1], Hout = m.width[2];
+    const float* __restrict__ W = m.W[1];
+    const float* __restrict__ b = m.b[1];
+    auto wv = [&](int frow, int fk) {
+        float v = 0.f;
+        if (frow < Hout) v = fk < Hin ? W[frow * Hin + fk] : (fk == Hin ? b[frow] : 0.f);
+        else if (frow == Hout && fk == Hin) v = 1.f;
+        return v;
+    };
+    for (int idx = tid; idx < BT * KSF * FRAG; idx += nthreads) {
+        const int j = idx & 7, ln = (idx >> 3) & 63, ts = idx >> 9;
+        const int s = ts % KSF, t = ts / KSF;
+        const float v = wv(fout_of(t, ln & 15), feat_of(2 * s + (j >> 2), j & 3, ln >> 4));
+        const _Float16 hi = (_Float16)v, lo = (_Float16)((v - (float)hi) * W16_LOSCALE);
+        img[(ts * 2 + 0) * FRAG + ln * 8 + j] = __builtin_bit_cast(unsigned short, hi);
+        img[(ts * 2 + 1) * FRAG + ln * 8 + j] = __builtin_bit_cast(unsigned short, lo);
+    }
+    if (T1 & 1) {
+        unsigned short* himg = img + BT * KSF * 2 * FRAG;
+        for (int idx = tid; idx < BT * 256; idx += nthreads) {
+            const int j = idx & 3, ln = (idx >> 2) & 63, t = idx >> 8;
+            const float v = wv(fout_of(t, ln & 15), feat_of(T1 - 1, j, ln >> 4));
+            const _Float16 hi = (_Float16)v, lo = (_Float16)((v - (float)hi) * W16_LOSCALE);
+            himg[(t * 2 + 0) * 256 + ln * 4 + j] = __builtin_bit_cast(unsigned short, hi);
+            himg[(t * 2 + 1) * 256 + ln * 4 + j] = __builtin_bit_cast(unsigned short, lo);
+        }
+    }
+}
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_f16_k16(u32x2 a, u32x2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+}
+// out[BT] = G1 x act[T1]: hi.hi + hi.lo in `out`, (2^11 lo).hi in its own accumulators, added back times 2^-11
+template <int T1>
+__device__ __forceinline__ void front_gemm16(const unsigned short* base, int lane, const f32x4 (&act)[T1], f32x4 (&out)[BT]) {
+    const unsigned short* img = base + lane * 8;
+    constexpr int KSF = T1 / 2;
+    u32x4 bf[KSF][2];
+#pragma unroll
+    for (int s = 0; s < KSF; ++s) {
+        unsigned q[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x0 = act[2 * s + (j >> 1)][2 * (j & 1)], x1 = act[2 * s + (j >> 1)][2 * (j & 1) + 1];
+            q[j][0] = h16_split_stage(x0, x1);
+            q[j][1] = h16_split_last(x0, x1);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) bf[s][k2] = u32x4{q[0][k2], q[1][k2], q[2][k2], q[3][k2]};
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc2[BT];
+#pragma unroll
+    for (int s = 0; s < KSF; ++s) {
+        u32x4 wf[BT][2];
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) wf[t][k2] = *reinterpret_cast<const u32x4*>(img + ((t * KSF + s) * 2 + k2) * FRAG);
+#pragma unroll
+        for (int t = 0; t < BT; ++t) out[t] = mfma_f16(wf[t][0], bf[s][0], s == 0 ? zero : out[t]);
+#pragma unroll
+        for (int t = 0; t < BT; ++t) out[t] = mfma_f16(wf[t][0], bf[s][1], out[t]);
+#pragma unroll
+        for (int t = 0; t < BT; ++t) acc2[t] = mfma_f16(wf[t][1], bf[s][0], s == 0 ? zero : acc2[t]);
+    }
+    if constexpr (T1 & 1) {
+        u32x2 hb[2];
+        {
+            float x0 = act[T1 - 1][0], x1 = act[T1 - 1][1], x2 = act[T1 - 1][2], x3 = act[T1 - 1][3];
+            const unsigned a0 = h16_split_stage(x0, x1), a1 = h16_split_stage(x2, x3);
+            hb[0] = u32x2{a0, a1};
+            hb[1] = u32x2{h16_split_last(x0, x1), h16_split_last(x2, x3)};
+        }
+        const unsigned short* himg = base + BT * KSF * 2 * FRAG + lane * 4;
+#pragma unroll
+        for (int t = 0; t < BT; ++t) {
+            const u32x2 wh = *reinterpret_cast<const u32x2*>(himg + (t * 2 + 0) * 256), wl = *reinterpret_cast<const u32x2*>(himg + (t * 2 + 1) * 256);
+            out[t] = mfma_f16_k16(wh, hb[0], KSF == 0 ? zero : out[t]);
+            out[t] = mfma_f16_k16(wh, hb[1], out[t]);
+            acc2[t] = mfma_f16_k16(wl, hb[0], KSF == 0 ? zero : acc2[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < BT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[t][r] = fmaf(acc2[t][r], W16_LOUNSCALE, out[t][r]);
+}
+
+template <int T1, int NL2>
+__global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_fwd16_kernel(const FrontArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const BwdArgs& a = fa.b;
+    const MlpDev& m = a.m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, p = lane & 15;
+    const int H1 = m.width[1];
+    const int E = a.E, d = a.d, n = a.n, nl2 = NL2 > 0 ? NL2 : fa.nl2;
+    const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
+    unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
+    stage_g1_image16<T1>(m, lds16, tid, blockDim.x);
+    __syncthreads();
+    float w1x[T1][4];
+    {
+        const float* __restrict__ W0 = m.W[0];
+#pragma unroll
+        for (int t = 0; t < T1; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = feat_of(t, r, g);
+                w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
+            }
+    }
+    const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + wid;
+    const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
+    for (unsigned item = wave_global; item < a.ngroups; item += nwaves) {
+        const unsigned grp = fa.grp0 + item;
+        const long long q = (long long)grp * 16 + p;
+        const long long qq = q < a.NI ? q : a.NI - 1;
+        const float xv = io_ld(a.x, qq, a.x_bf16);
+        const float x0v = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
+        const float dxv = xv - x0v;
+        const long long bi = qq / d;
+        const IoView hb = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
+        f32x4 c[T1];
+        front_prologue<T1>(m, hb, E, d, g, p, c);
+        const size_t frag0 = (size_t)item * (size_t)(n + 1) * nl2 * 64 + lane;
+        for (int k = 0; k <= n; ++k) {
+            const float u = a.ccs[k] + 1.f;
+            const float tk = k == 0 ? xv : __fadd_rn(x0v, __fmul_rn(dxv, u) * 0.5f);
+            f32x4 z1[T1], act[T1];
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    z1[t][r] = fmaf(w1x[t][r], tk, c[t][r]);
+                    act[t][r] = hidden_act_f(z1[t][r], slope);
+                }
+            f32x4 z2[BT];
+            front_gemm16<T1>(lds16, lane, act, z2);
+#pragma unroll
+            for (int t = 0; t < BT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * t + r < nl2) fa.z2[frag0 + ((size_t)k * nl2 + 4 * t + r) * 64] = z2[t][r];
+            if (k == 0 && fa.tz2) {
+                f32x4 ta[T1];
+#pragma unroll
+                for (int t = 0; t < T1; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ta[t][r] = w1x[t][r] * (z1[t][r] > 0.f ? 1.f : slope);
+                f32x4 tz[BT];
+                front_gemm16<T1>(lds16, lane, ta, tz);
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * t + r < nl2) fa.tz2[((size_t)item * nl2 + 4 * t + r) * 64 + lane] = tz[t][r];
+            }
+        }
+    }
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------- stage C
 template <int T1, int NL2>
@@ -464,8 +642,13 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
 // ------------------------------------------------------------------------------------------ host side
 typedef void (*front_kernel_t)(const FrontArgs);
 typedef void (*mid_kernel_t)(const BwdBf16Args);
-struct FrontVariant { int t1, nl2; front_kernel_t fwd, bwd; };
-#define FRONT_VARIANT(T, N) {T, N, cc_front_fwd_kernel<T, N>, cc_front_bwd_kernel<T, N>}
+#if UMNN_BWD_NPB == 2
+struct FrontVariant { int t1, nl2; front_kernel_t fwd, bwd, fwd16; };
+#define FRONT_VARIANT(T, N) {T, N, cc_front_fwd_kernel<T, N>, cc_front_bwd_kernel<T, N>, cc_front_fwd16_kernel<T, N>}
+#else
+struct FrontVariant { int t1, nl2; front_kernel_t fwd, bwd, fwd16; };
+#define FRONT_VARIANT(T, N) {T, N, cc_front_fwd_kernel<T, N>, cc_front_bwd_kernel<T, N>, nullptr}
+#endif
 static const FrontVariant kFrontVariants[] = {
     FRONT_VARIANT(5, 13), FRONT_VARIANT(6, 13), FRONT_VARIANT(7, 13), FRONT_VARIANT(8, 13),
     FRONT_VARIANT(5, 0), FRONT_VARIANT(6, 0), FRONT_VARIANT(7, 0), FRONT_VARIANT(8, 0),
@@ -577,6 +760,7 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
     const size_t lds_c = (size_t)T1 * BKS * NPB * FRAG * sizeof(unsigned short);
     if (lds_mid > 160 * 1024 || lds_a > 160 * 1024 || lds_c > 160 * 1024) return UMNN_EUNSUPPORTED;
     if (int rc = umnn_allow_lds((const void*)fv->fwd, lds_a)) return rc;
+    if (fv->fwd16) { if (int rc = umnn_allow_lds((const void*)fv->fwd16, lds_a)) return rc; }
     if (int rc = umnn_allow_lds((const void*)mv->fn, lds_mid)) return rc;
     if (int rc = umnn_allow_lds((const void*)fv->bwd, lds_c)) return rc;
     const MidVariant* wv = nullptr;
@@ -600,6 +784,7 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
 
     FrontArgs fa;
     fa.b = base;
+    fa.only_if = nullptr;
     fa.b.ns = 1;
     mid.b.ns = 1;
     mid.b.l_lo = 1;
@@ -616,21 +801,26 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
         if (nblocks < 1) nblocks = 1;
         fa.z2 = z2; fa.d2 = d2; fa.tz2 = tz2; fa.grp0 = (unsigned)t0; fa.b.ngroups = (unsigned)nt; fa.accumulate = t0 > 0;
         mid.z2 = z2; mid.d2 = d2; mid.tz2 = tz2; mid.grp0 = (unsigned)t0; mid.b.ngroups = (unsigned)nt; mid.accumulate = t0 > 0;
-        hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
 #if UMNN_BWD_NPB == 2
         if (hv) {
-            // (the fp16 pipeline, then the bf16 pipeline behind it that only runs if a piece overflowed: same outputs, rewritten)
+            // (stages A and B on fp16 pieces, then their bf16 builds behind them that only run if a piece overflowed -- the launch
+            // flag, raised by the checks of stage B, which also see a non-finite z_2 from stage A: same outputs, rewritten)
+            hipLaunchKernelGGL(fv->fwd16, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
             mid.scal = base.scal; mid.only_if = nullptr;
             if (int rc = umnn_ws16_front_launch(mid, nrl, nblocks_max, stream)) return rc;
-            mid.only_if = base.scal + 3;                         // (Ws16Scal::flag)
+            fa.only_if = mid.only_if = base.scal + 3;            // (Ws16Scal::flag)
+            hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
             hipLaunchKernelGGL(wv->fn, dim3(nblocks_max), dim3(64 * WS_WAVES), lds_ws, stream, mid);
+            fa.only_if = nullptr;
             used_ws = true;
         } else if (wv && nt >= 4LL * nblocks_max) {
+            hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
             hipLaunchKernelGGL(wv->fn, dim3(nblocks_max), dim3(64 * WS_WAVES), lds_ws, stream, mid);
             used_ws = true;
         } else
 #endif
         {
+            hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
             hipLaunchKernelGGL(mv->fn, dim3(nblocks * (UMNN_WAVES_PER_BLOCK / wpb_mid)), dim3(64 * wpb_mid), lds_mid, stream, mid);
         }
         hipLaunchKernelGGL(fv->bwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_c, stream, fa);

@@ -145,6 +145,7 @@ __device__ __forceinline__ bool ws16_finite(float v) { return __builtin_fabsf(v)
 
 // max |g (x - x0) / 2|, max |g_fx| over the integrals and max |w_k| over the nodes, as the bit patterns of non-negative floats
 // (which order like unsigned integers): order-independent, so the result -- and with it sigma -- is deterministic
+template <int = 0>           // (a template so that every translation unit that includes this header may hold a copy)
 __global__ __launch_bounds__(256) void cc_bwd_cotmax_kernel(const BwdArgs a, Ws16Scal* sc) {
     __shared__ float red[3][4];
     float m0 = 0.f, m1 = 0.f, m2 = 0.f;
