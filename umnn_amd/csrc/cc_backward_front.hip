@@ -294,27 +294,27 @@ __device__ __forceinline__ f32x4 mfma_f16_k16(u32x2 a, u32x2 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
 }
 // out[BT] = G1 x act[T1]: hi.hi + hi.lo in `out`, (2^11 lo).hi in its own accumulators, added back times 2^-11
-template <int T1>
-__device__ __forceinline__ void front_gemm16(const unsigned short* base, int lane, const f32x4 (&act)[T1], f32x4 (&out)[BT]) {
+// (act(t, r): the B operand's value of feature register r of tile t, produced K-step by K-step -- the whole of a_1 is never live)
+template <int T1, class ActFn>
+__device__ __forceinline__ void front_gemm16(const unsigned short* base, int lane, ActFn&& act, f32x4 (&out)[BT]) {
     const unsigned short* img = base + lane * 8;
     constexpr int KSF = T1 / 2;
-    u32x4 bf[KSF][2];
-#pragma unroll
-    for (int s = 0; s < KSF; ++s) {
-        unsigned q[4][2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x0 = act[2 * s + (j >> 1)][2 * (j & 1)], x1 = act[2 * s + (j >> 1)][2 * (j & 1) + 1];
-            q[j][0] = h16_split_stage(x0, x1);
-            q[j][1] = h16_split_last(x0, x1);
-        }
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) bf[s][k2] = u32x4{q[0][k2], q[1][k2], q[2][k2], q[3][k2]};
-    }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc2[BT];
 #pragma unroll
     for (int s = 0; s < KSF; ++s) {
+        u32x4 bf[KSF][2];
+        {
+            unsigned q[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x0 = act(2 * s + (j >> 1), 2 * (j & 1)), x1 = act(2 * s + (j >> 1), 2 * (j & 1) + 1);
+                q[j][0] = h16_split_stage(x0, x1);
+                q[j][1] = h16_split_last(x0, x1);
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) bf[s][k2] = u32x4{q[0][k2], q[1][k2], q[2][k2], q[3][k2]};
+        }
         u32x4 wf[BT][2];
 #pragma unroll
         for (int t = 0; t < BT; ++t)
@@ -330,7 +330,7 @@ __device__ __forceinline__ void front_gemm16(const unsigned short* base, int lan
     if constexpr (T1 & 1) {
         u32x2 hb[2];
         {
-            float x0 = act[T1 - 1][0], x1 = act[T1 - 1][1], x2 = act[T1 - 1][2], x3 = act[T1 - 1][3];
+            float x0 = act(T1 - 1, 0), x1 = act(T1 - 1, 1), x2 = act(T1 - 1, 2), x3 = act(T1 - 1, 3);
             const unsigned a0 = h16_split_stage(x0, x1), a1 = h16_split_stage(x2, x3);
             hb[0] = u32x2{a0, a1};
             hb[1] = u32x2{h16_split_last(x0, x1), h16_split_last(x2, x3)};
@@ -351,7 +351,7 @@ __device__ __forceinline__ void front_gemm16(const unsigned short* base, int lan
 }
 
 template <int T1, int NL2>
-__global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_fwd16_kernel(const FrontArgs fa) {
+__global__ __launch_bounds__(UMNN_BLOCK, 2) void cc_front_fwd16_kernel(const FrontArgs fa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const BwdArgs& a = fa.b;
     const MlpDev& m = a.m;
@@ -392,29 +392,16 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_fwd16_kernel(const Fro
         for (int k = 0; k <= n; ++k) {
             const float u = a.ccs[k] + 1.f;
             const float tk = k == 0 ? xv : __fadd_rn(x0v, __fmul_rn(dxv, u) * 0.5f);
-            f32x4 z1[T1], act[T1];
-#pragma unroll
-            for (int t = 0; t < T1; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    z1[t][r] = fmaf(w1x[t][r], tk, c[t][r]);
-                    act[t][r] = hidden_act_f(z1[t][r], slope);
-                }
             f32x4 z2[BT];
-            front_gemm16<T1>(lds16, lane, act, z2);
+            front_gemm16<T1>(lds16, lane, [&](int t, int r) { return hidden_act_f(fmaf(w1x[t][r], tk, c[t][r]), slope); }, z2);
 #pragma unroll
             for (int t = 0; t < BT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (4 * t + r < nl2) fa.z2[frag0 + ((size_t)k * nl2 + 4 * t + r) * 64] = z2[t][r];
             if (k == 0 && fa.tz2) {
-                f32x4 ta[T1];
-#pragma unroll
-                for (int t = 0; t < T1; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ta[t][r] = w1x[t][r] * (z1[t][r] > 0.f ? 1.f : slope);
                 f32x4 tz[BT];
-                front_gemm16<T1>(lds16, lane, ta, tz);
+                front_gemm16<T1>(lds16, lane, [&](int t, int r) { return w1x[t][r] * (fmaf(w1x[t][r], tk, c[t][r]) > 0.f ? 1.f : slope); }, tz);
 #pragma unroll
                 for (int t = 0; t < BT; ++t)
 #pragma unroll
@@ -805,7 +792,7 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
         if (hv) {
             // (stages A and B on fp16 pieces, then their bf16 builds behind them that only run if a piece overflowed -- the launch
             // flag, raised by the checks of stage B, which also see a non-finite z_2 from stage A: same outputs, rewritten)
-            hipLaunchKernelGGL(fv->fwd16, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
+            hipLaunchKernelGGL(fv->fwd16, dim3(2 * nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);      // (two workgroups per CU)
             mid.scal = base.scal; mid.only_if = nullptr;
             if (int rc = umnn_ws16_front_launch(mid, nrl, nblocks_max, stream)) return rc;
             fa.only_if = mid.only_if = base.scal + 3;            // (Ws16Scal::flag)
