@@ -322,6 +322,55 @@ def test_three_stage_backward_under_fp32_precision_is_the_six_term_build(hid, wi
         _lib.set_backward_precision("bf16x3")
 
 
+def test_three_stage_backward_at_the_benchmarked_mnist_size_runs_on_fp16_pieces(dev):
+    """MNISTExperiment's shape at the script's batch (100 x 784 integrals, n = 50, 31-100-50^4-1: what `bench.py --workload mnist
+    --mode train` times): under the library defaults stages A and B of the three-stage backward run on fp16 pieces.  Rows sampled
+    against the oracle in float64 (d_h, d_x depend on their own row), d_theta against the six-term build (bwd_precision = fp32) and
+    the bf16 route, halves concatenating / adding up, bit-repeatability."""
+    import umnn_amd
+    from umnn_amd import integral as I, _lib
+    from umnn_amd.nets import mlp_spec
+    torch.manual_seed(0)
+    B, d, E, n = 100, 784, 30, 50
+    net = umnn_amd.IntegrandNetwork(d, 1 + E, [100, 50, 50, 50, 50], 1)
+    with torch.no_grad():
+        for mod in net.net:
+            if isinstance(mod, torch.nn.Linear):
+                mod.weight.mul_(1.5)
+    lin = [m for m in net.net if isinstance(m, torch.nn.Linear)]
+    onet = O.Net([m.weight.detach().numpy() for m in lin], [m.bias.detach().numpy() for m in lin], O.LEAKY, O.ELU1)
+    net.to(dev)
+    spec = mlp_spec(net)
+    x, h = torch.randn(B, d), torch.randn(B, E * d)
+    g, gf = torch.randn(B, d), torch.randn(B, d) * 0.1
+    args = (spec, None, x.to(dev), h.to(dev), g.to(dev), gf.to(dev), n)
+    out = I.hip_backward(*args)
+    name = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+    assert name == "cc_bwd_f16<L=4,LIVE=13,WS,FRONT>", name
+    again = I.hip_backward(*args)
+    assert all(torch.equal(u, v) for u, v in zip(out[1:], again[1:]))
+    rows = np.array([0, 37, 99])
+    ref = _oracle_backward_chunked(onet, np.zeros((3, d), np.float32), x[rows].numpy(), h[rows].numpy(), n, g[rows].numpy(), gf[rows].numpy(), chunk=1)
+    for i, nm in ((1, "dx"), (2, "dh")):
+        got = out[i][rows].cpu().numpy().astype(np.float64)
+        per = np.abs(got - ref[i]).reshape(3, -1, d).max(axis=1).ravel() / np.abs(ref[i]).max()      # per integral
+        assert np.median(per) < 5e-6 and (per > TOL).sum() <= 4, (nm, float(np.median(per)), int((per > TOL).sum()), float(per.max()))
+    with _lib.options(bwd_ws16=0):
+        ob = I.hip_backward(*args)
+        assert _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode().startswith("cc_bwd_bf16<")
+    _lib.set_backward_precision("fp32")
+    try:
+        o6 = I.hip_backward(*args)
+        assert _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode().startswith("cc_bwd_bf16x6<")
+    finally:
+        _lib.set_backward_precision("bf16x3")
+    assert U.scaled_err(out[3].cpu().numpy(), o6[3].cpu().numpy()) < 2e-4, U.scaled_err(out[3].cpu().numpy(), o6[3].cpu().numpy())
+    assert U.scaled_err(out[3].cpu().numpy(), ob[3].cpu().numpy()) < 2e-4
+    # (d_x carries g_fx . df/dx at node 0: a LeakyReLU kink inside rounding noise moves its own integral)
+    per = (out[1] - o6[1]).abs().cpu().numpy().ravel() / float(o6[1].abs().max())
+    assert np.median(per) < 5e-6 and (per > TOL).sum() <= 16, (float(np.median(per)), int((per > TOL).sum()), float(per.max()))
+
+
 def test_fp16_piece_pipeline_scales_tiny_and_huge_cotangents(dev):
     """The cotangent scale is a per-launch power of two: gradients are homogeneous in g to the last bit."""
     import umnn_amd
