@@ -123,7 +123,7 @@ def test_bf16_workgroup_pipeline_matches_the_oracle_directly(dev):
 
 
 def test_fp16_piece_pipeline_matches_the_float64_oracle_where_it_is_the_default(dev):
-    """cc_bwd_ws16_kernel.h is the default from 2^22 node evaluations per launch: 672 x 63 integrals x 101 nodes, 31-50^4-1, g_fx on,
+    """cc_bwd_ws16_kernel.h is the default from 2^21 node evaluations per launch: 672 x 63 integrals x 101 nodes, 31-50^4-1, g_fx on,
     weights x 1.5, non-zero x0.  Against the oracle in float64 (chunked over rows): d_x0 and d_theta inside 1e-4; d_x and d_h inside
     1e-4 on every row that is not kink-ambiguous at 3e-6 (the recompute's noise on a pre-activation, relative to the magnitudes
     of its terms; fp32 arithmetic: ~1e-6) -- one of the 6.4e8 kink decisions going the other way moves ITS row by up to ~1e-3 of

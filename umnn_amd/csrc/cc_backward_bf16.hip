@@ -109,13 +109,13 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
             // fallback that only runs if a piece overflowed (same outputs, rewritten).  1/f launches, sigmoid outputs and quadratures
             // whose tables do not fit the kernel's LDS copy keep the bf16 pipeline.
             const BwdWsVariant* hv = nullptr;
-            // bwd_ws16 = 1 (default): only for launches of at least 2^22 node evaluations.  Its recompute carries ~3e-7 of relative noise
+            // bwd_ws16 = 1 (default): only for launches of at least 2^21 node evaluations (2^22 until the whole GPU suite had passed at 2^21).  Its recompute carries ~3e-7 of relative noise
             // on a pre-activation (fp32: ~1e-7), i.e. 3-4 times as many LeakyReLU kink decisions differ from an exact evaluation; one such
             // decision moves d_theta by ~4e-5 of its largest entry at 4e5 node evaluations (tools/bwd_truth64.py) and by 1 / N of
             // that beyond, so below the threshold the six-term bf16 pipeline keeps mid-size batches inside the 1e-4 parity band.
             // bwd_ws16 = 2: whenever the workgroup pipeline is eligible (tests, measurements).
             const int w16 = umnn_options().bwd_ws16;
-            const bool w16_size_ok = w16 == 2 || (w16 == 1 && a.NI * (long long)(a.n + 1) >= (1LL << 22));
+            const bool w16_size_ok = w16 == 2 || (w16 == 1 && a.NI * (long long)(a.n + 1) >= (1LL << 21));
             if (w16_size_ok && !a.inv_f && a.scal && a.m.out_act == UMNN_OUT_ELU_PLUS_ONE && a.n + 1 <= W16_MAX_NODES)
                 for (const BwdWsVariant& c : kBwdWs16Variants)
                     if (c.nrl == nrl) { hv = &c; break; }
