@@ -104,7 +104,9 @@ for tag, title in (("bsds300", "C3 BSDS300-shaped eval (8192 x 63 integrals per 
     lines += table("forward quadrature kernel", e)
     if tag.endswith("_train"):
         if tag.startswith("mnist"):     # three kernels per chunk share the backward's work: report each with its own counters
-            for part, ttl in (("cc_front_fwd_kernel", "stage A: front forward (a1, z2 -> HBM)"),
+            for part, ttl in ((next((k for k in ("cc_front_fwd16_kernel",) if any(k in r["Name"] for r in stats)), "cc_front_fwd_kernel"),
+                               "stage A: front forward (a1, z2 -> HBM; round 4: on fp16 pieces, two workgroups per CU -- the cc_front_fwd_kernel "
+                               "launches next to it are the queued overflow fallback returning at once)"),
                               (next((k for k in ("cc_bwd_ws16_kernel", "cc_bwd_ws_kernel") if any(k in r["Name"] for r in stats)), "cc_bwd_bf16_kernel"),
                                "stage B: flagship kernel on the net from hidden layer 2 on (FRONT; the workgroup pipeline, round 4: on fp16 pieces -- "
                                "the cc_bwd_ws_kernel launches next to it are the queued overflow fallback returning at once)"),
