@@ -194,7 +194,9 @@ def test_fp16_piece_pipeline_falls_back_when_a_piece_overflows(dev):
     assert not torch.equal(c[3], e[3]) and U.scaled_err(c[3].cpu().numpy(), e[3].cpu().numpy()) < 3e-4
 
 
-@pytest.mark.parametrize("hid, with_gfx", [([100, 50, 50, 50, 50], True), ([112, 48, 60, 36, 50], False)])
+@pytest.mark.parametrize("hid, with_gfx", [([100, 50, 50, 50, 50], True), ([112, 48, 60, 36, 50], False),
+                                           # (first layers of 5, 6 and 8 tiles: the other instantiations of stage A on fp16 pieces)
+                                           ([72, 50, 50, 50, 50], False), ([90, 52, 50, 44, 50], True), ([120, 50, 50, 50, 50], True)])
 def test_fp16_piece_pipeline_as_the_middle_stage_of_the_three_stage_backward(hid, with_gfx, dev):
     """MNISTExperiment's shape (31-100-50^4-1, d = 784): the middle stage of the three-stage backward (cc_backward_front.hip) on
     fp16 pieces -- z_2 from HBM into wave Ca, delta_2 un-scaled back to HBM from wave B1, single-chunk calls.  Forced here (the
