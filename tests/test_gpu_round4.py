@@ -373,6 +373,38 @@ def test_three_stage_backward_at_the_benchmarked_mnist_size_runs_on_fp16_pieces(
     assert np.median(per) < 5e-6 and (per > TOL).sum() <= 16, (float(np.median(per)), int((per > TOL).sum()), float(per.max()))
 
 
+def test_graphed_train_step_with_the_fp16_pipeline_inside_the_graph(dev):
+    """GraphedTrainStep at a size where the backward is the fp16-piece pipeline (1024 x 64 integrals x 51 nodes >= 2^21): the
+    capture then holds the scalar memset, the cotangent-scale pre-pass, the pipeline and the queued conditional bf16 kernel.  Replays
+    must reproduce eager training (same kernels, deterministic): losses and parameters after four steps on changing batches."""
+    import copy
+    import umnn_amd
+    from umnn_amd import _lib
+    torch.manual_seed(31)
+    model_a = umnn_amd.UMNNMAFFlow(nb_flow=2, nb_in=64, hidden_derivative=[50, 50, 50, 50], hidden_embedding=[128, 128], embedding_s=30,
+                                   nb_steps=50, device=dev).to(dev)
+    model_b = copy.deepcopy(model_a)
+    xs = [torch.randn(1024, 64, device=dev) for _ in range(4)]
+    opt_a = torch.optim.Adam([p for p in model_a.parameters() if p.requires_grad], lr=1e-3, capturable=True)
+    opt_b = torch.optim.Adam([p for p in model_b.parameters() if p.requires_grad], lr=1e-3, capturable=True)
+    model_a.train(); model_b.train()
+    warm = 1
+    losses_a = []
+    for x in [xs[0]] * warm + xs:
+        opt_a.zero_grad(set_to_none=True)
+        ll, _ = model_a.compute_ll(x)
+        loss = -ll.mean()
+        loss.backward()
+        opt_a.step()
+        losses_a.append(loss.item())
+    assert _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode().startswith("cc_bwd_f16<")
+    step = umnn_amd.GraphedTrainStep(model_b, opt_b, xs[0], warmup=warm)
+    losses_b = [step(x).item() for x in xs]
+    assert max(abs(a - b) for a, b in zip(losses_a[warm:], losses_b)) < 1e-5 * max(1.0, abs(losses_a[-1])), (losses_a, losses_b)
+    for (n, pa), (_, pb) in zip(model_a.named_parameters(), model_b.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6), n
+
+
 def test_fp16_piece_pipeline_scales_tiny_and_huge_cotangents(dev):
     """The cotangent scale is a per-launch power of two: gradients are homogeneous in g to the last bit."""
     import umnn_amd
