@@ -156,7 +156,9 @@ class GraphedTrainStep:
         torch.cuda.current_stream(x_example.device).wait_stream(side)
         _prime_for_capture(model, x_example)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
+        # (captured on the warm-up's stream: the parameters' AccumulateGrad nodes are bound to it -- on another capture stream
+        # autograd warns about the mismatch and synchronises through the legacy stream)
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode=_capture_mode()):
             self.loss = one_step()
 
     def __call__(self, x=None, context=None):
