@@ -238,5 +238,13 @@ def test_ipc_mode_is_set_before_the_gpu_runtime_can_initialise():
         r = subprocess.run([sys.executable, "-c", code], env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="1"), capture_output=True,
                            text=True, timeout=300, cwd=root)
         assert "IPC 1" in r.stdout, (mod, r.stdout)
+    # the common order `import torch; import umnn_amd`: the guard itself must not touch HIP before the default is
+    # written -- it may only read torch.cuda.is_initialized() (Python state); is_available() would call hipGetDeviceCount
+    code = ("import os, torch, unittest.mock as m\n"
+            "with m.patch.object(torch.cuda, 'is_available', side_effect=AssertionError('HIP probe before the env default')):\n"
+            "    import umnn_amd\n"
+            "print('IPC', os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "IPC 0" in r.stdout, (r.stdout, r.stderr[-800:])
     import inspect
     assert "setdefault(\"HSA_ENABLE_IPC_MODE_LEGACY\"" not in inspect.getsource(sharding.init_from_env)

@@ -7,16 +7,18 @@ import sys as _sys
 
 # RCCL / device-tensor sharing between the ranks of a node goes through dmabuf IPC on this driver stack; the legacy mode fails with
 # "hipIpcGetMemHandle: invalid argument".  The HSA runtime reads the variable ONCE, when the process first touches the GPU, so the
-# default has to be in the environment before that -- i.e. here, at import (an explicit setting wins).  Importing this package
-# after the GPU is already initialised cannot change the mode any more: say so instead of failing later inside a collective.
+# default has to be in the environment before that -- i.e. here, at import, and BEFORE anything below can make a HIP call (an
+# explicit setting wins).  Importing this package after the GPU is already initialised cannot change the mode any more: say so
+# instead of failing later inside a collective.  The probe is torch.cuda.is_initialized() only -- Python state, no HIP call
+# (torch.cuda.is_available() goes through hipGetDeviceCount, which may itself start the runtime and freeze the legacy mode).
 if "HSA_ENABLE_IPC_MODE_LEGACY" not in _os.environ:
+    _os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     _torch = _sys.modules.get("torch")
-    if _torch is not None and _torch.cuda.is_available() and _torch.cuda.is_initialized():
+    if _torch is not None and _torch.cuda.is_initialized():
         import warnings as _warnings
         _warnings.warn("umnn_amd: HSA_ENABLE_IPC_MODE_LEGACY was not set when this process initialised the GPU; multi-process RCCL "
                        "(torch.distributed backend 'nccl') may fail with 'hipIpcGetMemHandle: invalid argument'.  Export "
                        "HSA_ENABLE_IPC_MODE_LEGACY=0 or import umnn_amd before the first CUDA call.", RuntimeWarning)
-    _os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
 
 from .flow import UMNNMAFFlow, UMNNMAF, EmbeddingNetwork, IntegrandNetwork, ListModule
 from .monotonic import MonotonicNN, IntegrandNN
