@@ -507,12 +507,11 @@ def test_f16x3_forward_is_fp32_level_at_the_cost_of_bf16x3(dev):
         umnn_amd.set_forward_precision(old)
 
 
-def test_f16x3_forward_overflow_is_nan_never_a_wrong_number(dev):
-    """fp16 pieces have fp16's exponent range: hidden activations beyond +-65504 overflow the leading piece.  The kernels detect
-    that in the output-layer sum and return NaN for the affected integrals (ELU + 1 would otherwise map a -inf sum to a finite 0);
-    the default bf16x3 arithmetic has fp32's range and stays finite on the same inputs.  (The other end of the range: a weight below
-    2^-14 = 6e-5 has a subnormal leading piece -- absolute error 2^-25 per weight; harmless for nets whose weights are O(1e-2), and
-    part of why the mode is opt-in.)"""
+def test_f16x3_forward_overflow_is_finite_and_equal_to_bf16x3_on_the_overflowing_rows(dev):
+    """fp16 pieces have fp16's exponent range: hidden activations beyond +-65504 overflow the leading piece.  Round 4 detected that
+    in the output-layer sum and returned NaN (which kept the mode opt-in); since round 5 the affected tile groups are deferred to
+    the bf16x3 build queued behind the launch (tests/test_gpu_round5.py has the protocol's own tests): finite everywhere, the
+    overflowing rows bit-equal to a bf16x3 launch, every row inside 1e-4 of the exact-fp32 kernels."""
     import umnn_amd
     from umnn_amd import integral as I
     from umnn_amd.nets import mlp_spec
@@ -532,9 +531,7 @@ def test_f16x3_forward_overflow_is_nan_never_a_wrong_number(dev):
     finally:
         umnn_amd.set_forward_precision(old)
     assert torch.isfinite(Fb).all() and torch.isfinite(fb).all() and torch.isfinite(Fe).all()
-    bad = ~torch.isfinite(Ff)
-    assert bad[:12].any() and not bad[12:].any(), "rows 0..11 drive |a_1| beyond 65504: fp16 pieces must overflow there and only there"
-    ok = ~bad
-    # wherever f16x3 returned a number, it is the right number: closer to the exact-fp32 kernels than the default arithmetic is
-    rel = lambda A: float(((A - Fe).abs()[ok] / Fe.abs().clamp(min=1.0)[ok]).max())
+    assert torch.isfinite(Ff).all() and torch.isfinite(ff).all()
+    assert torch.equal(Ff[:12], Fb[:12]) and torch.equal(ff[:12], fb[:12])
+    rel = lambda A: float(((A - Fe).abs() / Fe.abs().clamp(min=1.0)).max())
     assert rel(Ff) < 1e-4 and rel(Ff) <= rel(Fb), (rel(Ff), rel(Fb))

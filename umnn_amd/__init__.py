@@ -34,14 +34,17 @@ from ._lib import set_forward_precision, get_forward_precision, set_backward_pre
 def set_precision(name):
     """One switch for the arithmetic of the whole path.
 
+    'f16x3'  : the library default -- hidden GEMMs of the forward kernels on TWO fp16 pieces / 3 cross terms: fp32-level accuracy
+               (~5e-7 on F against float64; the exact-fp32 kernels: ~4e-7) at the speed of 'bf16x3'.  fp16's exponent range is
+               handled, not assumed: a tile group in which a hidden activation leaves +-65504 is detected in its quadrature sum,
+               writes nothing, and is recomputed by the bf16x3 build of the same kernel queued right behind the launch (idle cost:
+               one scalar load per workgroup) -- those integrals come back at bf16x3 accuracy, never NaN, never a wrong number.
+               Conditioner inference GEMMs as K-concatenated bf16 GEMMs (3e-6 of the output range).
     'fp32'   : exact fp32 products everywhere (fp32 MFMA kernels forward and backward, fp32 conditioner GEMMs) -- the
                reference's arithmetic, ~2.4x slower forward.
     'bf16x6' : hidden GEMMs on the bf16 matrix cores with 6 cross terms (fp32-level accuracy, ~4e-7 on F).
-    'f16x3'  : hidden GEMMs of the forward kernels on TWO fp16 pieces / 3 cross terms (fp32-level accuracy, ~4e-7 on F, at the
-               speed of 'bf16x3').  fp16's exponent range: hidden activations beyond +-65504 overflow; that is detected and makes
-               the affected integrals NaN (never a wrong finite value) -- which is why it is not the default.
-    'bf16x3' : the library default -- 3 cross terms on bf16 pieces (F to ~6e-6, every parity test passes at 1e-4), conditioner
-               inference GEMMs as K-concatenated bf16 GEMMs (3e-6 of the output range).
+    'bf16x3' : 3 cross terms on bf16 pieces (F to ~6e-6, every parity test passes at 1e-4) -- the default until round 4, and the
+               arithmetic of the overflow fallback.
     The backward kernels know 'fp32' and 'bf16x3' (fp32-level recompute + 3-term delta / dW; on fp16 pieces at large batch);
     'bf16x6' and 'f16x3' select 'bf16x3' there."""
     if name not in ("fp32", "bf16x3", "bf16x6", "f16x3"):

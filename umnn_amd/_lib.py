@@ -149,8 +149,9 @@ def check(rc, what):
 
 
 def set_forward_precision(name):
-    """'fp32' (exact fp32 MFMA), 'bf16x3' (default: bf16 split, 3 cross terms), 'bf16x6' (three bf16 pieces: fp32-level accuracy) or
-    'f16x3' (two fp16 pieces, three cross terms: fp32-level accuracy at the cost of bf16x3, fp16 range -- overflow gives NaN)."""
+    """'f16x3' (default: two fp16 pieces, three cross terms -- fp32-level accuracy at the cost of bf16x3; tile groups whose pieces
+    overflow fp16's range are recomputed by the queued bf16x3 build), 'fp32' (exact fp32 MFMA), 'bf16x3' (bf16 split, 3 cross terms)
+    or 'bf16x6' (three bf16 pieces: fp32-level accuracy)."""
     check(lib().umnn_set_forward_precision(PRECISIONS[name]), "umnn_set_forward_precision")
 
 

@@ -61,6 +61,36 @@ int umnn_num_cus() {
     return v;
 }
 
+// Flag words of the forward overflow protocol (cc_forward_bf16.hip): 256 zeroed 64-bit words per device, allocated on the first
+// fp16-piece launch of that device (in relaxed capture mode, should that launch be recorded into a hipGraph); every launch takes
+// the next generation number and the word generation % 256.
+int umnn_ovf_slot(unsigned long long** flag, unsigned long long* gen) {
+    static std::mutex mu;
+    static unsigned long long* ring[64] = {nullptr};
+    static std::atomic<unsigned long long> next{1};
+    int dev = 0;
+    if (int rc = umnn_check(hipGetDevice(&dev), "hipGetDevice")) return rc;
+    if (dev < 0 || dev >= 64) return umnn_fail(UMNN_EINVAL, "device ordinal above 63");
+    unsigned long long* r = __atomic_load_n(&ring[dev], __ATOMIC_ACQUIRE);
+    if (!r) {
+        std::lock_guard<std::mutex> lk(mu);
+        r = ring[dev];
+        if (!r) {
+            hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+            (void)hipThreadExchangeStreamCaptureMode(&mode);
+            hipError_t e = hipMalloc(&r, 256 * sizeof(unsigned long long));
+            if (e == hipSuccess) e = hipMemset(r, 0, 256 * sizeof(unsigned long long));
+            (void)hipThreadExchangeStreamCaptureMode(&mode);
+            if (e != hipSuccess) return umnn_check(e, "overflow flag ring");
+            __atomic_store_n(&ring[dev], r, __ATOMIC_RELEASE);
+        }
+    }
+    const unsigned long long g = next.fetch_add(1, std::memory_order_relaxed);
+    *flag = r + (g & 255);
+    *gen = g;
+    return 0;
+}
+
 int umnn_allow_lds(const void* fn, size_t bytes) {
     // raising the dynamic-LDS cap is per (device, function); cache what we already granted
     struct Key { int dev; const void* fn; bool operator==(const Key& o) const { return dev == o.dev && fn == o.fn; } };
@@ -82,11 +112,11 @@ int umnn_allow_lds(const void* fn, size_t bytes) {
 // ---- options: environment read once, atomics afterwards --------------------------------------------------------
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; }
 static void load_env(UmnnOptions& o) {
-    int fp = UMNN_PRECISION_BF16X3, bp = UMNN_PRECISION_BF16X3;
+    int fp = UMNN_PRECISION_F16X3, bp = UMNN_PRECISION_BF16X3;
     if (const char* ev = getenv("UMNN_FWD_PRECISION")) {
         if (!strcmp(ev, "fp32")) fp = UMNN_PRECISION_FP32;
         else if (!strcmp(ev, "bf16x6")) fp = UMNN_PRECISION_BF16X6;
-        else if (!strcmp(ev, "f16x3")) fp = UMNN_PRECISION_F16X3;
+        else if (!strcmp(ev, "bf16x3")) fp = UMNN_PRECISION_BF16X3;
     }
     if (const char* ev = getenv("UMNN_BWD_PRECISION")) bp = !strcmp(ev, "fp32") ? UMNN_PRECISION_FP32 : UMNN_PRECISION_BF16X3;
     o.fwd_precision = fp; o.bwd_precision = bp;

@@ -234,8 +234,9 @@ static const FwdVariant kFwdVariants[] = {
     FWD_VARIANT(8, 0, 1, 0, 0),  FWD_VARIANT(8, 0, 2, 0, 0),    // generic, <= 127
 };
 
-int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps, hipStream_t stream);
-int umnn_launch_forward_f16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps, hipStream_t stream);     // cc_forward_f16.hip
+struct FwdOvfPlan;        // cc_forward_bf16.hip: the queued-fallback plan of an fp16-piece launch (null = a plain launch)
+int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps, hipStream_t stream, const FwdOvfPlan* ovf);
+int umnn_launch_forward_f16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps, hipStream_t stream, const FwdOvfPlan* ovf);     // cc_forward_f16.hip
 
 static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, const float* h,
                           const float* scaling, const float* cc_w, const float* cc_s, int nb_steps,
@@ -263,6 +264,7 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
     a.inv_z = nullptr; a.inv_x = nullptr; a.inv_j = 0; a.inv_iters = 0;
     if (ll && a.x_bf16) return umnn_fail(UMNN_EINVAL, "flow ll forward: z / log_jac scratch must be fp32");
     a.NI = B * (long long)d; a.d = d; a.E = E; a.n = nb_steps; a.inv_f = inv_f;
+    a.ovf_mode = 0; a.ovf_flag = nullptr; a.ovf_gen = 0;
 
     // ---- choose the variant: exact (compile-time K-steps) when all hidden layers share a width we
     // instantiated, otherwise the smallest generic tile count that fits
@@ -282,13 +284,21 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
     const int prec = opt.fwd_precision;
     if (prec != UMNN_PRECISION_FP32 && a.m.n_linear - 1 >= 2) {
         a.ns = ns;
-        // f16x3: two fp16 pieces, three cross terms (fp32-level).  Shapes that family does not cover fall through to the three-piece
-        // bf16 kernels (the same accuracy class), then to fp32 MFMA -- never to the two-piece bf16 arithmetic.
+        // f16x3 (default): two fp16 pieces, three cross terms (fp32-level), the bf16x3 build queued behind it for tile groups whose
+        // pieces overflow (cc_forward_bf16.hip).  The deferred groups are marked IN the output (F, or z), so a launch whose marker
+        // output aliases one of its inputs runs bf16x3 outright -- the arithmetic its overflowing groups would get anyway.  Shapes
+        // that family does not cover fall through to the three-piece bf16 kernels (the same accuracy class), then to fp32 MFMA.
         if (prec == UMNN_PRECISION_F16X3) {
-            const int rc16 = umnn_launch_forward_f16(a, net, 2, P, ns, nb_steps, stream);
-            if (rc16 != UMNN_EUNSUPPORTED) return rc16;
+            const float* marker = F ? F : z;
+            if (marker == x || marker == x0 || marker == h) {
+                const int rc2 = umnn_launch_forward_bf16(a, net, 2, P, ns, nb_steps, stream, nullptr);
+                if (rc2 != UMNN_EUNSUPPORTED) return rc2;
+            } else {
+                const int rc16 = umnn_launch_forward_f16(a, net, 2, P, ns, nb_steps, stream, nullptr);
+                if (rc16 != UMNN_EUNSUPPORTED) return rc16;
+            }
         }
-        const int rc = umnn_launch_forward_bf16(a, net, prec == UMNN_PRECISION_BF16X3 ? 2 : 3, P, ns, nb_steps, stream);
+        const int rc = umnn_launch_forward_bf16(a, net, prec == UMNN_PRECISION_BF16X3 ? 2 : 3, P, ns, nb_steps, stream, nullptr);
         if (rc != UMNN_EUNSUPPORTED) return rc;
     }
     // TAIL is possible when every hidden layer has the same width H with 16(T-1) <= H <= 16(T-1)+3

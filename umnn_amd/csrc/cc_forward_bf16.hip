@@ -42,13 +42,71 @@ static const Bf16Variant kBf16Variants[] = {
 
 int umnn_launch_forward_p32(FwdArgs& a, const umnn_mlp* net, int nb_steps, hipStream_t stream);      // cc_forward_p32.hip
 
+// ---- overflow protocol of the fp16-piece forward (the library default) -------------------------------------------------------------
+// An fp16 piece overflows at 65520; the value it belongs to then reaches the quadrature sum of its integral as inf / NaN (every
+// product with an inf piece is inf or NaN and nothing downstream can make it finite again).  The fp16 build therefore checks that sum
+// once per tile group, in the epilogue: a group with a non-finite sum writes NOTHING but a NaN marker into its output slots, raises
+// the launch's flag word, and leaves its integrals to the bf16 build of the same kernel (bf16 pieces share fp32's exponent range),
+// which this launcher queues right behind the fp16 launch with the same group mapping (P, NS forced).  That second launch costs one
+// scalar load per workgroup when the flag is down (every benchmarked net); when it is up it recomputes exactly the marked groups --
+// on two bf16 pieces, i.e. those integrals come back at bf16x3 accuracy (~6e-6) instead of ~5e-7 -- and publishes them, the
+// one-pass log-likelihood rows included (a deferred group has not counted towards its rows yet).  NaN inputs take the same road and come
+// back NaN.  Flag words: a per-device ring of 64-bit words, launch generation g uses word g % 256, raised with atomicMax(word, g),
+// tested as word >= g -- no memset between launches, safe across streams, and a replayed hipGraph (g baked into its nodes) at worst
+// runs a fallback that finds no marked group.
+struct FwdOvfPlan { int mode; unsigned long long* flag; unsigned long long gen; };
+int umnn_ovf_slot(unsigned long long** flag, unsigned long long* gen);                                  // cc_api.hip
+#ifdef UMNN_FWD_PIECE_F16
+int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps, hipStream_t stream,
+                             const FwdOvfPlan* ovf);
+#endif
+
+// The planned launch itself.  fp16 build: the launch with ovf_mode = 1, then the bf16 build of the same plan queued as its fallback
+// (one profiling bracket around both, one launch note).  bf16 build: a plain launch, or (ovf) that queued fallback.
+static int launch_planned(fwd_bf16_kernel_t fn, const char* name, unsigned nblk, size_t lds_bytes, FwdBf16Args& args, FwdArgs& a,
+                          const umnn_mlp* net, int P, int ns, int nb_steps, hipStream_t stream, const FwdOvfPlan* ovf) {
+    args.f.ovf_mode = ovf ? ovf->mode : 0;
+    args.f.ovf_flag = ovf ? ovf->flag : nullptr;
+    args.f.ovf_gen = ovf ? ovf->gen : 0;
+#ifdef UMNN_FWD_PIECE_F16
+    umnn_prof_begin(stream);
+    hipLaunchKernelGGL(fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
+    const FwdOvfPlan second{2, ovf->flag, ovf->gen};
+    int rc = umnn_check(hipGetLastError(), "cc_fwd_f16 launch");
+    if (!rc) rc = umnn_launch_forward_bf16(a, net, 2, P, ns, nb_steps, stream, &second);
+    if (rc == UMNN_EUNSUPPORTED) rc = umnn_fail(UMNN_EUNSUPPORTED, "cc_fwd_f16: the bf16 build has no kernel for the plan of the fp16 launch");
+    umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * (double)a.NI);
+    umnn_note_launch(name);
+    return rc;
+#else
+    (void)P; (void)ns;
+    if (!ovf) umnn_prof_begin(stream);
+    hipLaunchKernelGGL(fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
+    if (!ovf) {
+        umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * (double)a.NI);
+        umnn_note_launch(name);
+    }
+    return umnn_check(hipGetLastError(), "cc_fwd_bf16 launch");
+#endif
+}
+
 // Returns 0 and launches, UMNN_EUNSUPPORTED (without setting the error text's prefix) if the shape does not fit
 // this kernel family (caller then uses the fp32-MFMA kernels), or another error code.
+// ovf (bf16 build only): non-null = this launch is the queued fallback of an fp16-piece launch -- P and ns are that launch's (forced),
+// no profiling bracket, no launch note.
 int FWD_LAUNCH(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int nb_steps,
-                             hipStream_t stream) {
+                             hipStream_t stream, const FwdOvfPlan* ovf) {
     const int L = a.m.n_linear - 1;
     const UmnnOptions& opt = umnn_options();
-    const bool p_forced = opt.fwd_p > 0, ns_forced = opt.fwd_ns > 0;
+#ifdef UMNN_FWD_PIECE_F16
+    FwdOvfPlan own{1, nullptr, 0};
+    if (int rc = umnn_ovf_slot(&own.flag, &own.gen)) return rc;
+    ovf = &own;
+    const bool fb = false;
+#else
+    const bool fb = ovf != nullptr;
+#endif
+    const bool p_forced = opt.fwd_p > 0 || fb, ns_forced = opt.fwd_ns > 0 || fb;
     int tmax = 0;
     for (int l = 1; l <= L; ++l) tmax = a.m.t_out[l] > tmax ? a.m.t_out[l] : tmax;
     int T = tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8;
@@ -100,11 +158,7 @@ int FWD_LAUNCH(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int n
                 args.f.ngroups = (unsigned)((a.NI + 16 * pick->p - 1) / (16 * pick->p));
                 const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
                 const unsigned nblk = (args.f.ngroups + gpb - 1) / gpb;
-                umnn_prof_begin(stream);
-                hipLaunchKernelGGL(pick->fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
-                umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * (double)a.NI);
-                umnn_note_launch(pick->name);
-                return umnn_check(hipGetLastError(), "cc_fwd_bf16 launch");
+                return launch_planned(pick->fn, pick->name, nblk, lds_bytes, args, a, net, pick->p, ns, nb_steps, stream, ovf);
             }
             args.f = a;         // (not launched: fall through to the generic plan)
         }
@@ -139,7 +193,7 @@ int FWD_LAUNCH(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int n
     // the 32x32x16 formulation of the flagship shape: opt-in (UMNN_FWD_PIPE=2 / option fwd_pipe = 2).  Same wall time as the
     // default at C3 with 10 % fewer cycles -- the chip clocks it lower (the kernel is power-bound)
 #ifndef UMNN_FWD_PIECE_F16
-    if (opt.fwd_pipe == 2 && exact && T == 4 && nparts == 2 && nrl == 13) {
+    if (opt.fwd_pipe == 2 && !fb && exact && T == 4 && nparts == 2 && nrl == 13) {
         const int rc = umnn_launch_forward_p32(a, net, nb_steps, stream);
         if (rc != UMNN_EUNSUPPORTED) return rc;
     }
@@ -164,9 +218,5 @@ int FWD_LAUNCH(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int n
     args.f.ngroups = (unsigned)((a.NI + 16 * P - 1) / (16 * P));
     const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
     const unsigned nblk = (args.f.ngroups + gpb - 1) / gpb;
-    umnn_prof_begin(stream);
-    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
-    umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * (double)a.NI);
-    umnn_note_launch(kname);
-    return umnn_check(hipGetLastError(), "cc_fwd_bf16 launch");
+    return launch_planned(kfn, kname, nblk, lds_bytes, args, a, net, P, ns, nb_steps, stream, ovf);
 }

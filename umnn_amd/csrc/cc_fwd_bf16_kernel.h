@@ -228,6 +228,8 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
     const int E = a.E, d = a.d, n = a.n;
     const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
     unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
+    // queued behind an fp16-piece launch as its overflow fallback: nothing to do unless that launch raised the flag (cc_fwd_shared.h)
+    if constexpr (!INV) { if (a.ovf_mode == 2 && *a.ovf_flag < a.ovf_gen) return; }
 
     stage_bf16_images<NPARTS, MERGE ? 1 : MERGE_REST ? 2 : 0>(m, args.pl.ks32, args.pl.off16, args.pl.half_in, lds16, tid, UMNN_BLOCK);
     __syncthreads();
@@ -236,7 +238,8 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
     const int sub = wid / ns, part = wid % ns;
     const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
     const unsigned grp = xcd_remap(blockIdx.x, gridDim.x) * gpb + sub;
-    const bool live = grp < a.ngroups;
+    bool live = grp < a.ngroups;
+    if constexpr (!INV) { if (a.ovf_mode == 2 && live) live = fwd_group_marked<P>(a, grp, p); }      // ... and then only the deferred groups
     const int k_lo = (int)(((long long)part * (n + 1)) / ns);
     const int k_hi = (int)(((long long)(part + 1) * (n + 1)) / ns);
 

@@ -30,7 +30,39 @@ struct FwdArgs {
     long long NI;      // B*d integrals
     int d, E, n, ns, inv_f;
     unsigned ngroups;  // tile groups (of 16*P integrals)
+    // fp16-piece launches and their queued bf16 fallback (cc_forward_bf16.hip, "overflow protocol" there).  ovf_mode 0: plain launch.
+    // 1 (the fp16 build): a tile group whose quadrature sum is not finite -- an overflowed fp16 piece always ends there -- writes
+    // nothing but a NaN into its slots of the MARKER output (F, or z for the flow entry points), does not count towards the one-pass
+    // log-likelihood, and raises *ovf_flag to ovf_gen.  2 (the bf16 build queued right behind it with the same group mapping): returns
+    // at once unless *ovf_flag >= ovf_gen, then recomputes exactly the groups whose marker slots hold a NaN and publishes them.
+    unsigned long long* ovf_flag;
+    unsigned long long ovf_gen;
+    int ovf_mode;
 };
+
+// the marker slot of integral q: element q of F when the launch writes F, else this integral's element of z
+__device__ __forceinline__ float* fwd_marker(const FwdArgs& a, long long q, long long* idx) {
+    if (a.F) { *idx = q; return a.F; }
+    const long long bi = q / a.d;
+    *idx = a.reverse_z ? bi * a.d + (a.d - 1 - (q - bi * a.d)) : q;
+    return a.z;
+}
+// ovf_mode 2: does any integral of this wave's tile group carry the marker?  (wave-uniform; lanes beyond NI re-read the last integral,
+// which belongs to the same -- the last -- group)
+template <int P>
+__device__ __forceinline__ bool fwd_group_marked(const FwdArgs& a, unsigned grp, int p) {
+    bool m = false;
+#pragma unroll
+    for (int pt = 0; pt < P; ++pt) {
+        long long q = ((long long)grp * P + pt) * 16 + p;
+        if (q >= a.NI) q = a.NI - 1;
+        long long idx;
+        float* mk = fwd_marker(a, q, &idx);
+        const float v = io_ld(mk, idx, a.x_bf16);
+        m = m || v != v;
+    }
+    return __any(m);
+}
 
 // Combine the node-range partials of the NS waves sharing a tile group (through LDS), then write F, f(x), f(x0)
 // and, for the flow entry point, z and log_jac.  Called by every wave of the workgroup (it contains a barrier).
@@ -62,7 +94,29 @@ __device__ __forceinline__ void fwd_epilogue(const FwdArgs& a, float* lds, float
             }
         }
     }
-    if (live && part == 0 && g == 0) {
+    // overflow protocol, fp16 build: a non-finite quadrature sum anywhere in the group defers the WHOLE group to the queued bf16 launch
+    bool deferred = false;
+    if (a.ovf_mode == 1) {
+        bool bad = false;
+        if (live && part == 0 && g == 0) {
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) bad = bad || (ok[pt] && !(__builtin_fabsf(Facc[pt]) < __builtin_inff()));
+        }
+        deferred = __any(bad);
+        if (deferred) {
+            if (g == 0 && part == 0) {
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt) {
+                    if (!ok[pt]) continue;
+                    long long idx;
+                    float* mk = fwd_marker(a, qv[pt], &idx);
+                    io_st(mk, idx, __builtin_nanf(""), a.x_bf16);
+                }
+            }
+            if (part == 0 && g == 0 && p == 0) atomicMax(a.ovf_flag, a.ovf_gen);
+        }
+    }
+    if (live && part == 0 && g == 0 && !deferred) {
 #pragma unroll
         for (int pt = 0; pt < P; ++pt) {
             if (!ok[pt]) continue;
@@ -97,7 +151,7 @@ __device__ __forceinline__ void fwd_epilogue(const FwdArgs& a, float* lds, float
         const int lane = 16 * g + p;
 #pragma unroll
         for (int pt = 0; pt < P; ++pt) {
-            const bool writer = live && part == 0 && g == 0 && ok[pt];
+            const bool writer = live && part == 0 && g == 0 && ok[pt] && !deferred;
             const long long q = qv[pt];
             const long long bi = q / d;
             const int i = (int)(q - bi * d);

@@ -17,7 +17,7 @@ int umnn_num_cus();                                      // CU count of the CURR
 // Process-wide launch options.  The UMNN_* environment variables are read ONCE (first use, or umnn_reload_env());
 // after that every launch reads plain atomics -- no getenv on the launch path.  -1 = "auto" for the tuning knobs.
 struct UmnnOptions {
-    std::atomic<int> fwd_precision{UMNN_PRECISION_BF16X3};   // UMNN_FWD_PRECISION = fp32 | bf16x3 | bf16x6 | f16x3
+    std::atomic<int> fwd_precision{UMNN_PRECISION_F16X3};    // UMNN_FWD_PRECISION = fp32 | bf16x3 | bf16x6 | f16x3 (default)
     std::atomic<int> bwd_precision{UMNN_PRECISION_BF16X3};   // UMNN_BWD_PRECISION = fp32 | bf16x3
     std::atomic<int> fwd_p{-1};          // UMNN_FWD_P: point tiles per wave (1|2)
     std::atomic<int> fwd_ns{-1};         // UMNN_FWD_NS: node-range split (1|2|4)
