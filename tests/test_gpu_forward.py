@@ -282,12 +282,14 @@ def test_in_kernel_inversion_round_trip(d, hid, E, n, nb_flow, B, dev, precision
             warnings.simplefilter("ignore", RuntimeWarning)      # (exact-products modes announce the host-driven search once)
             x_inv = m.invert(z, iter=iters)
         wide = max(hid) > 63
-        if precision == "bf16x3" or not wide:
+        if precision in ("bf16x3", "f16x3") or not wide:
             # one launch per dimension and block.  Under "exact products" (bf16x6 / fp32) nets of up to four tiles per layer run the
-            # same in-kernel search with three bf16 pieces / six cross terms (round 4: PARTS=3 variants)
+            # same in-kernel search with three bf16 pieces / six cross terms (round 4: PARTS=3 variants); f16x3 (the default) runs
+            # it on two fp16 pieces -- fp32-level products -- for every net, its bf16x3 build queued as the overflow fallback (round 5)
             assert _lib.lib().umnn_launch_count() - before == nb_flow * d
             name = _lib.lib().umnn_last_kernel_name().decode()
-            assert "cc_invert_bf16" in name and (("PARTS=3" in name) == (precision != "bf16x3")), name
+            assert ("cc_invert_f16" if precision == "f16x3" else "cc_invert_bf16") in name, name
+            assert ("PARTS=3" in name) == (precision in ("bf16x6", "fp32")), name
             if hid[0] == 100 and len(hid) == 5:
                 assert "T1=7,TREST=4" in name
         else:

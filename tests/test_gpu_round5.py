@@ -239,3 +239,33 @@ def test_f16x3_is_fp32_level_on_the_benchmarked_launch(dev, restore_precision):
     print("forward error, C3 launch: against float64 (32 sampled rows)", e64, "| against the exact-fp32 kernels (all rows)", e32)
     assert max(e64.values()) < 2e-6, e64
     assert e32["f16x3"] < 6e-7 and e32["bf16x3"] > 2 * e32["f16x3"], e32      # (measured 2.9e-7 / 7.7e-7 at default-initialised weights)
+
+
+def test_in_kernel_sampling_survives_overflow(dev, restore_precision):
+    """umnn_flow_invert_dim under the default arithmetic: the bracket search on fp16 pieces, a sample any of whose candidate integrals
+    overflowed marked with a NaN in x_inv[:, j] and redone by the queued bf16x3 build.  Weights scaled so that candidates near the
+    ends of the [-50, 50] bracket overflow the first hidden layer for every sample: x_inv is finite and bit-equal to the bf16x3
+    search; with benign weights the fp16 search agrees with the bf16x3 one to the search's own resolution."""
+    import umnn_amd
+    from umnn_amd import _lib
+    torch.manual_seed(6)
+    model = umnn_amd.UMNNMAFFlow(nb_flow=1, nb_in=4, hidden_derivative=[50] * 4, hidden_embedding=[32, 32], embedding_s=8,
+                                 nb_steps=30, solver="CCParallel").to(dev).eval()
+    z = torch.randn(96, 4, device=dev)
+    outs = {}
+    with torch.no_grad():
+        for mode in ("bf16x3", "f16x3"):
+            umnn_amd.set_forward_precision(mode)
+            n0 = _lib.lib().umnn_launch_count()
+            outs[mode] = model.invert(z, iter=10)
+            assert _lib.lib().umnn_launch_count() - n0 == 4
+        assert _kname().startswith("cc_invert_f16<"), _kname()
+        assert float((outs["f16x3"] - outs["bf16x3"]).abs().median()) < 1e-3
+        lin0 = [m for m in model.nets[0].net.parallel_nets.net if isinstance(m, torch.nn.Linear)][0]
+        lin0.weight[:, 0] *= 3e4                  # a_1 = W1[:, 0] * t + c: |t| <= 50 -> up to ~2e5 for most units
+        hot = {}
+        for mode in ("bf16x3", "f16x3"):
+            umnn_amd.set_forward_precision(mode)
+            hot[mode] = model.invert(z, iter=10)
+    assert torch.isfinite(hot["f16x3"]).all()
+    assert torch.equal(hot["f16x3"], hot["bf16x3"])

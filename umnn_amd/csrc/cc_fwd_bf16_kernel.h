@@ -229,7 +229,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
     const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
     unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
     // queued behind an fp16-piece launch as its overflow fallback: nothing to do unless that launch raised the flag (cc_fwd_shared.h)
-    if constexpr (!INV) { if (a.ovf_mode == 2 && *a.ovf_flag < a.ovf_gen) return; }
+    if (a.ovf_mode == 2 && *a.ovf_flag < a.ovf_gen) return;
 
     stage_bf16_images<NPARTS, MERGE ? 1 : MERGE_REST ? 2 : 0>(m, args.pl.ks32, args.pl.off16, args.pl.half_in, lds16, tid, UMNN_BLOCK);
     __syncthreads();
@@ -239,7 +239,10 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
     const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
     const unsigned grp = xcd_remap(blockIdx.x, gridDim.x) * gpb + sub;
     bool live = grp < a.ngroups;
-    if constexpr (!INV) { if (a.ovf_mode == 2 && live) live = fwd_group_marked<P>(a, grp, p); }      // ... and then only the deferred groups
+    if (a.ovf_mode == 2 && live) {                                                                    // ... and then only the deferred groups
+        if constexpr (INV) { const float v = a.inv_x[(long long)grp * d + a.inv_j]; live = v != v; }   // (tile = sample: its slot of x_inv[:, j])
+        else live = fwd_group_marked<P>(a, grp, p);
+    }
     const int k_lo = (int)(((long long)part * (n + 1)) / ns);
     const int k_hi = (int)(((long long)(part + 1) * (n + 1)) / ns);
 
@@ -557,6 +560,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
             inv_scale = __expf(a.scaling[a.inv_j]);
         }
         const int rounds = INV ? a.inv_iters : 1;
+        bool inv_bad = false;            // (fp16 pieces: some candidate integral of some round was not finite -- an overflowed piece)
         for (int round = 0; round < rounds; ++round) {
         if constexpr (INV) {
             xv[0] = __fadd_rn(__fmul_rn(frac, br_right - br_left), br_left);      // x_range * (right - left) + left
@@ -713,6 +717,7 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
             }
         }
         if constexpr (INV) {
+            if constexpr (PC_F16) inv_bad = inv_bad || (p < 10 && !(__builtin_fabsf(Facc[0]) < __builtin_inff()));
             // image of every candidate, then argmin_p |z_est - target| over the ten candidate lanes (ties: lower p)
             const float z_est = inv_scale * (inv_off + Facc[0] * dxv[0] * 0.5f);
             float dist = p < 10 ? fabsf(z_est - inv_target) : __builtin_inff();
@@ -735,7 +740,12 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
         }
         }   // rounds
         if constexpr (INV) {
-            if (ok[0] && lane == 0) a.inv_x[qv[0] * d + a.inv_j] = br_best;
+            // overflow protocol (cc_invert.hip): the sample is left to the queued bf16 build, its slot marked with a NaN
+            const bool defer = a.ovf_mode == 1 && __any(inv_bad);
+            if (ok[0] && lane == 0) {
+                a.inv_x[qv[0] * d + a.inv_j] = defer ? __builtin_nanf("") : br_best;
+                if (defer) atomicMax(a.ovf_flag, a.ovf_gen);
+            }
         }
         }
     }

@@ -9,16 +9,36 @@
 // layer run the same search with THREE bf16 pieces and six cross terms (PARTS=3: fp32-level products, ~4e-7 on F -- the
 // matrix-core arithmetic of the bf16x6 forward mode; there is no fp32-MFMA form of this kernel); wider nets keep the host-driven
 // search on the forward kernels of that mode (8 tiles x 3 pieces do not fit the register file).
+// This file is compiled twice, like cc_forward_bf16.hip: as is (bf16 pieces; exports umnn_flow_invert_dim) and through cc_invert_f16.hip
+// with -DUMNN_FWD_PIECE_F16 (fp16 pieces: the search of the library's default arithmetic, f16x3).  The fp16 build follows the
+// forward's overflow protocol (cc_forward_bf16.hip): a sample for which any candidate integral of any round was not finite gets a NaN
+// in its slot of x_inv[:, j] and raises the launch's flag word; the two-piece bf16 build of the same search, queued right behind it,
+// returns at once when the flag is down and otherwise redoes exactly the samples whose slot holds the NaN.
 #include "cc_fwd_bf16_kernel.h"
 using namespace UMNN_FWD_NS;
+#ifdef UMNN_FWD_PIECE_F16
+#define INV_KNAME "cc_invert_f16"
+#define INV_IMPL umnn_invert_impl_f16
+#else
+#define INV_KNAME "cc_invert_bf16"
+#define INV_IMPL umnn_invert_impl_bf16
+#endif
+struct InvOvfPlan { int mode; unsigned long long* flag; unsigned long long gen; };
+int umnn_ovf_slot(unsigned long long** flag, unsigned long long* gen);                                  // cc_api.hip
+int umnn_invert_impl_bf16(const umnn_mlp* net, const float* h, const float* z, const float* scaling, const float* cc_w, const float* cc_s,
+                          int nb_steps, long long B, int d, int E, int j, int iters, float* x_inv, hipStream_t stream, int nparts,
+                          const InvOvfPlan* ovf);
+int umnn_invert_impl_f16(const umnn_mlp* net, const float* h, const float* z, const float* scaling, const float* cc_w, const float* cc_s,
+                         int nb_steps, long long B, int d, int E, int j, int iters, float* x_inv, hipStream_t stream, int nparts,
+                         const InvOvfPlan* ovf);
 
 typedef void (*inv_kernel_t)(const FwdBf16Args);
 struct InvVariant { int tmax, exact, nrl, nparts; inv_kernel_t fn; const char* name; };
-#define INV_VARIANT(T, EX, NR) { T, EX, NR, 2, cc_fwd_bf16_kernel<T, 2, 1, (EX) != 0, NR, false, true>, "cc_invert_bf16<T=" #T ",EXACT=" #EX ",LIVE=" #NR ">" }
-#define INV_VARIANT3(T, EX, NR) { T, EX, NR, 3, cc_fwd_bf16_kernel<T, 3, 1, (EX) != 0, NR, false, true>, "cc_invert_bf16<T=" #T ",PARTS=3,EXACT=" #EX ",LIVE=" #NR ">" }
+#define INV_VARIANT(T, EX, NR) { T, EX, NR, 2, cc_fwd_bf16_kernel<T, 2, 1, (EX) != 0, NR, false, true>, INV_KNAME "<T=" #T ",EXACT=" #EX ",LIVE=" #NR ">" }
+#define INV_VARIANT3(T, EX, NR) { T, EX, NR, 3, cc_fwd_bf16_kernel<T, 3, 1, (EX) != 0, NR, false, true>, INV_KNAME "<T=" #T ",PARTS=3,EXACT=" #EX ",LIVE=" #NR ">" }
 // wide first hidden layer over a narrow rest (MNISTExperiment's integrand: sampling d = 784 images is 3 920 of these launches)
 struct InvWideFirst { int t1, nrl; inv_kernel_t fn; const char* name; };
-#define INV_WIDE_FIRST(T, NR) { T, NR, cc_fwd_bf16_kernel<T, 2, 1, true, NR, false, true, 4>, "cc_invert_bf16<T1=" #T ",TREST=4,LIVE=" #NR ">" }
+#define INV_WIDE_FIRST(T, NR) { T, NR, cc_fwd_bf16_kernel<T, 2, 1, true, NR, false, true, 4>, INV_KNAME "<T1=" #T ",TREST=4,LIVE=" #NR ">" }
 static const InvWideFirst kInvWideFirst[] = { INV_WIDE_FIRST(5, 13), INV_WIDE_FIRST(6, 13), INV_WIDE_FIRST(7, 13), INV_WIDE_FIRST(8, 13),
                                               INV_WIDE_FIRST(5, 0), INV_WIDE_FIRST(6, 0), INV_WIDE_FIRST(7, 0), INV_WIDE_FIRST(8, 0) };
 static const InvVariant kInvVariants[] = {
@@ -26,29 +46,44 @@ static const InvVariant kInvVariants[] = {
     INV_VARIANT(7, 1, 26), INV_VARIANT(7, 1, 0),       // 100-wide toy nets
     INV_VARIANT(5, 1, 0), INV_VARIANT(6, 1, 0), INV_VARIANT(8, 1, 0),
     INV_VARIANT(2, 0, 0), INV_VARIANT(4, 0, 0), INV_VARIANT(8, 0, 0),   // generic (runtime tile counts): mixed widths, e.g. 100-50-50-50-50
+#ifndef UMNN_FWD_PIECE_F16
     // three pieces / six cross terms (fwd_precision = fp32 | bf16x6): nets of up to four tiles per layer
     INV_VARIANT3(4, 1, 13), INV_VARIANT3(4, 1, 0), INV_VARIANT3(2, 0, 0), INV_VARIANT3(4, 0, 0),
+#endif
 };
 
-extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const float* z, const float* scaling,
-                                    const float* cc_w, const float* cc_s, int nb_steps,
-                                    long long B, int d, int E, int j, int iters, float* x_inv, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+// One launch of the search (see the file header); ovf: bf16 build only -- non-null = the queued fallback of an fp16-piece launch.
+int INV_IMPL(const umnn_mlp* net, const float* h, const float* z, const float* scaling, const float* cc_w, const float* cc_s,
+             int nb_steps, long long B, int d, int E, int j, int iters, float* x_inv, hipStream_t stream, int nparts,
+             const InvOvfPlan* ovf) {
     FwdBf16Args args;
     FwdArgs& a = args.f;
     int tmax = 0, ksu = 0;
     if (int rc = umnn_prepare_mlp(net, E, &a.m, &tmax, &ksu)) return rc;
-    if (nb_steps < 1 || iters < 1) return umnn_fail(UMNN_EINVAL, "invert: nb_steps and iters must be >= 1");
-    if (B < 0 || d < 1 || j < 0 || j >= d) return umnn_fail(UMNN_EINVAL, "invert: B >= 0, d >= 1, 0 <= j < d");
-    if (B == 0) return 0;
-    if (!h || !z || !scaling || !cc_w || !cc_s || !x_inv) return umnn_fail(UMNN_EINVAL, "invert: null pointer");
     const int L = a.m.n_linear - 1;
-    if (L < 2) return umnn_fail(UMNN_EUNSUPPORTED, "invert: the matrix-core kernels need at least two hidden layers");
-    // fwd_precision = fp32 / bf16x6 ("exact products everywhere"): the three-piece variants, which exist for up to four tiles per
-    // layer; wider nets keep the caller's host-driven search on the forward kernels of that mode -- never a silent ~6e-6 search
-    const int nparts = umnn_options().fwd_precision == UMNN_PRECISION_BF16X3 ? 2 : 3;      // (f16x3 counts as an exact-products mode here)
-    if (nparts == 3 && tmax > 4)
-        return umnn_fail(UMNN_EUNSUPPORTED, "invert: the fp32-level in-kernel search exists for nets of at most four tiles per layer; the forward precision asks for exact products");
+#ifdef UMNN_FWD_PIECE_F16
+    InvOvfPlan own{1, nullptr, 0};
+    if (int rc = umnn_ovf_slot(&own.flag, &own.gen)) return rc;
+    ovf = &own;
+#endif
+    a.ovf_mode = ovf ? ovf->mode : 0; a.ovf_flag = ovf ? ovf->flag : nullptr; a.ovf_gen = ovf ? ovf->gen : 0;
+    // the planned launch: fp16 build = the launch, then the two-piece bf16 build of the same search queued as its fallback
+    auto launch = [&](inv_kernel_t fn, const char* name, unsigned nblk, size_t lds_bytes) -> int {
+        const bool queued = ovf && ovf->mode == 2;
+        if (!queued) umnn_prof_begin(stream);
+        hipLaunchKernelGGL(fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
+        int rc = umnn_check(hipGetLastError(), "cc_invert launch");
+#ifdef UMNN_FWD_PIECE_F16
+        const InvOvfPlan second{2, ovf->flag, ovf->gen};
+        if (!rc) rc = umnn_invert_impl_bf16(net, h, z, scaling, cc_w, cc_s, nb_steps, B, d, E, j, iters, x_inv, stream, 2, &second);
+#endif
+        if (!queued) {
+            // algorithmic work: iters rounds x 10 candidate integrals per sample
+            umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * 10.0 * iters * (double)B);
+            umnn_note_launch(name);
+        }
+        return rc;
+    };
     a.x0 = nullptr; a.x = nullptr; a.h = h; a.ccw = cc_w; a.ccs = cc_s;
     a.F = a.fx = a.fx0 = nullptr; a.scaling = scaling; a.z = nullptr; a.logjac = nullptr; a.logjac_in = nullptr;
     a.reverse_z = 0; a.ll = nullptr; a.row_cnt = nullptr; a.ll_first = a.ll_last = 0;
@@ -82,11 +117,7 @@ extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const f
                 if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
                 a.ngroups = (unsigned)B;
                 const unsigned nblk = (a.ngroups + UMNN_WAVES_PER_BLOCK - 1) / UMNN_WAVES_PER_BLOCK;
-                umnn_prof_begin(stream);
-                hipLaunchKernelGGL(pick->fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
-                umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * 10.0 * iters * (double)B);
-                umnn_note_launch(pick->name);
-                return umnn_check(hipGetLastError(), "cc_invert launch");
+                return launch(pick->fn, pick->name, nblk, lds_bytes);
             }
             return umnn_fail(UMNN_EUNSUPPORTED, "invert: weight images exceed 160 KiB of LDS");
         }
@@ -131,10 +162,33 @@ extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const f
     if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
     a.ngroups = (unsigned)B;                                  // one tile (= one sample) per wave
     const unsigned nblk = (a.ngroups + UMNN_WAVES_PER_BLOCK - 1) / UMNN_WAVES_PER_BLOCK;
-    umnn_prof_begin(stream);
-    hipLaunchKernelGGL(pick->fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
-    // algorithmic work: iters rounds x 10 candidate integrals per sample
-    umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * 10.0 * iters * (double)B);
-    umnn_note_launch(pick->name);
-    return umnn_check(hipGetLastError(), "cc_invert launch");
+    return launch(pick->fn, pick->name, nblk, lds_bytes);
 }
+
+#ifndef UMNN_FWD_PIECE_F16
+extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const float* z, const float* scaling,
+                                    const float* cc_w, const float* cc_s, int nb_steps,
+                                    long long B, int d, int E, int j, int iters, float* x_inv, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!net) return umnn_fail(UMNN_EINVAL, "net is null");
+    if (nb_steps < 1 || iters < 1) return umnn_fail(UMNN_EINVAL, "invert: nb_steps and iters must be >= 1");
+    if (B < 0 || d < 1 || j < 0 || j >= d) return umnn_fail(UMNN_EINVAL, "invert: B >= 0, d >= 1, 0 <= j < d");
+    {
+        MlpDev m; int tmax = 0, ksu = 0;
+        if (int rc = umnn_prepare_mlp(net, E, &m, &tmax, &ksu)) return rc;
+        if (B == 0) return 0;
+        if (!h || !z || !scaling || !cc_w || !cc_s || !x_inv) return umnn_fail(UMNN_EINVAL, "invert: null pointer");
+        if (m.n_linear - 1 < 2) return umnn_fail(UMNN_EUNSUPPORTED, "invert: the matrix-core kernels need at least two hidden layers");
+        // f16x3 (default): the search on two fp16 pieces (fp32-level products) with its queued bf16x3 fallback.  bf16x3: two bf16 pieces.
+        // fwd_precision = fp32 / bf16x6 ("exact products everywhere"): the three-piece variants, which exist for up to four tiles per
+        // layer; wider nets keep the caller's host-driven search on the forward kernels of that mode -- never a silent ~6e-6 search
+        const int prec = umnn_options().fwd_precision;
+        if (prec == UMNN_PRECISION_F16X3)
+            return umnn_invert_impl_f16(net, h, z, scaling, cc_w, cc_s, nb_steps, B, d, E, j, iters, x_inv, stream, 2, nullptr);
+        const int nparts = prec == UMNN_PRECISION_BF16X3 ? 2 : 3;
+        if (nparts == 3 && tmax > 4)
+            return umnn_fail(UMNN_EUNSUPPORTED, "invert: the fp32-level in-kernel search exists for nets of at most four tiles per layer; the forward precision asks for exact products");
+        return umnn_invert_impl_bf16(net, h, z, scaling, cc_w, cc_s, nb_steps, B, d, E, j, iters, x_inv, stream, nparts, nullptr);
+    }
+}
+#endif
