@@ -50,7 +50,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (
 # sources that define the dominant forward kernel: profiles/hbm_traffic.json is only trusted while their hash matches
 # (the translation unit and the two headers that hold the kernel's code; cc_common.h / cc_bf16.h also carry helpers of the BACKWARD
 # kernels -- hashing them made round 3's record go stale over an unrelated change)
-TRAFFIC_SOURCES = ["umnn_amd/csrc/cc_forward_bf16.hip", "umnn_amd/csrc/cc_fwd_bf16_kernel.h", "umnn_amd/csrc/cc_fwd_shared.h"]
+TRAFFIC_SOURCES = ["umnn_amd/csrc/cc_forward_bf16.hip", "umnn_amd/csrc/cc_forward_f16.hip", "umnn_amd/csrc/cc_fwd_bf16_kernel.h",
+                   "umnn_amd/csrc/cc_fwd_shared.h", "umnn_amd/csrc/cc_bf16.h", "umnn_amd/csrc/cc_forward.hip"]
 
 
 def kernel_source_hash():
@@ -246,7 +247,7 @@ def main():
                     help="storage of the [B, E*d] embedding between conditioner and quadrature kernels (bf16: configuration C4's "
                          "storage mode -- the kernels load bf16, arithmetic stays fp32; reported in config.embedding_storage)")
     ap.add_argument("--precision", default="", choices=["", "fp32", "bf16x3", "bf16x6", "f16x3"],
-                    help="forward arithmetic (default: the library default, bf16x3)")
+                    help="forward arithmetic (default: the library default, f16x3 -- two fp16 pieces, fp32-level, queued bf16x3 overflow fallback)")
     args = ap.parse_args()
 
     from umnn_amd import _lib, sharding
@@ -382,14 +383,17 @@ def main():
 
     # for the record: the same workload in the reference's own arithmetic (exact fp32 products on the fp32 MFMA kernels, fp32
     # conditioner GEMMs) and in the fp32-accurate middle mode on the bf16 matrix cores (three bf16 pieces, six cross terms: ~4e-7 on F)
-    exact = bf16x6 = f16x3 = None
+    exact = bf16x6 = f16x3 = bf16x3 = None
     if extras and precision != "fp32":
         exact = side_record("fp32", PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA", "fp32 F.linear")
-    if extras and precision == "bf16x3":
+    if extras and precision in ("bf16x3", "f16x3"):
         bf16x6 = side_record("bf16x6", PEAK_BF16_MFMA_TFLOPS, "bf16 dense MFMA", "K-concatenated bf16 GEMMs (three products)")
-        # ... and on two fp16 pieces / three cross terms: the same fp32-level accuracy at the two-piece cost (fp16 exponent range:
-        # an opt-in mode, umnn_amd.set_precision("f16x3"))
-        f16x3 = side_record("f16x3", PEAK_BF16_MFMA_TFLOPS, "fp16 dense MFMA (same rate as bf16)", "K-concatenated bf16 GEMMs (three products)")
+        # ... and the other two-piece arithmetic: f16x3 (the default since round 5: fp32-level, fp16 pieces + queued bf16x3 overflow
+        # fallback) when the run is bf16x3, bf16x3 (the default until round 4: ~6e-6 on F) when the run is f16x3
+        if precision == "bf16x3":
+            f16x3 = side_record("f16x3", PEAK_BF16_MFMA_TFLOPS, "fp16 dense MFMA (same rate as bf16)", "K-concatenated bf16 GEMMs (three products)")
+        else:
+            bf16x3 = side_record("bf16x3", PEAK_BF16_MFMA_TFLOPS, "bf16 dense MFMA", "K-concatenated bf16 GEMMs (three products)")
     # the un-sharded C3 batch on ONE GPU (65536 rows): the anchor the 8-GPU point of the sharded run is compared with
     full = None
     if extras and args.workload == "bsds300" and not args.rows and not args.graph:
@@ -495,6 +499,8 @@ def main():
             out["bf16x6"] = bf16x6
         if f16x3 is not None:
             out["f16x3"] = f16x3
+        if bf16x3 is not None:
+            out["bf16x3"] = bf16x3
         if full is not None:
             out["full_batch_n1"] = full
         if args.mode == "train":

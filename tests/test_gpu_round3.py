@@ -468,16 +468,13 @@ def test_weight_stationary_backward_is_only_taken_for_large_unsplit_batches(dev)
 
 def test_weight_stationary_backward_at_the_benchmarked_size(dev):
     """The configuration ``bench.py --mode train`` times (8192 x 63 integrals per block, n = 100, 50-wide net): every workgroup of
-    the pipeline streams ~126 tiles x 102 elements.  Both workgroup pipelines against the software-pipelined loop on the same
-    inputs, bit-reproducible.  The bf16 pipeline (same six-term recompute as the loop) agrees to 5e-6.  The fp16-piece pipeline
-    -- the default at this size -- is another fp32-level evaluation, and ANY two of those decide some of the 3e8 LeakyReLU kinks of
-    this launch differently, each such decision moving its own row of d_h (and of d_x through g_fx . df/dx) by up to a few per
-    cent of the largest entry and d_theta by up to ~2e-4.  Measured against the loop (tools/kink_rows.py, this very launch): the
-    EXACT-fp32 kernels differ in 191 rows of d_h by more than 1e-5 (58 by more than 1e-4) and in d_theta by 2.4e-4; the fp16-piece
-    pipeline in 467 rows (124), d_theta 2.4e-4 -- 2.4x the kink noise of fp32 arithmetic (two 11-bit pieces per operand; before
-    the low weight pieces were scaled out of the subnormal range: 624).  Held to: fewer than 900 of the 8192 rows of d_h off by
-    1e-5, median row error < 5e-6, d_theta within 5e-4; tests/test_gpu_round4.py checks at smaller sizes that EVERY differing row
-    has a pre-activation inside the rounding noise (float64 margins), which this size is too large to do in numpy."""
+    the pipeline streams ~126 tiles x 102 elements.  The bf16 pipeline against the software-pipelined loop on the same inputs
+    (same six-term recompute: agreement to 5e-6, d_h 2e-5), both workgroup pipelines bit-reproducible and on the kernels the
+    defaults name.  What the fp16-piece pipeline -- the default at this size -- is held to is FLOAT64 TRUTH, not a sibling kernel:
+    tests/test_gpu_round5.py::test_default_backward_against_float64_truth_at_the_benchmarked_c3_size (same shape and seed).  Round
+    4 bounded it by 5e-4 against the loop here; measured against truth in round 5 it is the LOOP's arithmetic (six-term recompute,
+    three-term bf16 delta / dW) that sits 2.4e-4 from the float64 d_theta, the fp16 pipeline 5.8e-5, the exact-fp32 kernels 3.1e-5,
+    a float32 ATen run of the reference's own algorithm 2.7e-5 (profiles/r05/bwd_truth64_c3.txt)."""
     import umnn_amd
     from umnn_amd import _lib
     from umnn_amd import integral as I
@@ -502,12 +499,6 @@ def test_weight_stationary_backward_at_the_benchmarked_size(dev):
         assert np.isfinite(b_).all() and np.isfinite(c_).all(), nm
         # (at this size a handful of the 3e8 kink decisions differ between any two summation orders: dh is compared at 2e-5)
         assert U.scaled_err(b_, a_) < (2e-5 if nm == "dh" else 5e-6), (nm, U.scaled_err(b_, a_))
-        if nm == "dtheta":
-            assert U.scaled_err(c_, a_) < 5e-4, U.scaled_err(c_, a_)
-        else:
-            row_err = np.abs(c_ - a_).max(axis=1) / np.abs(a_).max()
-            cap = 16 if nm == "dx" else 900
-            assert (row_err > 1e-5).sum() <= cap and np.median(row_err) < 5e-6, (nm, int((row_err > 1e-5).sum()), float(row_err.max()))
 
 
 @pytest.mark.parametrize("hid, with_gfx", [([100, 50, 50, 50, 50], True), ([112, 48, 60, 36, 50], False)])

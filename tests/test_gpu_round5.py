@@ -269,3 +269,124 @@ def test_in_kernel_sampling_survives_overflow(dev, restore_precision):
             hot[mode] = model.invert(z, iter=10)
     assert torch.isfinite(hot["f16x3"]).all()
     assert torch.equal(hot["f16x3"], hot["bf16x3"])
+
+
+# ---- the default backward against FLOAT64 TRUTH at the benchmarked sizes -------------------------------------
+def test_truth64_evaluator_matches_the_pinned_oracle(dev):
+    """tests/_truth64.py (torch, chunked, any dtype) against what pins everything else: oracle.integrate_backward in float64 on the g8
+    REFERENCE fixture (280 x 63, 31-50^4-1, the reference's own ParallelNeuralIntegral.backward produced its float32 outputs), plus
+    the g_fx cotangent against oracle.integrand_vjp.  Float64 both sides: agreement to 1e-7 -- not 1e-15 because the evaluator (like the
+    reference and the kernels) integrates with the float32-ROUNDED Clenshaw-Curtis tables of compute_cc_weights, the oracle's float64
+    mode with float64 tables (2e-8 apart)."""
+    from tests import _truth64 as T
+    from tests.test_gpu_forward import build_integrand, t
+    G = U.load("g8_ws_d63")
+    net = build_integrand(G, dev)
+    n = int(G["n"])
+    rs = np.random.RandomState(0)
+    gfx = rs.randn(*G["x"].shape).astype(np.float32)
+    got = T.backward_reference(net, t(G["x0"], dev), t(G["x"], dev), t(G["h"], dev), t(G["g"], dev), t(gfx, dev), n, chunk=64)
+    net64 = U.net_from_g2(G, np.float64)
+    a = [G[k].astype(np.float64) for k in ("x0", "x", "h", "g")]
+    dx0, dx, dh, _, _, flat = O.integrate_backward(net64, a[0], a[1], a[2], n, a[3])
+    vx, vh, vflat = O.integrand_vjp(net64, a[1], a[2], gfx.astype(np.float64))
+    for nm, g_, r_ in (("dx0", got[0], dx0), ("dx", got[1], dx + vx), ("dh", got[2], dh + vh), ("dtheta", got[3], flat + vflat)):
+        assert U.scaled_err(g_.cpu().numpy(), r_) < 1e-7, (nm, U.scaled_err(g_.cpu().numpy(), r_))
+    # and the reference's float32 outputs of the fixture sit where a float32 run of this evaluator sits (kink noise included)
+    assert U.scaled_err(dx0, G["dx0_par"]) < 1e-5
+
+
+def _truth_case(dev, B, d, hid, n, seed, wscale=1.0, gfx_scale=1.0):
+    import umnn_amd
+    from umnn_amd.nets import mlp_spec
+    torch.manual_seed(seed)
+    net = umnn_amd.IntegrandNetwork(d, 31, hid, 1)
+    if wscale != 1.0:
+        with torch.no_grad():
+            for mod in net.net:
+                if isinstance(mod, torch.nn.Linear):
+                    mod.weight.mul_(wscale)
+    net.to(dev)
+    x, h = torch.randn(B, d, device=dev), torch.randn(B, 30 * d, device=dev)
+    g, gf = torch.randn(B, d, device=dev), torch.randn(B, d, device=dev) * gfx_scale
+    return net, mlp_spec(net), x, h, g, gf
+
+
+def backward_truth_report(dev, B, d, hid, n, seed, wscale, gfx_scale, chunk, routes):
+    """Every route's (d_x0, d_x, d_h, d_theta) error against the float64 evaluator + the reference's own arithmetic (the same evaluator
+    in float32: ATen fp32 GEMMs over the materialised nodes).  -> {route: {tensor: scaled error}}, kernel names."""
+    from tests import _truth64 as T
+    from umnn_amd import integral as I, _lib
+    net, spec, x, h, g, gf = _truth_case(dev, B, d, hid, n, seed, wscale, gfx_scale)
+    truth = T.backward_reference(net, None, x, h, g, gf, n, torch.float64, chunk)
+    ref32 = T.backward_reference(net, None, x, h, g, gf, n, torch.float32, chunk)
+    names = ("dx0", "dx", "dh", "dtheta")
+    rep = {"reference arithmetic (ATen float32, materialised nodes)": {k: T.scaled_err(o, r) for k, o, r in zip(names, ref32, truth)}}
+    kernels = {}
+    for key, opts, prec in routes:
+        _lib.set_backward_precision(prec)
+        try:
+            with _lib.options(**opts):
+                out = I.hip_backward(spec, None, x, h, g, gf, n)
+                torch.cuda.synchronize()
+                kernels[key] = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
+        finally:
+            _lib.set_backward_precision("bf16x3")
+        rep[key] = {k: T.scaled_err(o, r) for k, o, r in zip(names, out, truth)}
+        # d_h rows that are off by more than 1e-4 of the largest entry (kink decisions: each moves its own row only)
+        row = (out[2].double() - truth[2]).abs().amax(dim=1) / truth[2].abs().max()
+        rep[key]["dh_rows_over_1e-4"] = int((row > 1e-4).sum())
+        rep[key]["dh_row_median"] = float(row.median())
+    return rep, kernels
+
+
+C3_ROUTES = (("default (fp16-piece pipeline)", {}, "bf16x3"),
+             ("six-term bf16 pipeline", {"bwd_ws16": 0}, "bf16x3"),
+             ("exact-fp32 kernels", {}, "fp32"))
+
+
+def test_default_backward_against_float64_truth_at_the_benchmarked_c3_size(dev):
+    """8192 x 63 integrals x 101 nodes, 31-50^4-1 (what `bench.py --mode train` times per block), g_fx on.  d_theta of the library
+    default (cc_bwd_ws16_kernel: fp16 pieces) against the float64 evaluator of the reference algorithm, beside the exact-fp32 kernels
+    and a float32 run of the reference's own materialised algorithm against the same truth.  At 5.2e7 node evaluations x 200 hidden
+    units every float32 evaluation -- the reference's included -- decides some LeakyReLU kinks differently from float64, so the
+    bound is truth-anchored in two ways: an absolute one, and `no worse than 1.5x the exact-fp32 kernels / the reference's own
+    float32 arithmetic` (numbers: profiles/r05/bwd_truth64_c3.txt, written by tools/bwd_truth64_sizes.py from this function)."""
+    rep, kernels = backward_truth_report(dev, 8192, 63, [50] * 4, 100, seed=3, wscale=1.0, gfx_scale=1.0, chunk=128, routes=C3_ROUTES)
+    print("C3 backward against float64:", rep, kernels)
+    assert kernels["default (fp16-piece pipeline)"] == "cc_bwd_f16<L=4,LIVE=13,WS>", kernels
+    assert kernels["exact-fp32 kernels"].startswith("cc_bwd<"), kernels
+    dflt, exact, ref32 = (rep[k] for k in ("default (fp16-piece pipeline)", "exact-fp32 kernels",
+                                           "reference arithmetic (ATen float32, materialised nodes)"))
+    worst32 = max(exact["dtheta"], ref32["dtheta"])
+    assert dflt["dtheta"] <= max(1.5 * worst32, 1e-4), (dflt["dtheta"], exact["dtheta"], ref32["dtheta"])
+    assert dflt["dtheta"] < 4e-4, dflt["dtheta"]
+    for k in ("dx0",):
+        assert dflt[k] < 1e-4
+    # d_x / d_h: per-row quantities -- the median row is at rounding level, the rows off by more than 1e-4 are kink rows, and there are
+    # no more of them than 3x what the exact-fp32 kernels leave (+ a floor for small counts)
+    assert dflt["dh_row_median"] < 5e-6
+    assert dflt["dh_rows_over_1e-4"] <= 3 * exact["dh_rows_over_1e-4"] + 40, (dflt["dh_rows_over_1e-4"], exact["dh_rows_over_1e-4"])
+
+
+MNIST_ROUTES = (("default (three stages, fp16 pieces)", {}, "bf16x3"),
+                ("three stages, bf16 pieces", {"bwd_ws16": 0}, "bf16x3"),
+                ("three stages, six bf16 terms (bwd_precision = fp32)", {}, "fp32"))
+
+
+def test_default_backward_against_float64_truth_at_the_benchmarked_mnist_size(dev):
+    """100 x 784 integrals x 51 nodes, 31-100-50^4-1 (MNISTExperiment.py:33-46,238; `bench.py --workload mnist --mode train`), weights
+    x 1.5: the three-stage backward under the library defaults against the float64 evaluator, beside its six-term build and a
+    float32 run of the reference's materialised algorithm."""
+    rep, kernels = backward_truth_report(dev, 100, 784, [100, 50, 50, 50, 50], 50, seed=0, wscale=1.5, gfx_scale=0.1, chunk=4,
+                                         routes=MNIST_ROUTES)
+    print("MNIST-shaped backward against float64:", rep, kernels)
+    assert kernels["default (three stages, fp16 pieces)"] == "cc_bwd_f16<L=4,LIVE=13,WS,FRONT>", kernels
+    dflt, six, ref32 = (rep[k] for k in ("default (three stages, fp16 pieces)", "three stages, six bf16 terms (bwd_precision = fp32)",
+                                         "reference arithmetic (ATen float32, materialised nodes)"))
+    worst32 = max(six["dtheta"], ref32["dtheta"])
+    assert dflt["dtheta"] <= max(1.5 * worst32, 1e-4), (dflt["dtheta"], six["dtheta"], ref32["dtheta"])
+    assert dflt["dtheta"] < 4e-4 and dflt["dx0"] < 1e-4
+    # (a row of d_h is a SAMPLE here: 784 integrals x 51 nodes x 300 hidden units -- the typical row already contains a kink decision
+    # inside float32 noise; measured 8.7e-6 default / 1.0e-5 six-term build)
+    assert dflt["dh_row_median"] <= 1.5 * six["dh_row_median"] + 1e-6 and dflt["dh_rows_over_1e-4"] <= 2 * six["dh_rows_over_1e-4"] + 5
