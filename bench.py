@@ -524,14 +524,27 @@ def main():
 
 def make_train_step(model, opt, x, ctx, world, clip_value=10.0):
     """One data-parallel optimisation step as the reference's scripts do it (UCIExperiments.py:133-146): loss, backward,
-    ONE flattened gradient all-reduce, value clipping AFTER the reduction (:143), Adam."""
+    ONE flattened gradient all-reduce, value clipping AFTER the reduction (:143), Adam.  The reference is single-process: ONE mean
+    over the whole batch.  With shards of unequal size (sharding.shard_bounds hands them out when world does not divide the rows)
+    the average of per-rank means is a different gradient, so every rank normalises its summed log-likelihood by the GLOBAL row
+    count (one scalar all-reduce when the step is built) and the gradient all-reduce is a plain SUM."""
     from umnn_amd import sharding
+    import torch.distributed as dist
+    global_rows = x.shape[0]
+    if world > 1:
+        cnt = torch.tensor([float(x.shape[0])], dtype=torch.float64,
+                           device=x.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        global_rows = int(cnt.item())
 
     def step():
         opt.zero_grad(set_to_none=True)
         ll, z = model.compute_ll(x, context=ctx) if ctx is not None else model.compute_ll(x)
-        (-ll.mean()).backward()
-        sharding.allreduce_gradients(model, world)          # one flattened all-reduce, before clipping
+        if world > 1:
+            (-(ll.sum() / global_rows)).backward()
+            sharding.allreduce_gradients(model, world, average=False)          # one flattened all-reduce (SUM), before clipping
+        else:
+            (-ll.mean()).backward()
         torch.nn.utils.clip_grad_value_(model.parameters(), clip_value)
         opt.step()
         return ll.detach(), z

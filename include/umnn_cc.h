@@ -185,22 +185,55 @@ int umnn_cc_forward_timed(const umnn_mlp* net, const float* x0, const float* x, 
                           long long B, int d, int E, float* F, float* f_x, float* f_x0,
                           int reps, float* ms, void* stream);
 
-/* Arithmetic of the hidden-layer GEMMs in the FORWARD kernels (process-wide; default UMNN_PRECISION_BF16X3, or the
- * environment variable UMNN_FWD_PRECISION = fp32 | bf16x3 | bf16x6 at first use).  Every mode meets the 1e-4
- * tolerance of the path with margin (measured max relative error of F: fp32 ~4e-7, bf16x6 ~4e-7, bf16x3 ~6e-6);
- * backward always runs in fp32.
- *   FP32    v_mfma_f32_16x16x4_f32: exact fp32 products (an fmaf chain), fp32-vector-rate matrix path
- *   BF16X3  operands split in two bf16 pieces, 3 cross terms on v_mfma_f32_16x16x32_bf16, fp32 accumulation
- *   BF16X6  three pieces, 6 cross terms: fp32-level accuracy */
+/* Arithmetic of the hidden-layer GEMMs in the FORWARD kernels -- umnn_cc_forward, the umnn_flow_*_forward entry points, their _io
+ * forms and umnn_flow_invert_dim (process-wide; default UMNN_PRECISION_F16X3, or the environment variable UMNN_FWD_PRECISION =
+ * fp32 | bf16x3 | bf16x6 | f16x3 at first use).  Every mode meets the 1e-4 tolerance of the path with margin (measured max
+ * relative error of F on the golden set: fp32 ~4e-7, bf16x6 ~4e-7, f16x3 ~5e-7, bf16x3 ~6e-6; layer 1, the hoisted first-layer
+ * term, the output dot product, ELU and the quadrature sum are fp32 in every mode).
+ *   F16X3   (default since round 5)  operands split in two fp16 pieces (11 bits each), 3 cross terms on v_mfma_f32_16x16x32_f16,
+ *           fp32 accumulation: fp32-level accuracy at the cost of BF16X3.  fp16's exponent range is handled by an overflow
+ *           protocol (umnn_amd/csrc/cc_forward_bf16.hip): a tile group (16 or 32 integrals) whose quadrature sum is not finite --
+ *           where an overflowed piece always ends -- writes only a NaN marker into its slots of F (z for the flow entry points,
+ *           x_inv[:, j] for umnn_flow_invert_dim), and the BF16X3 build of the same kernel, queued behind every launch on the
+ *           same stream, recomputes exactly the marked groups (one scalar load per workgroup when nothing overflowed).  Those
+ *           integrals therefore come back at BF16X3 accuracy -- never NaN unless an input was, never a wrong finite value.  A
+ *           launch whose marker output aliases x, x0 or h runs BF16X3 outright.  umnn_launch_count() counts the pair as one.
+ *   FP32    v_mfma_f32_16x16x4_f32: exact fp32 products (an fmaf chain), fp32-vector-rate matrix path -- the reference's arithmetic
+ *   BF16X3  operands split in two bf16 pieces, 3 cross terms on v_mfma_f32_16x16x32_bf16, fp32 accumulation (the default until round 4)
+ *   BF16X6  three bf16 pieces, 6 cross terms: fp32-level accuracy at twice the matrix work
+ * umnn_flow_invert_dim: F16X3 and BF16X3 run the in-kernel bracket search for every net the forward covers; FP32 / BF16X6 run it on
+ * three bf16 pieces for nets of at most four 16-feature tiles per layer and return UMNN_EUNSUPPORTED for wider ones (the caller
+ * then drives the search from the host on the forward kernels of that mode). */
 #define UMNN_PRECISION_FP32 0
 #define UMNN_PRECISION_BF16X3 1
 #define UMNN_PRECISION_BF16X6 2
-#define UMNN_PRECISION_F16X3 3   /* two fp16 pieces, three cross terms: fp32-level accuracy at the two-piece cost; fp16 range (overflow -> NaN) */
+#define UMNN_PRECISION_F16X3 3
 int umnn_set_forward_precision(int mode);
 int umnn_get_forward_precision(void);
-/* Same for the backward kernels: UMNN_PRECISION_FP32 or UMNN_PRECISION_BF16X3 (default; env UMNN_BWD_PRECISION =
- * fp32 | bf16x3).  The bf16 kernels cover nets with 2..4 hidden layers, each 32..63 wide (narrower layers of
- * such a net are zero-padded to four 16-feature tiles); other shapes always run the fp32 kernels. */
+/* Arithmetic of the BACKWARD kernels (umnn_cc_backward, _io): UMNN_PRECISION_BF16X3 (default) or UMNN_PRECISION_FP32 (env
+ * UMNN_BWD_PRECISION = bf16x3 | fp32).  Under both, d_x0 / d_x Leibniz terms, the output layer, dc and every reduction are fp32.
+ *   BF16X3  the matrix-core kernels.  The forward recompute inside them is always fp32-LEVEL (the sign of every hidden
+ *           pre-activation decides a LeakyReLU slope): six cross terms on three bf16 pieces, or three cross terms on two fp16
+ *           pieces; the delta chain and the dW products carry three cross terms.  Which kernel runs:
+ *             - four hidden layers of 32..63 units, ELU+1 output, un-split node range, >= 4 tiles per workgroup:
+ *               the eight-wave workgroup pipeline -- on fp16 pieces (cc_bwd_ws16_kernel.h, kernel names cc_bwd_f16<...,WS>) for
+ *               launches of >= 2^21 node evaluations (option bwd_ws16 = 1; 2 = whenever eligible; 0 = never), on bf16 pieces
+ *               (cc_bwd_ws_kernel.h, cc_bwd_bf16<...,WS>) otherwise and for 1/f launches and sigmoid outputs.  The fp16 kernel
+ *               carries cotangents scaled by a per-launch power of two (cc_bwd_cotmax_kernel), detects an overflowed piece in
+ *               its output-layer and dc sums, raises a flag word in the workspace, and the bf16 pipeline queued behind it
+ *               rewrites every output when -- and only when -- the flag is set.  Measured against a float64 run of the reference
+ *               algorithm at the benchmarked size (8192 x 63 x 101 nodes): d_theta 5.8e-5 of its largest entry (exact-fp32
+ *               kernels 3.1e-5, a float32 ATen run of the reference's own algorithm 2.7e-5, the bf16 pipeline 2.4e-4);
+ *             - two or three hidden layers of 32..63 units, or small batches: the software-pipelined one-pass loop
+ *               (cc_bwd_swp_kernel.h; option bwd_swp = 0: the round-2 loop);
+ *             - a first hidden layer of 5..8 tiles over 2..4 narrower ones (31-100-50-50-50-50-1): three stages through HBM
+ *               (cc_backward_front.hip) -- stages A and B on fp16 pieces for single-chunk calls of >= 2^21 node evaluations with
+ *               their bf16 builds queued as the overflow fallback, on bf16 pieces otherwise;
+ *             - every other shape: the fp32 kernels below.
+ *   FP32    exact fp32 MFMA (cc_backward.hip) for every one-pass shape; the three-stage family runs its build with three bf16
+ *           pieces / six cross terms in EVERY product (cc_backward_front_p3.hip, kernel names cc_bwd_bf16x6<...>): fp32-level,
+ *           not fp32 instructions.
+ * Narrower layers of a 32..63-wide net are zero-padded to four 16-feature tiles by the staged weight images. */
 /* Which kernel family umnn_cc_backward would run for this net: 1 shape-exact kernels (one pass; or, for a first hidden layer
  * of 5..8 sixteen-feature tiles over 2..4 narrower ones such as MNISTExperiment's 100-50-50-50-50, the three-stage kernels
  * of cc_backward_front.hip -- under UMNN_PRECISION_FP32 their build with six bf16 cross terms in every product, fp32-level; or, for unequal hidden widths of 64..127, the shape-exact fp32 kernels of
@@ -222,7 +255,7 @@ int umnn_get_backward_precision(void);
  * pipeline, cc_bwd_ws_kernel.h; 0: they stay on the one-pass loop), "bwd_ws16" (that pipeline on fp16 pieces,
  * cc_bwd_ws16_kernel.h -- three-term recompute, cotangents scaled by a per-launch power of two, overflow flag + queued bf16
  * fallback: 1, default: launches of >= 2^21 node evaluations; 2: whenever the pipeline is eligible; 0: never);
- * -1 = automatic for the tuning knobs. */
+ * -1 = automatic for the tuning knobs.  "fwd_precision" defaults to UMNN_PRECISION_F16X3 (see above). */
 int umnn_set_option(const char* name, int value);
 int umnn_get_option(const char* name, int* value);
 int umnn_reload_env(void);

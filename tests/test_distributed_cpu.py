@@ -134,6 +134,52 @@ def test_bench_train_step_two_ranks_equals_single_process():
         assert torch.allclose(parts[0][k], ref[k], atol=2e-6, rtol=1e-5), k
 
 
+def _uneven_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import bench
+    sharding.init_from_env(backend="gloo")
+    model = _model()
+    sharding.broadcast_parameters(model, src=0)
+    model.train()
+    torch.manual_seed(9)
+    x = torch.randn(10, 3) * 2                                  # 10 rows over 3 ranks: shards of 4, 3, 3 rows
+    xs = sharding.shard_rows(x, rank, world).contiguous()
+    assert xs.shape[0] == (4 if rank == 0 else 3)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2)
+    step = bench.make_train_step(model, opt, xs, None, world, clip_value=0.05)
+    for _ in range(3):
+        step()
+    torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, os.path.join(outdir, f"u{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_train_step_with_uneven_shards_equals_single_process():
+    """10 rows over 3 ranks (4 + 3 + 3).  The reference takes ONE mean over the whole batch
+    (UCIExperiments.py:133-146); averaging per-rank means would weight the rows of the short shards 4/3 too much.  bench.py's step
+    normalises by the global row count and sums the gradients: three replicas bit-identical and equal to single-process training."""
+    import bench
+    world = 3
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_uneven_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        parts = [torch.load(os.path.join(out, f"u{r}.pt")) for r in range(world)]
+    model = _model()
+    model.train()
+    torch.manual_seed(9)
+    x = torch.randn(10, 3) * 2
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2)
+    step = bench.make_train_step(model, opt, x, None, 1, clip_value=0.05)
+    for _ in range(3):
+        step()
+    ref = model.state_dict()
+    for k in ref:
+        for r in range(1, world):
+            assert torch.equal(parts[0][k], parts[r][k]), (k, r)
+        assert torch.allclose(parts[0][k], ref[k], atol=3e-6, rtol=1e-5), k
+
+
 def _one_rank_worker(port, q):
     import os
     os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

@@ -123,8 +123,8 @@ int umnn_launch_backward_bf16(const BwdArgs& base, const umnn_mlp* net, int nblo
                 const size_t lds16b = (size_t)W16_LDS_USHORTS * sizeof(unsigned short);
                 if (int rc = umnn_allow_lds((const void*)hv->fn, lds16b)) return rc;
                 args.scal = a.scal;
-                umnn_prof_begin(stream);
                 if (int rc = umnn_check(hipMemsetAsync(a.scal, 0, sizeof(Ws16Scal), stream), "memset launch scalars")) return rc;
+                umnn_prof_begin(stream);       // (after the memset: its error return must not leave the bracket open)
                 const long long want = (a.NI + 1023) / 1024;             // (>= 4 integrals per thread; at most one workgroup per CU)
                 const unsigned nbm = (unsigned)(want < (long long)nblocks_max ? want : (long long)nblocks_max);
                 hipLaunchKernelGGL(cc_bwd_cotmax_kernel<>, dim3(nbm), dim3(256), 0, stream, a, reinterpret_cast<Ws16Scal*>(a.scal));

@@ -776,8 +776,9 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
     mid.b.ns = 1;
     mid.b.l_lo = 1;
     fa.nl2 = mid.nl2 = nl2;
-    umnn_prof_begin(stream);
+    // (the scalar memset + cotangent-scale pre-pass first: an error return must not leave a profiling bracket open)
     if (hv) { if (int rc = umnn_ws16_front_prepare(base, nblocks_max, stream)) return rc; }
+    umnn_prof_begin(stream);
     for (long long t0 = 0; t0 < tiles; t0 += chunk) {
         const long long nt = tiles - t0 < chunk ? tiles - t0 : chunk;
         float* z2 = (float*)scratch;
@@ -794,7 +795,7 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
             // flag, raised by the checks of stage B, which also see a non-finite z_2 from stage A: same outputs, rewritten)
             hipLaunchKernelGGL(fv->fwd16, dim3(2 * nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);      // (two workgroups per CU)
             mid.scal = base.scal; mid.only_if = nullptr;
-            if (int rc = umnn_ws16_front_launch(mid, nrl, nblocks_max, stream)) return rc;
+            if (int rc = umnn_ws16_front_launch(mid, nrl, nblocks_max, stream)) { umnn_prof_end(stream, 0.0, UMNN_PROF_BACKWARD); return rc; }
             fa.only_if = mid.only_if = base.scal + 3;            // (Ws16Scal::flag)
             hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
             hipLaunchKernelGGL(wv->fn, dim3(nblocks_max), dim3(64 * WS_WAVES), lds_ws, stream, mid);

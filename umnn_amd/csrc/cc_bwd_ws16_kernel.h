@@ -169,7 +169,9 @@ __global__ __launch_bounds__(256) void cc_bwd_cotmax_kernel(const BwdArgs a, Ws1
         m0 = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
         m1 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
         m2 = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
-        // (a non-finite cotangent has the largest bit pattern: sigma falls back to 1 and the run ends in the flag)
+        // (an INFINITE cotangent has the largest bit pattern: sigma falls back to 1 and the run ends in the flag.  A NaN one is dropped
+        // by fmaxf -- sigma then comes from the finite values -- and reaches the dc sum of its tile as NaN, which raises the flag too:
+        // either way the bf16 pipeline rewrites the launch)
         atomicMax(&sc->cotmax, __float_as_uint(m0));
         if (a.gfx) atomicMax(&sc->gfxmax, __float_as_uint(m1));
         if (blockIdx.x == 0) atomicMax(&sc->wmax, __float_as_uint(m2));
