@@ -163,6 +163,18 @@ int umnn_cc_backward(const umnn_mlp* net, const float* x0, const float* x, const
                      void* workspace, long long workspace_bytes, void* stream);
 long long umnn_cc_backward_workspace_bytes(const umnn_mlp* net, long long B, int d, int E);
 
+/* Elementwise glue of a block's TRAINING path (umnn_amd/csrc/cc_flow_glue.hip), one launch each.
+ * umnn_flow_block_cotangents: backward of the block epilogue (UMNNMAF.py:80-83,134,138-139)
+ *     z[b, rev(i)] = exp(s_i) (F[b,i] + h_0[b,i]),  log_jac[b,i] = log(f_x[b,i] + 1e-10) + s_i      (rev(i) = d-1-i if reverse_z)
+ *   from the cotangents g_z, g_log_jac [B,d] (either nullable = zero) to gF = exp(s_i) g_z[b, rev(i)] (also the cotangent of h_0) and
+ *   g_fx = g_log_jac / (f_x + 1e-10) (g_fx nullable: not wanted) -- the g / g_fx inputs of umnn_cc_backward.
+ * umnn_flow_ll_forward / _backward: UMNNMAFFlow.compute_ll's reduction (UMNNMAFFlow.py:109-119)
+ *     ll[b] = sum_i log_jac[b,i] - 1/2 sum_i (log 2 pi + z[b,i]^2);   g_log_jac[b,i] = g_ll[b],  g_z[b,i] = -z[b,i] g_ll[b]. */
+int umnn_flow_block_cotangents(const float* g_z, const float* g_log_jac, const float* f_x, const float* scaling,
+                               long long B, int d, int reverse_z, float* gF, float* g_fx, void* stream);
+int umnn_flow_ll_forward(const float* z, const float* log_jac, long long B, int d, float* ll, void* stream);
+int umnn_flow_ll_backward(const float* z, const float* g_ll, long long B, int d, float* g_z, float* g_log_jac, void* stream);
+
 /* Replaces compute_cc_weights -- ParallelNeuralIntegral.py:14-34: writes nb_steps+1 fp32
  * weights and nodes into HOST buffers (float64 arithmetic, cast at the end). */
 int umnn_cc_tables_host(int nb_steps, float* w_host, float* s_host);
@@ -202,8 +214,8 @@ int umnn_cc_forward_timed(const umnn_mlp* net, const float* x0, const float* x, 
  *   BF16X3  operands split in two bf16 pieces, 3 cross terms on v_mfma_f32_16x16x32_bf16, fp32 accumulation (the default until round 4)
  *   BF16X6  three bf16 pieces, 6 cross terms: fp32-level accuracy at twice the matrix work
  * umnn_flow_invert_dim: F16X3 and BF16X3 run the in-kernel bracket search for every net the forward covers; FP32 / BF16X6 run it on
- * three bf16 pieces for nets of at most four 16-feature tiles per layer and return UMNN_EUNSUPPORTED for wider ones (the caller
- * then drives the search from the host on the forward kernels of that mode). */
+ * three bf16 pieces for nets of at most four 16-feature tiles per layer and on two fp16 pieces (the F16X3 search: fp32-level
+ * products, overflowing samples redone on bf16 pieces) for wider ones, whose three-piece form does not fit the register file. */
 #define UMNN_PRECISION_FP32 0
 #define UMNN_PRECISION_BF16X3 1
 #define UMNN_PRECISION_BF16X6 2

@@ -282,21 +282,17 @@ def test_in_kernel_inversion_round_trip(d, hid, E, n, nb_flow, B, dev, precision
             warnings.simplefilter("ignore", RuntimeWarning)      # (exact-products modes announce the host-driven search once)
             x_inv = m.invert(z, iter=iters)
         wide = max(hid) > 63
-        if precision in ("bf16x3", "f16x3") or not wide:
-            # one launch per dimension and block.  Under "exact products" (bf16x6 / fp32) nets of up to four tiles per layer run the
-            # same in-kernel search with three bf16 pieces / six cross terms (round 4: PARTS=3 variants); f16x3 (the default) runs
-            # it on two fp16 pieces -- fp32-level products -- for every net, its bf16x3 build queued as the overflow fallback (round 5)
-            assert _lib.lib().umnn_launch_count() - before == nb_flow * d
-            name = _lib.lib().umnn_last_kernel_name().decode()
-            assert ("cc_invert_f16" if precision == "f16x3" else "cc_invert_bf16") in name, name
-            assert ("PARTS=3" in name) == (precision in ("bf16x6", "fp32")), name
-            if hid[0] == 100 and len(hid) == 5:
-                assert "T1=7,TREST=4" in name
-        else:
-            # wider nets have no three-piece search kernel (8 tiles x 3 pieces do not fit the register file): the bracket search
-            # is driven from the host, one forward launch of that precision per round (umnn_flow_invert_dim: UMNN_EUNSUPPORTED)
-            assert _lib.lib().umnn_launch_count() - before >= nb_flow * d * iters
-            assert "invert" not in _lib.lib().umnn_last_kernel_name().decode()
+        # one launch per dimension and block in every mode.  Under "exact products" (bf16x6 / fp32) nets of up to four tiles per layer
+        # run the search with three bf16 pieces / six cross terms (round 4: PARTS=3 variants), wider ones -- whose three-piece form does
+        # not fit the register file -- on two fp16 pieces like f16x3 (the default), every fp16 launch with its bf16x3 build queued as
+        # the overflow fallback (round 5; until then those nets fell back to a host-driven search)
+        assert _lib.lib().umnn_launch_count() - before == nb_flow * d
+        name = _lib.lib().umnn_last_kernel_name().decode()
+        on_f16 = precision == "f16x3" or (precision in ("bf16x6", "fp32") and wide)
+        assert ("cc_invert_f16" if on_f16 else "cc_invert_bf16") in name, name
+        assert ("PARTS=3" in name) == (precision in ("bf16x6", "fp32") and not wide), name
+        if hid[0] == 100 and len(hid) == 5:
+            assert "T1=7,TREST=4" in name
         assert float((x_inv - x).abs().max()) < tol * nb_flow
         with I.force_generic():                       # host-driven search, ATen integrals
             x_ref = m.invert(z, iter=iters)

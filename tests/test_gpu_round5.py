@@ -390,3 +390,49 @@ def test_default_backward_against_float64_truth_at_the_benchmarked_mnist_size(de
     # (a row of d_h is a SAMPLE here: 784 integrals x 51 nodes x 300 hidden units -- the typical row already contains a kink decision
     # inside float32 noise; measured 8.7e-6 default / 1.0e-5 six-term build)
     assert dflt["dh_row_median"] <= 1.5 * six["dh_row_median"] + 1e-6 and dflt["dh_rows_over_1e-4"] <= 2 * six["dh_rows_over_1e-4"] + 5
+
+
+# ---- the training path's elementwise glue as single launches ------------------------------------------------
+@pytest.mark.parametrize("cond", [0, 5])
+def test_fused_training_nodes_match_the_composed_autograd_path(cond, dev, monkeypatch):
+    """FlowBlockTransform / FlowLogLikelihood (one autograd node per block, one per log-likelihood) against the same arithmetic
+    composed from torch ops (UMNN_FUSED_TRAIN=0: IntegralWithJacobianParams + exp / mul / add / log / flip / sum, i.e. the
+    reference's formulas UMNNMAF.py:76-139, UMNNMAFFlow.py:109-119 under ordinary autograd): ll, z and every gradient -- parameters of
+    all blocks' conditioners and integrands, and the input -- to 1e-5 of their largest entry; and the launch diet it buys."""
+    import umnn_amd
+    torch.manual_seed(11)
+    model = umnn_amd.UMNNMAFFlow(nb_flow=3, nb_in=6, hidden_derivative=[50] * 4, hidden_embedding=[64, 64], embedding_s=30,
+                                 nb_steps=20, solver="CCParallel", cond_in=cond, device=str(dev)).to(dev).train()
+    x = torch.randn(300, 6, device=dev)
+    ctx = torch.randn(300, cond, device=dev) if cond else None
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("UMNN_FUSED_TRAIN", fused)
+        model.zero_grad(set_to_none=True)
+        xr = x.clone().requires_grad_()
+        ll, z = model.compute_ll(xr, context=ctx) if cond else model.compute_ll(xr)
+        if fused == "1":
+            assert type(ll.grad_fn).__name__ == "FlowLogLikelihoodBackward", type(ll.grad_fn).__name__
+        (-(ll.mean()) + 0.01 * (z ** 2).mean()).backward()
+        res[fused] = (ll.detach(), z.detach(), xr.grad.clone(), [p.grad.clone() for p in model.parameters() if p.requires_grad])
+    rel = lambda a_, b_: float((a_ - b_).abs().max() / b_.abs().max().clamp(min=1e-30))      # noqa: E731
+    assert rel(res["1"][0], res["0"][0]) < 1e-5 and rel(res["1"][1], res["0"][1]) < 1e-6
+    assert rel(res["1"][2], res["0"][2]) < 1e-5
+    assert len(res["1"][3]) == len(res["0"][3]) > 0
+    for a_, b_ in zip(res["1"][3], res["0"][3]):
+        assert rel(a_, b_) < 1e-5, (a_.shape, rel(a_, b_))
+
+
+def test_block_level_compute_ll_in_training_mode_still_clamps_in_place(dev):
+    """UMNNMAF.compute_ll (block level, UMNNMAF.py:148-152) clamps z IN PLACE after the transform: z is now a direct output of
+    the fused node -- the clamp must neither raise nor change the gradients of the unclamped entries."""
+    import umnn_amd
+    torch.manual_seed(2)
+    model = umnn_amd.UMNNMAFFlow(nb_flow=1, nb_in=4, hidden_derivative=[50] * 4, hidden_embedding=[32, 32], embedding_s=8,
+                                 nb_steps=20, solver="CCParallel", device=str(dev)).to(dev).train()
+    blk = model.nets[0]
+    x = torch.randn(64, 4, device=dev) * 4
+    ll, z = blk.compute_ll(x)
+    assert float(z.abs().max()) <= 10.0
+    ll.mean().backward()
+    assert all(torch.isfinite(p.grad).all() for p in blk.parameters() if p.requires_grad and p.grad is not None)

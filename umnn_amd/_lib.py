@@ -86,6 +86,9 @@ SIGNATURES = {
     "umnn_profile_read_tag": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_ll),
                                              ctypes.POINTER(ctypes.c_double)]),
     "umnn_last_kernel_name_of": (ctypes.c_char_p, [ctypes.c_int]),
+    "umnn_flow_block_cotangents": (ctypes.c_int, [_fp, _fp, _fp, _fp, _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
+    "umnn_flow_ll_forward": (ctypes.c_int, [_fp, _fp, _ll, ctypes.c_int, _fp, _fp]),
+    "umnn_flow_ll_backward": (ctypes.c_int, [_fp, _fp, _ll, ctypes.c_int, _fp, _fp, _fp]),
     "umnn_made_split3": (ctypes.c_int, [_fp, _ll, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]),
     "umnn_made_launch_count": (ctypes.c_longlong, []),
     "umnn_last_made_kernel_name": (ctypes.c_char_p, []),

@@ -186,8 +186,12 @@ extern "C" int umnn_flow_invert_dim(const umnn_mlp* net, const float* h, const f
         if (prec == UMNN_PRECISION_F16X3)
             return umnn_invert_impl_f16(net, h, z, scaling, cc_w, cc_s, nb_steps, B, d, E, j, iters, x_inv, stream, 2, nullptr);
         const int nparts = prec == UMNN_PRECISION_BF16X3 ? 2 : 3;
+        // (8 tiles x 3 bf16 pieces do not fit the register file: nets above four tiles per layer get their fp32-level products from
+        // the two-fp16-piece search instead -- the same accuracy class, ~5e-7 on F; a sample whose candidates overflow fp16 is redone
+        // on two bf16 pieces, ~6e-6 on F, three orders of magnitude inside the search's own resolution 100 (2/9)^iter.  Until round 4
+        // this case returned UMNN_EUNSUPPORTED and the caller drove d x iter forward launches from the host)
         if (nparts == 3 && tmax > 4)
-            return umnn_fail(UMNN_EUNSUPPORTED, "invert: the fp32-level in-kernel search exists for nets of at most four tiles per layer; the forward precision asks for exact products");
+            return umnn_invert_impl_f16(net, h, z, scaling, cc_w, cc_s, nb_steps, B, d, E, j, iters, x_inv, stream, 2, nullptr);
         return umnn_invert_impl_bf16(net, h, z, scaling, cc_w, cc_s, nb_steps, B, d, E, j, iters, x_inv, stream, nparts, nullptr);
     }
 }

@@ -14,6 +14,7 @@ What is different underneath (MI355X-first, results unchanged):
 Names the reference's scripts call but the reference never defines exist here as aliases.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -120,6 +121,10 @@ class UMNNMAF(nn.Module):
             x0 = x0.to(x.device) if x0 is not None else None      # None = lower limit 0 inside the kernels
             if no_graph:
                 F, fx, _ = _I.hip_forward(spec, x0, x, h, self.nb_steps)
+            elif _I.fused_block_ok(x, h, self.scaling, x0, want_jac) and (log_jac_in is None or log_jac_in.dtype == torch.float32):
+                # training: the whole block -- quadrature + epilogue, and their backward -- as ONE autograd node
+                return _I.FlowBlockTransform.apply(x.contiguous(), integrand, h.contiguous(), self.scaling, self.nb_steps,
+                                                   reverse_z, log_jac_in, *integrand.parameters())
             else:
                 F, fx = IntegralWithJacobianParams.apply(x0, x, integrand, h, self.nb_steps, *integrand.parameters())
         else:
@@ -362,6 +367,10 @@ class UMNNMAFFlow(nn.Module):
                                              reverse_z=i + 1 < nb, first=i == 0, last=i + 1 == nb, ll=ll, scratch=scratch, cnt=cnt)
             return ll, x
         z, log_jac = self._stack(x, context, True)
+        if (z.is_cuda and z.dtype == torch.float32 and log_jac.dtype == torch.float32 and z.dim() == 2 and torch.is_grad_enabled()
+                and (z.requires_grad or log_jac.requires_grad) and not torch.is_autocast_enabled()
+                and os.environ.get("UMNN_FUSED_TRAIN", "1") != "0"):
+            return _I.FlowLogLikelihood.apply(z, log_jac), z        # (training: the reduction and its backward as one launch each)
         log_prob_gauss = -.5 * (torch.log(self.pi * 2) + z ** 2).sum(1)
         return log_jac.sum(1) + log_prob_gauss, z
 

@@ -485,6 +485,92 @@ class IntegralWithJacobianParams(torch.autograd.Function):
         return (None if ctx.x0_none else dx0, dx, None, dh, None, *grads)
 
 
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class FlowBlockTransform(torch.autograd.Function):
+    """(z, log_jac) of one UMNN-MAF block on the TRAINING path as ONE autograd node (UMNNMAF.py:76-139):
+
+        z[b, rev(i)] = exp(s_i) (int_0^{x_bi} f(t; h_b) dt + h_0[b,i]),     log_jac = [log_jac_in +] log(f(x; h) + 1e-10) + s
+
+    forward = the fused-epilogue launch of the inference path (umnn_flow_stack_block_forward); backward = one elementwise launch
+    (umnn_flow_block_cotangents: cotangents of F and f_x from those of z and log_jac), the quadrature backward, and the h_0 term
+    added into d_h.  Composed from torch ops (exp, mul, add, log, add, flip, select and their backward nodes) the same
+    arithmetic is ~15 launches and 8 autograd nodes per block.  Internal to the flow blocks: fp32 storage, lower limit 0, frozen
+    ``scaling`` (UMNNMAF.py:53) -- anything else keeps the composed path."""
+
+    @staticmethod
+    def forward(ctx, x, integrand, h, scaling, nb_steps, reverse_z, log_jac_in, *params):
+        spec = mlp_spec(integrand)
+        ctx.spec, ctx.nb_steps, ctx.integrand, ctx.reverse_z = spec, nb_steps, integrand, bool(reverse_z)
+        ctx.shapes = [p.shape for p in params]
+        z, lj, fx, _ = hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z, log_jac_in)
+        ctx.save_for_backward(x.clone(), h, fx, scaling)      # (x cloned: callers clamp z / reuse x in place, UMNNMAF.py:150)
+        return z, lj
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gz, glj):
+        x, h, fx, scaling = ctx.saved_tensors
+        lib = _lib.lib()
+        B, d = x.shape
+        gz = None if gz is None else gz.contiguous()
+        glj = None if glj is None else glj.contiguous()
+        gF, gfx = torch.empty_like(x), (torch.empty_like(x) if glj is not None else None)
+        with torch.cuda.device(x.device):
+            rc = lib.umnn_flow_block_cotangents(_ptr(gz), _ptr(glj), _ptr(fx), _ptr(scaling), B, d, 1 if ctx.reverse_z else 0,
+                                                _ptr(gF), _ptr(gfx), _stream(x.device))
+        _lib.check(rc, "umnn_flow_block_cotangents")
+        if not _hip_backward_ok(ctx.spec, x, h):
+            _, dx, dh, dtheta = aten_backward_jac(ctx.integrand, torch.zeros_like(x), x, h, gF, gfx, ctx.nb_steps)
+        else:
+            need = (False, ctx.needs_input_grad[0], ctx.needs_input_grad[2], any(ctx.needs_input_grad[7:]))
+            _, dx, dh, dtheta = hip_backward(ctx.spec, None, x, h, gF, gfx, ctx.nb_steps, need)
+        if dh is not None:
+            dh.view(B, -1, d)[:, 0, :].add_(gF)            # z carries h_0 = embedding row 0 (UMNNMAF.py:80)
+        grads, o = [], 0
+        for shp, needed in zip(ctx.shapes, ctx.needs_input_grad[7:]):
+            n = int(torch.Size(shp).numel())
+            grads.append(dtheta[o:o + n].view(shp) if (needed and dtheta is not None) else None)
+            o += n
+        return (dx, None, dh, None, None, None, glj if ctx.needs_input_grad[6] else None, *grads)
+
+
+class FlowLogLikelihood(torch.autograd.Function):
+    """ll[b] = sum_i log_jac[b,i] - 1/2 sum_i (log 2 pi + z[b,i]^2)  (UMNNMAFFlow.py:109-119) as one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, z, log_jac):
+        z, log_jac = z.contiguous(), log_jac.contiguous()
+        B, d = z.shape
+        ll = torch.empty(B, device=z.device, dtype=torch.float32)
+        with torch.cuda.device(z.device):
+            rc = _lib.lib().umnn_flow_ll_forward(_ptr(z), _ptr(log_jac), B, d, _ptr(ll), _stream(z.device))
+        _lib.check(rc, "umnn_flow_ll_forward")
+        ctx.save_for_backward(z)
+        return ll
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_ll):
+        (z,) = ctx.saved_tensors
+        B, d = z.shape
+        g_ll = g_ll.contiguous()
+        gz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
+        glj = torch.empty_like(z) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(z.device):
+            rc = _lib.lib().umnn_flow_ll_backward(_ptr(z), _ptr(g_ll), B, d, _ptr(gz), _ptr(glj), _stream(z.device))
+        _lib.check(rc, "umnn_flow_ll_backward")
+        return gz, glj
+
+
+def fused_block_ok(x, h, scaling, x0, want_jac):
+    """The one-node training path of a block applies: fp32 storage, lower limit 0, log_jac wanted, frozen scaling, no autocast."""
+    return (x0 is None and want_jac and x.dtype == torch.float32 and h.dtype == torch.float32 and x.dim() == 2
+            and not scaling.requires_grad and not torch.is_autocast_enabled() and os.environ.get("UMNN_FUSED_TRAIN", "1") != "0")
+
+
 # ----------------------------------------------------------------------------------------------
 # reference-shaped public API
 # ----------------------------------------------------------------------------------------------
