@@ -66,10 +66,11 @@ __device__ __forceinline__ float pc_lo_f32(unsigned bits) { return __uint_as_flo
 __device__ __forceinline__ float pc_hi_f32(unsigned bits) { return __uint_as_float(bits & 0xffff0000u); }
 #endif
 // output activation.  fp16 pieces: an overflowed piece (|a| >= 65520) is +-inf and reaches the output-layer sum as inf / NaN; ELU + 1
-// would map -inf to a finite 0, so a non-finite sum is made a NaN outright (bf16 pieces share fp32's range: nothing to guard)
+// would map -inf to a finite 0, so a non-finite sum is made a NaN outright (bf16 pieces share fp32's range: nothing to guard).  The NaN
+// is what the epilogue's overflow protocol looks for in the quadrature sum (cc_fwd_shared.h)
 __device__ __forceinline__ float pc_out_act(float sd, int kind) {
     const float f = out_act_f(sd, kind);
-    if constexpr (PC_F16) return __builtin_fabsf(sd) < __builtin_inff() ? f : __builtin_nanf("");
+    if constexpr (PC_F16) return __builtin_fmaf(sd, 0.f, f);      // sd * 0 = NaN for a non-finite sd, +-0 otherwise: one instruction
     return f;
 }
 // (x0, x1) -> packed pairs of the NPARTS pieces (piece k of x0 in the low half of out[k], of x1 in the high half): each piece the
