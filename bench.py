@@ -444,7 +444,8 @@ def main():
             per_tile_node = sum(-(-(hd[i + 1] + 1) // 16) * -(-(-(-(hd[i] + 1) // 16)) // 2) * terms for i in range(len(hd) - 1))
             if "LIVE=13" in kernel_name and terms == 3:     # widths 48..51: the three terms share FIVE K-steps (merged layout)
                 per_tile_node = sum(-(-(hd[i + 1] + 1) // 16) * 5 for i in range(len(hd) - 1))
-            if "PIPE" in kernel_name:     # + one remainder MFMA per fully live tile and split (see cc_forward_bf16.hip)
+            if "PIPE" in kernel_name and "cc_fwd_bf16" in kernel_name:     # + one remainder MFMA per fully live tile and split (the bf16
+                # build only: since round 5 the fp16 build takes its remainders on the VALU, cc_fwd_bf16_kernel.h)
                 per_tile_node += sum((-(-(hd[i] + 1) // 4)) // 4 for i in range(len(hd) - 1))
             tiles = -(-cfg["rows"] * cfg["d"] // 16)
             executed = per_tile_node * 16384.0 * tiles * (cfg["n"] + 1) / max(avg_kernel_ms, 1e-9) / 1e9

@@ -73,10 +73,42 @@ __device__ __forceinline__ float pc_out_act(float sd, int kind) {
     if constexpr (PC_F16) return __builtin_fmaf(sd, 0.f, f);      // sd * 0 = NaN for a non-finite sd, +-0 otherwise: one instruction
     return f;
 }
+#ifdef UMNN_FWD_PIECE_F16
+// second fp16 piece of a pair, straight from the values and their packed leading pieces: v_fma_mixlo_f16 / v_fma_mixhi_f16 read an f16
+// half of a register as an operand, form x - hi exactly (fp32 fma) and round it to f16 into one half of the destination -- the
+// remainder never exists as a separate fp32 value: two instructions per pair where subtracting and converting takes five
+// (tools/ubench/mixlo_check.hip: bit-identical to cvt_pk(x - float(hi)) over 1 M random pairs of 40 binades, zeros, subnormals).
+// HAZARDS: the compiler's hazard recogniser does not look inside inline assembly, and with MFMA accumulators in VGPRs the register
+// allocator hands a just-dead accumulator to the next temporary -- a vector write into a register that an in-flight MFMA still reads
+// as its C operand (first version of this function, output "=v": one launch shape returned f(x) 4e-4 off).  So the output is TIED to
+// the register of x0 (and, if x0 lives on, to the compiler's own copy of it): a register whose last writer is an instruction the
+// recogniser has seen, and which no matrix instruction reads.
+__device__ __forceinline__ unsigned pc_lo_pair(float x0, float x1, unsigned hi) {
+    unsigned lo = __float_as_uint(x0);
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(x1));
+    return lo;
+}
+// v[I], v[I + 1] -= the two fp16 halves of `bits`, exactly (v_fma_mix_f32 reads an f16 half as an operand); outputs tied to inputs
+template <int I>
+__device__ __forceinline__ void pc_sub_halves(f32x4& v, unsigned bits) {
+    float x0 = v[I], x1 = v[I + 1];
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(x0) : "v"(bits));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x1) : "v"(bits));
+    v[I] = x0; v[I + 1] = x1;
+}
+#endif
 // (x0, x1) -> packed pairs of the NPARTS pieces (piece k of x0 in the low half of out[k], of x1 in the high half): each piece the
 // round-to-nearest value of the running remainder (same arithmetic as split_pair of cc_bf16.h for bf16 pieces)
 template <int NPARTS>
 __device__ __forceinline__ void pc_split_pair(float x0, float x1, unsigned (&out)[NPARTS]) {
+#ifdef UMNN_FWD_PIECE_F16
+    if constexpr (NPARTS == 2) {
+        out[0] = pc_cvt_pk(x0, x1);
+        out[1] = pc_lo_pair(x0, x1, out[0]);
+        return;
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < NPARTS; ++k) {
         const unsigned bits = pc_cvt_pk(x0, x1);
@@ -433,10 +465,25 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     bfout[QCVT][0] = u32x4{a0, a1,
                                            b0, b1};
                 }
+#ifdef UMNN_FWD_PIECE_F16
+                // fp16 pieces (round 5): the remainders on the VALU after all -- v_fma_mix_f32 subtracts a packed f16 half straight from
+                // the fp32 value, one instruction per register, spread over the slots behind the quad's conversions.  Same-box A/B at
+                // C3 against the remainder MFMAs below: 2.470 -> 2.427 ms, 9 of 69 matrix instructions per tile-node fewer, shader
+                // clock 2141 -> 2170 MHz under the same power -- the kernel is bound by matrix-pipe cycles and package power, not by
+                // vector issue (the bf16 build keeps the MFMA form: its VALU remainder is three instructions per register).
+                constexpr int QV = (!MERGE && i >= 19 && i <= 21) ? 1 : ((i >= 9 && i <= 11) ? 0 : -1);
+                if constexpr (QV >= 0) {
+                    constexpr int k = i - (QV ? 19 : 9);               // 0: first tile of the quad; 1, 2: halves of the second
+                    if constexpr (k == 0) { pc_sub_halves<0>(z[2 * QV], bfout[QV][0][0]); pc_sub_halves<2>(z[2 * QV], bfout[QV][0][1]); }
+                    if constexpr (k == 1) pc_sub_halves<0>(z[2 * QV + 1], bfout[QV][0][2]);
+                    if constexpr (k == 2) pc_sub_halves<2>(z[2 * QV + 1], bfout[QV][0][3]);
+                }
+#else
                 if constexpr (QSEL >= 0) {
                     z[2 * QSEL] = pc_mfma(sel[0], bfout[QSEL][0], z[2 * QSEL]);          // exact remainders
                     z[2 * QSEL + 1] = pc_mfma(sel[1], bfout[QSEL][0], z[2 * QSEL + 1]);
                 }
+#endif
                 if constexpr (t_hi >= 0) {
                     const unsigned h0 = pc_cvt_pk(z[t_hi][0], z[t_hi][1]);
                     const unsigned h1 = pc_cvt_pk(z[t_hi][2], z[t_hi][3]);
@@ -446,7 +493,11 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                         bfout[1][1][2] = h0;
                         bfout[1][1][3] = h1;
                     }
+#ifdef UMNN_FWD_PIECE_F16
+                    pc_sub_halves<0>(z[t_hi], h0); pc_sub_halves<2>(z[t_hi], h1);
+#else
                     z[t_hi] = pc_mfma(sel[t_hi % 2], bfout[t_hi / 2][0], z[t_hi]);          // exact remainders
+#endif
                 }
                 if constexpr (t_lo >= 0) {
                     const unsigned l0 = pc_cvt_pk(z[t_lo][0], z[t_lo][1]);
@@ -462,7 +513,13 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
                     bfout[1][0][3] = rem_hi;                     // k-slots 6,7: (hi, 0)
                 }
                 if constexpr (i == T3B) {
+#ifdef UMNN_FWD_PIECE_F16
+                    float rr = rem_a;
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(rr) : "v"(rem_hi));
+                    const unsigned l = pc_cvt_pk(rr, 0.f);
+#else
                     const unsigned l = pc_cvt_pk(rem_a - pc_lo_f32(rem_hi), 0.f);
+#endif
                     bfout[1][0][2] = rem_hi | (l << 16);      // k-slots 4,5: (hi, lo)
                 }
             };
