@@ -6,6 +6,7 @@ run() { timeout 400 python $R/bench.py --no-cpu-baseline --no-extras --steps ${S
 fast() { STEPS=200 WARMUP=40 run "$@"; }          # the sub-3-ms steps: 200 timed steps
 run --workload bsds300
 run --workload bsds300 --precision fp32
+run --workload bsds300 --precision bf16x3
 run --workload bsds300 --embedding bf16
 fast --workload power
 fast --workload toy
