@@ -103,10 +103,23 @@ __device__ __forceinline__ void item_embedding_gemm(const IoView& hb, const floa
 
 // v_max_f32 without the canonicalising v_max(v,v) hipcc puts in front of fmaxf on MFMA results (fmaxf must quiet
 // signalling NaNs; the hardware instruction on already-finite data does not need it).  One VALU op instead of two.
+// Inline assembly and MFMA hazards: the compiler's hazard recogniser does not look inside `asm`, and a free-standing "=v" output may be
+// given a register that an in-flight MFMA still reads as its C operand when the accumulators live in VGPRs and the compiler has renamed
+// one (dst != srcC) -- round 5 met exactly that with another instruction (EXPERIMENTS.md).  A hazard of this kind is a property of
+// the BINARY (straight-line distance between two instructions), so the bit-exactness and parity tests of a build either see it or it is
+// not there.  UMNN_ASM_TIED (the forward translation units: built with -amdgpu-mfma-vgpr-form, re-scheduled by hand every round): the
+// output is tied to the first input, whose last writer is a compiler-visible instruction -- no such register can be handed out.  The
+// backward translation units keep the untied form: tied, every activation that stays live costs a v_mov (measured: C3 backward
+// 10.30 -> 10.42 ms, MNIST-shaped stages 1.77 -> 1.81 ms).
 __device__ __forceinline__ float vmax_f32(float a, float b) {
+#ifdef UMNN_ASM_TIED
+    asm("v_max_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+    return a;
+#else
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+#endif
 }
 // hidden activation: LeakyReLU(0.01) (slope = 0.01) or ReLU (slope = 0) as max(v, slope*v)
 __device__ __forceinline__ float hidden_act_f(float v, float slope) { return vmax_f32(v, slope * v); }

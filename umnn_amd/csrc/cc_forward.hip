@@ -15,6 +15,9 @@
 // node-invariant part W1[:,1:]*h + b1 is hoisted and computed once per integral, itself on MFMA);
 // hidden layers are 16x16x4 fp32 MFMAs against LDS-resident weight images; the scalar output layer
 // is a per-lane dot product plus a 4-lane-group all-reduce.  See cc_common.h for the layouts.
+#ifndef UMNN_ASM_TIED
+#define UMNN_ASM_TIED 1      // cc_common.h: inline-assembly outputs tied to inputs in the forward translation units
+#endif
 #include "cc_fwd_shared.h"
 
 // TAIL = 1 (exact variants only): the last tile holds at most 4 features (<= 3 real ones + the constant), all

@@ -1,5 +1,8 @@
 // Forward quadrature on the bf16 matrix cores: variant table and launcher (the kernel template, with its layout notes,
 // lives in cc_fwd_bf16_kernel.h and is shared with the inversion variants of cc_invert.hip).
+#ifndef UMNN_ASM_TIED
+#define UMNN_ASM_TIED 1      // cc_common.h: inline-assembly outputs tied to inputs in the forward translation units
+#endif
 #include "cc_fwd_bf16_kernel.h"
 using namespace UMNN_FWD_NS;
 // (this file is compiled twice: as is -- bf16 pieces, umnn_launch_forward_bf16 -- and through cc_forward_f16.hip with
@@ -14,7 +17,7 @@ using namespace UMNN_FWD_NS;
 
 // ------------------------------------------------------------------------------------------
 typedef void (*fwd_bf16_kernel_t)(const FwdBf16Args);
-struct Bf16Variant { int tmax, nparts, p, exact, nrl, pipe; fwd_bf16_kernel_t fn; const char* name; };
+struct Bf16Variant { int tmax, nparts, p, exact, nrl, pipe, wpb; fwd_bf16_kernel_t fn; const char* name; };
 // first hidden layer T1 = 5..8 tiles, every other hidden layer at most four (zero-padded to four): MNISTExperiment's
 // 31-100-50-50-50-50-1.  Shape-exact: layer 1's GEMM contracts over T1 tiles, the others over four.
 // LIVE=13: every later layer 48..51 wide -- 13 live registers per lane and the merged five-K-step layout from layer 2 on.
@@ -23,8 +26,10 @@ struct Bf16WideFirst { int t1, nrl, p; fwd_bf16_kernel_t fn; const char* name; }
 static const Bf16WideFirst kBf16WideFirst[] = { BF16_WIDE_FIRST(5, 13, 1), BF16_WIDE_FIRST(6, 13, 1), BF16_WIDE_FIRST(7, 13, 1), BF16_WIDE_FIRST(8, 13, 1),
                                                 BF16_WIDE_FIRST(5, 0, 1), BF16_WIDE_FIRST(6, 0, 1), BF16_WIDE_FIRST(7, 0, 1), BF16_WIDE_FIRST(8, 0, 1) };
 // (two point tiles per wave, P = 2: 260 registers = one wave per SIMD, 0.63 ms against 0.49 ms at the MNIST shape -- not instantiated)
-#define BF16_VARIANT(T, NP, PP, EX, NR) { T, NP, PP, EX, NR, 0, cc_fwd_bf16_kernel<T, NP, PP, (EX) != 0, NR>, FWD_KNAME "<T=" #T ",PARTS=" #NP ",P=" #PP ",EXACT=" #EX ",LIVE=" #NR ">" }
-#define BF16_PIPE_VARIANT(NP, PP, NR) { 4, NP, PP, 1, NR, 1, cc_fwd_bf16_kernel<4, NP, PP, true, NR, true>, FWD_KNAME "<T=4,PARTS=" #NP ",P=" #PP ",EXACT=1,LIVE=" #NR ",PIPE>" }
+#define BF16_VARIANT(T, NP, PP, EX, NR) { T, NP, PP, EX, NR, 0, 4, cc_fwd_bf16_kernel<T, NP, PP, (EX) != 0, NR>, FWD_KNAME "<T=" #T ",PARTS=" #NP ",P=" #PP ",EXACT=" #EX ",LIVE=" #NR ">" }
+#define BF16_PIPE_VARIANT(NP, PP, NR) { 4, NP, PP, 1, NR, 1, 4, cc_fwd_bf16_kernel<4, NP, PP, true, NR, true>, FWD_KNAME "<T=4,PARTS=" #NP ",P=" #PP ",EXACT=1,LIVE=" #NR ",PIPE>" }
+// eight waves per workgroup (one workgroup per CU: see WPB in cc_fwd_bf16_kernel.h)
+#define BF16_VARIANT_W8(T, NR) { T, 2, 1, 1, NR, 0, 8, cc_fwd_bf16_kernel<T, 2, 1, true, NR, false, false, 0, 8>, FWD_KNAME "<T=" #T ",PARTS=2,P=1,EXACT=1,LIVE=" #NR ",WAVES=8>" }
 static const Bf16Variant kBf16Variants[] = {
     BF16_PIPE_VARIANT(2, 2, 13), BF16_PIPE_VARIANT(2, 2, 0),   // software-pipelined node loop (>= 2 hidden layers, bf16x3)
     BF16_VARIANT(4, 2, 1, 1, 13), BF16_VARIANT(4, 2, 2, 1, 13),   // widths 48..51
@@ -37,6 +42,7 @@ static const Bf16Variant kBf16Variants[] = {
 #endif
     BF16_VARIANT(7, 2, 1, 1, 26), BF16_VARIANT(7, 2, 1, 1, 0),   // widths 96..111 (100-wide toy / MonotonicNN nets): 3 K-steps + a half one
     BF16_VARIANT(5, 2, 1, 1, 0), BF16_VARIANT(6, 2, 1, 1, 0), BF16_VARIANT(8, 2, 1, 1, 0),   // widths 64..79, 80..95, 112..127
+    BF16_VARIANT_W8(7, 26), BF16_VARIANT_W8(7, 0), BF16_VARIANT_W8(5, 0), BF16_VARIANT_W8(6, 0), BF16_VARIANT_W8(8, 0),
     BF16_VARIANT(8, 2, 1, 0, 0), BF16_VARIANT(8, 2, 2, 0, 0),   // (8 tiles x 3 parts does not fit the register file: fp32 kernels instead)
 };
 
@@ -64,13 +70,13 @@ int umnn_launch_forward_bf16(FwdArgs& a, const umnn_mlp* net, int nparts, int P,
 // The planned launch itself.  fp16 build: the launch with ovf_mode = 1, then the bf16 build of the same plan queued as its fallback
 // (one profiling bracket around both, one launch note).  bf16 build: a plain launch, or (ovf) that queued fallback.
 static int launch_planned(fwd_bf16_kernel_t fn, const char* name, unsigned nblk, size_t lds_bytes, FwdBf16Args& args, FwdArgs& a,
-                          const umnn_mlp* net, int P, int ns, int nb_steps, hipStream_t stream, const FwdOvfPlan* ovf) {
+                          const umnn_mlp* net, int P, int ns, int nb_steps, hipStream_t stream, const FwdOvfPlan* ovf, int block) {
     args.f.ovf_mode = ovf ? ovf->mode : 0;
     args.f.ovf_flag = ovf ? ovf->flag : nullptr;
     args.f.ovf_gen = ovf ? ovf->gen : 0;
 #ifdef UMNN_FWD_PIECE_F16
     umnn_prof_begin(stream);
-    hipLaunchKernelGGL(fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
+    hipLaunchKernelGGL(fn, dim3(nblk), dim3(block), lds_bytes, stream, args);
     const FwdOvfPlan second{2, ovf->flag, ovf->gen};
     int rc = umnn_check(hipGetLastError(), "cc_fwd_f16 launch");
     if (!rc) rc = umnn_launch_forward_bf16(a, net, 2, P, ns, nb_steps, stream, &second);
@@ -81,7 +87,7 @@ static int launch_planned(fwd_bf16_kernel_t fn, const char* name, unsigned nblk,
 #else
     (void)P; (void)ns;
     if (!ovf) umnn_prof_begin(stream);
-    hipLaunchKernelGGL(fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
+    hipLaunchKernelGGL(fn, dim3(nblk), dim3(block), lds_bytes, stream, args);
     if (!ovf) {
         umnn_prof_end(stream, umnn_cc_forward_flops_per_integral(net, nb_steps) * (double)a.NI);
         umnn_note_launch(name);
@@ -114,9 +120,16 @@ int FWD_LAUNCH(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int n
     int wide = (nparts == 2 && tmax >= 5) ? tmax : 0;
     for (int l = 1; l <= L && wide; ++l) if (a.m.t_out[l] != wide) wide = 0;
     if (wide && (P == 1 || !p_forced)) { T = wide; P = 1; } else wide = 0;    // (no two-tile variant at these widths)
+    // uniform wide nets: how many workgroups of images fit a CU?  One -> eight waves per workgroup (both waves of every SIMD share the
+    // images); two -> four waves each.  Either way a CU runs eight waves.
+    int wpb = UMNN_WAVES_PER_BLOCK;
+    if (wide) {
+        const size_t img = (size_t)(L - 1) * wide * ((wide / 2) * nparts * 512 + (wide & 1) * nparts * 256) * sizeof(unsigned short);
+        if (2 * (img + 1024) > 160 * 1024) wpb = 8;
+    }
     if (wide && !ns_forced) {
-        // images this large leave one or two workgroups per CU: split the node range only as far as that fills the SIMDs
-        const long long tiles16 = (a.NI + 15) / 16, slots = (long long)umnn_num_cus() * 4 * (wide >= 7 ? 1 : 2);
+        // split the node range only as far as that fills the SIMDs (two waves each)
+        const long long tiles16 = (a.NI + 15) / 16, slots = (long long)umnn_num_cus() * 8;
         ns = tiles16 * 4 <= slots ? 4 : tiles16 * 2 <= slots ? 2 : 1;
         if (ns > nb_steps + 1) ns = 1;
     }
@@ -158,7 +171,7 @@ int FWD_LAUNCH(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int n
                 args.f.ngroups = (unsigned)((a.NI + 16 * pick->p - 1) / (16 * pick->p));
                 const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
                 const unsigned nblk = (args.f.ngroups + gpb - 1) / gpb;
-                return launch_planned(pick->fn, pick->name, nblk, lds_bytes, args, a, net, pick->p, ns, nb_steps, stream, ovf);
+                return launch_planned(pick->fn, pick->name, nblk, lds_bytes, args, a, net, pick->p, ns, nb_steps, stream, ovf, UMNN_BLOCK);
             }
             args.f = a;         // (not launched: fall through to the generic plan)
         }
@@ -202,13 +215,15 @@ int FWD_LAUNCH(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int n
     // (measured at the POWER and VAE shapes: P=2, NS=1 beats every P=1 split by 6-7 %)
     if (want_pipe && exact && T == 4 && nparts == 2 && !p_forced && !ns_forced &&
         (a.NI + 15) / 16 >= 2LL * umnn_num_cus() * 4) { P = 2; ns = 1; }
-    const size_t lds_bytes = ((size_t)args.f.m.lds_off[L] + (ns > 1 ? UMNN_WAVES_PER_BLOCK * 3 * P * 16 : 0)) * sizeof(float);
+    if (!(wide && exact)) wpb = UMNN_WAVES_PER_BLOCK;
+    size_t lds_bytes = ((size_t)args.f.m.lds_off[L] + (ns > 1 ? wpb * 3 * P * 16 : 0)) * sizeof(float);
+    if (lds_bytes > 160 * 1024 && wpb == 8) { wpb = UMNN_WAVES_PER_BLOCK; lds_bytes = ((size_t)args.f.m.lds_off[L] + (ns > 1 ? wpb * 3 * P * 16 : 0)) * sizeof(float); }
     if (lds_bytes > 160 * 1024) return UMNN_EUNSUPPORTED;
     const Bf16Variant* pick = nullptr;
     for (int ex = exact; ex >= 0 && !pick; --ex)
         for (int pass = 0; pass < 2 && !pick; ++pass)      // pass 0: a variant with exactly this live-register count
             for (const Bf16Variant& v : kBf16Variants)
-                if (v.tmax == T && v.nparts == nparts && v.p == P && v.exact == ex && (!v.pipe || want_pipe) &&
+                if (v.tmax == T && v.nparts == nparts && v.p == P && v.exact == ex && (!v.pipe || want_pipe) && v.wpb == (ex ? wpb : 4) &&
                     (pass == 0 ? (ex && nrl && v.nrl == nrl) : v.nrl == 0)) { pick = &v; break; }
     if (!pick) return UMNN_EUNSUPPORTED;
     fwd_bf16_kernel_t kfn = pick->fn;
@@ -216,7 +231,7 @@ int FWD_LAUNCH(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int n
     if (int rc = umnn_allow_lds((const void*)kfn, lds_bytes)) return rc;
     args.f.ns = ns;
     args.f.ngroups = (unsigned)((a.NI + 16 * P - 1) / (16 * P));
-    const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
+    const unsigned gpb = pick->wpb / ns;
     const unsigned nblk = (args.f.ngroups + gpb - 1) / gpb;
-    return launch_planned(kfn, kname, nblk, lds_bytes, args, a, net, P, ns, nb_steps, stream, ovf);
+    return launch_planned(kfn, kname, nblk, lds_bytes, args, a, net, P, ns, nb_steps, stream, ovf, 64 * pick->wpb);
 }

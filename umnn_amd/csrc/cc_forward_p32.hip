@@ -16,6 +16,9 @@
 // Per layer 2 M-tiles x 10 = 20 matrix instructions + 3 that return the split remainders (a - bf16(a), exact, as in the
 // pipelined 16x16x32 kernel).  Weight fragments: 7 per M-tile and layer (Whi c0..2, Wlo c0..2, merged), 14 KB per layer in LDS,
 // streamed (each is used by one or two consecutive instructions: no fragment cache in registers).
+#ifndef UMNN_ASM_TIED
+#define UMNN_ASM_TIED 1      // cc_common.h: inline-assembly outputs tied to inputs in the forward translation units
+#endif
 #include "cc_bf16.h"
 #include "cc_fwd_bf16_kernel.h"
 using namespace UMNN_FWD_NS;

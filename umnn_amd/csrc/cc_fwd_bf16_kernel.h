@@ -240,8 +240,11 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
 // to start with, `iter` rounds, the new bracket is the pair of candidates around the one whose image is closest to the
 // target); every round integrates all ten candidates with the node loop below, the search itself is a 16-lane butterfly.
 // The hoisted first-layer term depends on the sample only and is computed once for all rounds.
-template <int TMAX, int NPARTS, int P, bool EXACT, int NRL, bool PIPE = false, bool INV = false, int TREST = 0>
-__global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Args args) {
+// WPB: waves per workgroup.  Eight for the shapes whose weight images leave room for ONE workgroup per CU (uniform 6..8-tile nets, deep
+// 5-tile ones: 100-wide toy / MonotonicNN integrands stage 98-147 KB): the second wave of every SIMD then comes from the same
+// workgroup and shares its images, instead of the SIMD running one wave with nothing to overlap its vector phases with.
+template <int TMAX, int NPARTS, int P, bool EXACT, int NRL, bool PIPE = false, bool INV = false, int TREST = 0, int WPB = UMNN_WAVES_PER_BLOCK>
+__global__ __launch_bounds__(64 * WPB) void cc_fwd_bf16_kernel(const FwdBf16Args args) {
     static_assert(TREST == 0 || (EXACT && !PIPE && TREST < TMAX && (TREST & 1) == 0), "wide-first-layer variants: exact, plain loop");
     static_assert(!INV || (P == 1 && !PIPE), "inversion variants: plain loop, one tile per wave");
     constexpr int KSM = TMAX / 2;
@@ -264,12 +267,12 @@ __global__ __launch_bounds__(UMNN_BLOCK) void cc_fwd_bf16_kernel(const FwdBf16Ar
     // queued behind an fp16-piece launch as its overflow fallback: nothing to do unless that launch raised the flag (cc_fwd_shared.h)
     if (a.ovf_mode == 2 && *a.ovf_flag < a.ovf_gen) return;
 
-    stage_bf16_images<NPARTS, MERGE ? 1 : MERGE_REST ? 2 : 0>(m, args.pl.ks32, args.pl.off16, args.pl.half_in, lds16, tid, UMNN_BLOCK);
+    stage_bf16_images<NPARTS, MERGE ? 1 : MERGE_REST ? 2 : 0>(m, args.pl.ks32, args.pl.off16, args.pl.half_in, lds16, tid, 64 * WPB);
     __syncthreads();
 
     const int ns = a.ns;
     const int sub = wid / ns, part = wid % ns;
-    const unsigned gpb = UMNN_WAVES_PER_BLOCK / ns;
+    const unsigned gpb = WPB / ns;
     const unsigned grp = xcd_remap(blockIdx.x, gridDim.x) * gpb + sub;
     bool live = grp < a.ngroups;
     if (a.ovf_mode == 2 && live) {                                                                    // ... and then only the deferred groups

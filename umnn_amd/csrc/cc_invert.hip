@@ -14,6 +14,9 @@
 // forward's overflow protocol (cc_forward_bf16.hip): a sample for which any candidate integral of any round was not finite gets a NaN
 // in its slot of x_inv[:, j] and raises the launch's flag word; the two-piece bf16 build of the same search, queued right behind it,
 // returns at once when the flag is down and otherwise redoes exactly the samples whose slot holds the NaN.
+#ifndef UMNN_ASM_TIED
+#define UMNN_ASM_TIED 1      // cc_common.h: inline-assembly outputs tied to inputs in the forward translation units
+#endif
 #include "cc_fwd_bf16_kernel.h"
 using namespace UMNN_FWD_NS;
 #ifdef UMNN_FWD_PIECE_F16
