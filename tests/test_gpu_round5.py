@@ -436,3 +436,37 @@ def test_block_level_compute_ll_in_training_mode_still_clamps_in_place(dev):
     assert float(z.detach().abs().max()) <= 10.0
     ll.mean().backward()
     assert all(torch.isfinite(p.grad).all() for p in blk.parameters() if p.requires_grad and p.grad is not None)
+
+
+def test_overflow_protocol_through_the_stacked_blocks_and_bf16_storage(dev, restore_precision):
+    """The marker lives in z for the flow entry points -- written REVERSED between the blocks of a flow (umnn_flow_stack_block_forward)
+    -- and in whatever storage type the caller keeps its tensors in (umnn_*_io: bf16 x-class tensors).  Overflowing rows through
+    UMNNMAFFlow.forward / compute_log_jac_bis (three blocks, reversal on) and through hip_forward on bf16 tensors: finite, the
+    overflowing rows equal to the bf16x3 run, the others to a batch without them."""
+    import umnn_amd
+    from umnn_amd import integral as I
+    model = _flow(dev, nb_flow=3, seed=7)
+    torch.manual_seed(8)
+    x = torch.randn(300, 6, device=dev)
+    x[:4] *= 2e6
+    out = {}
+    with torch.no_grad():
+        for mode in ("bf16x3", "f16x3"):
+            umnn_amd.set_forward_precision(mode)
+            out[mode] = (model(x), *model.compute_log_jac_bis(x))
+        clean = (model(x[48:].contiguous()), *model.compute_log_jac_bis(x[48:].contiguous()))
+    for a_, b_, c_ in zip(out["f16x3"], out["bf16x3"], clean):
+        assert not torch.isnan(a_).any()
+        assert torch.isfinite(a_[48:]).all() and torch.equal(a_[48:], c_)
+        fin = torch.isfinite(b_[:4])
+        assert torch.equal(a_[:4][fin], b_[:4][fin])          # (block 1's rows are the bf16 build's; later blocks see its z)
+    # bf16 storage of x / h / F (configuration C4's mode): the marker is a bf16 NaN
+    net, spec, xs, hs = _overflow_case(dev, B=200, rows=5)
+    xb, hb = xs.bfloat16(), hs.bfloat16()
+    umnn_amd.set_forward_precision("bf16x3")
+    Fb, fb, _ = I.hip_forward(spec, None, xb, hb, 30)
+    umnn_amd.set_forward_precision("f16x3")
+    Ff, ff, _ = I.hip_forward(spec, None, xb, hb, 30)
+    assert Ff.dtype == torch.bfloat16 and torch.isfinite(Ff.float()).all() and torch.isfinite(ff.float()).all()
+    assert torch.equal(Ff[:5], Fb[:5]) and torch.equal(ff[:5], fb[:5])
+    assert float(((Ff.float() - Fb.float()).abs() / Fb.float().abs().clamp(min=1.0)).max()) < 1e-2      # (one bf16 ulp of the stored result)

@@ -36,9 +36,11 @@ int umnn_invert_impl_f16(const umnn_mlp* net, const float* h, const float* z, co
                          const InvOvfPlan* ovf);
 
 typedef void (*inv_kernel_t)(const FwdBf16Args);
-struct InvVariant { int tmax, exact, nrl, nparts; inv_kernel_t fn; const char* name; };
-#define INV_VARIANT(T, EX, NR) { T, EX, NR, 2, cc_fwd_bf16_kernel<T, 2, 1, (EX) != 0, NR, false, true>, INV_KNAME "<T=" #T ",EXACT=" #EX ",LIVE=" #NR ">" }
-#define INV_VARIANT3(T, EX, NR) { T, EX, NR, 3, cc_fwd_bf16_kernel<T, 3, 1, (EX) != 0, NR, false, true>, INV_KNAME "<T=" #T ",PARTS=3,EXACT=" #EX ",LIVE=" #NR ">" }
+struct InvVariant { int tmax, exact, nrl, nparts, wpb; inv_kernel_t fn; const char* name; };
+#define INV_VARIANT(T, EX, NR) { T, EX, NR, 2, 4, cc_fwd_bf16_kernel<T, 2, 1, (EX) != 0, NR, false, true>, INV_KNAME "<T=" #T ",EXACT=" #EX ",LIVE=" #NR ">" }
+// (eight waves per workgroup: images that leave room for one workgroup per CU -- WPB in cc_fwd_bf16_kernel.h)
+#define INV_VARIANT_W8(T, NR) { T, 1, NR, 2, 8, cc_fwd_bf16_kernel<T, 2, 1, true, NR, false, true, 0, 8>, INV_KNAME "<T=" #T ",EXACT=1,LIVE=" #NR ",WAVES=8>" }
+#define INV_VARIANT3(T, EX, NR) { T, EX, NR, 3, 4, cc_fwd_bf16_kernel<T, 3, 1, (EX) != 0, NR, false, true>, INV_KNAME "<T=" #T ",PARTS=3,EXACT=" #EX ",LIVE=" #NR ">" }
 // wide first hidden layer over a narrow rest (MNISTExperiment's integrand: sampling d = 784 images is 3 920 of these launches)
 struct InvWideFirst { int t1, nrl; inv_kernel_t fn; const char* name; };
 #define INV_WIDE_FIRST(T, NR) { T, NR, cc_fwd_bf16_kernel<T, 2, 1, true, NR, false, true, 4>, INV_KNAME "<T1=" #T ",TREST=4,LIVE=" #NR ">" }
@@ -48,6 +50,7 @@ static const InvVariant kInvVariants[] = {
     INV_VARIANT(4, 1, 13), INV_VARIANT(4, 1, 0),       // UCI / VAE nets (31-50^4-1) and every other 3..4-tile net (zero-padded)
     INV_VARIANT(7, 1, 26), INV_VARIANT(7, 1, 0),       // 100-wide toy nets
     INV_VARIANT(5, 1, 0), INV_VARIANT(6, 1, 0), INV_VARIANT(8, 1, 0),
+    INV_VARIANT_W8(7, 26), INV_VARIANT_W8(7, 0), INV_VARIANT_W8(5, 0), INV_VARIANT_W8(6, 0), INV_VARIANT_W8(8, 0),
     INV_VARIANT(2, 0, 0), INV_VARIANT(4, 0, 0), INV_VARIANT(8, 0, 0),   // generic (runtime tile counts): mixed widths, e.g. 100-50-50-50-50
 #ifndef UMNN_FWD_PIECE_F16
     // three pieces / six cross terms (fwd_precision = fp32 | bf16x6): nets of up to four tiles per layer
@@ -71,10 +74,10 @@ int INV_IMPL(const umnn_mlp* net, const float* h, const float* z, const float* s
 #endif
     a.ovf_mode = ovf ? ovf->mode : 0; a.ovf_flag = ovf ? ovf->flag : nullptr; a.ovf_gen = ovf ? ovf->gen : 0;
     // the planned launch: fp16 build = the launch, then the two-piece bf16 build of the same search queued as its fallback
-    auto launch = [&](inv_kernel_t fn, const char* name, unsigned nblk, size_t lds_bytes) -> int {
+    auto launch = [&](inv_kernel_t fn, const char* name, unsigned nblk, size_t lds_bytes, int block = UMNN_BLOCK) -> int {
         const bool queued = ovf && ovf->mode == 2;
         if (!queued) umnn_prof_begin(stream);
-        hipLaunchKernelGGL(fn, dim3(nblk), dim3(UMNN_BLOCK), lds_bytes, stream, args);
+        hipLaunchKernelGGL(fn, dim3(nblk), dim3(block), lds_bytes, stream, args);
         int rc = umnn_check(hipGetLastError(), "cc_invert launch");
 #ifdef UMNN_FWD_PIECE_F16
         const InvOvfPlan second{2, ovf->flag, ovf->gen};
@@ -155,17 +158,18 @@ int INV_IMPL(const umnn_mlp* net, const float* h, const float* z, const float* s
     if (lds_bytes > 160 * 1024) return umnn_fail(UMNN_EUNSUPPORTED, "invert: weight images exceed 160 KiB of LDS");
     // exact variant for (T, live registers) if instantiated, else the generic one of the tile-count bucket (runtime counts:
     // only reached by unpadded plans -- every padded or wide plan has its exact variant above)
+    const int wpb = (wide && exact && nparts == 2 && 2 * (lds_bytes + 1024) > 160 * 1024) ? 8 : 4;      // one workgroup per CU: eight waves
     const InvVariant* pick = nullptr;
     for (int ex = exact; ex >= 0 && !pick; --ex)
         for (int pass = 0; pass < 2 && !pick; ++pass)
             for (const InvVariant& v : kInvVariants)
-                if (v.tmax == (ex ? T : (tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8)) && v.exact == ex && v.nparts == nparts &&
+                if (v.tmax == (ex ? T : (tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8)) && v.exact == ex && v.nparts == nparts && v.wpb == (ex ? wpb : 4) &&
                     (pass == 0 ? (ex && nrl && v.nrl == nrl) : v.nrl == 0)) { pick = &v; break; }
     if (!pick) return umnn_fail(UMNN_EUNSUPPORTED, "invert: no kernel variant for this shape");
     if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
     a.ngroups = (unsigned)B;                                  // one tile (= one sample) per wave
-    const unsigned nblk = (a.ngroups + UMNN_WAVES_PER_BLOCK - 1) / UMNN_WAVES_PER_BLOCK;
-    return launch(pick->fn, pick->name, nblk, lds_bytes);
+    const unsigned nblk = (a.ngroups + pick->wpb - 1) / pick->wpb;
+    return launch(pick->fn, pick->name, nblk, lds_bytes, 64 * pick->wpb);
 }
 
 #ifndef UMNN_FWD_PIECE_F16
