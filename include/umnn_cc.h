@@ -163,6 +163,25 @@ int umnn_cc_backward(const umnn_mlp* net, const float* x0, const float* x, const
                      void* workspace, long long workspace_bytes, void* stream);
 long long umnn_cc_backward_workspace_bytes(const umnn_mlp* net, long long B, int d, int E);
 
+/* Training forward / backward pair for nets of the three-stage backward family (first hidden layer of 5..8 sixteen-feature tiles
+ * over 2..4 narrower ones: MNISTExperiment's 31-100-50-50-50-50-1, /root/reference MNISTExperiment.py:238).  That backward recomputes
+ * the pre-activations z_2 of hidden layer 2 at every node in its stage A and hands them to stage B through HBM; the forward has just
+ * computed the same numbers.  umnn_flow_stack_block_forward_save = umnn_flow_stack_block_forward that also leaves them in z2_save
+ * ([tile][node][register][lane] fp32, umnn_cc_forward_z2_floats() floats: 0.83 GB for 100 x 784 integrals at n = 50);
+ * umnn_cc_backward_saved = umnn_cc_backward (lower limit 0) that reads them and runs stage A for the tangent element of the g_fx term
+ * only.  umnn_cc_forward_z2_floats returns 0 when the pair does not apply (other nets; fwd_precision fp32 / bf16x6; bwd_precision fp32):
+ * callers then use the plain entry points.  Trade: memory held from forward to backward for ~0.26 ms per MNIST-shaped block. */
+long long umnn_cc_forward_z2_floats(const umnn_mlp* net, long long B, int d, int E, int nb_steps);
+int umnn_flow_stack_block_forward_save(const umnn_mlp* net, const float* x, const float* h, const float* scaling,
+                                       const float* cc_w, const float* cc_s, int nb_steps,
+                                       long long B, int d, int E, int reverse_z, const float* log_jac_in,
+                                       float* z, float* log_jac, float* f_x, float* f_x0,
+                                       float* z2_save, long long z2_floats, void* stream);
+int umnn_cc_backward_saved(const umnn_mlp* net, const float* x, const float* h, const float* g, const float* g_fx,
+                           const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
+                           float* dx, float* dh, float* dtheta, const float* z2_saved, long long z2_floats,
+                           void* workspace, long long workspace_bytes, void* stream);
+
 /* Elementwise glue of a block's TRAINING path (umnn_amd/csrc/cc_flow_glue.hip), one launch each.
  * umnn_flow_block_cotangents: backward of the block epilogue (UMNNMAF.py:80-83,134,138-139)
  *     z[b, rev(i)] = exp(s_i) (F[b,i] + h_0[b,i]),  log_jac[b,i] = log(f_x[b,i] + 1e-10) + s_i      (rev(i) = d-1-i if reverse_z)

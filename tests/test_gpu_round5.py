@@ -327,12 +327,16 @@ def backward_truth_report(dev, B, d, hid, n, seed, wscale, gfx_scale, chunk, rou
         _lib.set_backward_precision(prec)
         try:
             with _lib.options(**opts):
-                out = I.hip_backward(spec, None, x, h, g, gf, n)
+                z2 = None
+                if key.startswith("z2 from the forward"):      # the training pair: forward leaves z_2, backward skips its stage A
+                    z2 = I.hip_flow_block(spec, x, h, torch.zeros(d, device=dev), n, save_z2=True)[4]
+                    assert z2 is not None, "umnn_cc_forward_z2_floats says the pair does not apply"
+                out = I.hip_backward(spec, None, x, h, g, gf, n, need=(z2 is None, True, True, True), z2_saved=z2)
                 torch.cuda.synchronize()
                 kernels[key] = _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode()
         finally:
             _lib.set_backward_precision("bf16x3")
-        rep[key] = {k: T.scaled_err(o, r) for k, o, r in zip(names, out, truth)}
+        rep[key] = {k: T.scaled_err(o, r) for k, o, r in zip(names, out, truth) if o is not None}
         # d_h rows that are off by more than 1e-4 of the largest entry (kink decisions: each moves its own row only)
         row = (out[2].double() - truth[2]).abs().amax(dim=1) / truth[2].abs().max()
         rep[key]["dh_rows_over_1e-4"] = int((row > 1e-4).sum())
@@ -369,7 +373,8 @@ def test_default_backward_against_float64_truth_at_the_benchmarked_c3_size(dev):
     assert dflt["dh_rows_over_1e-4"] <= 3 * exact["dh_rows_over_1e-4"] + 40, (dflt["dh_rows_over_1e-4"], exact["dh_rows_over_1e-4"])
 
 
-MNIST_ROUTES = (("default (three stages, fp16 pieces)", {}, "bf16x3"),
+MNIST_ROUTES = (("z2 from the forward + stages B, C (the training path's default)", {}, "bf16x3"),
+                ("default (three stages, fp16 pieces)", {}, "bf16x3"),
                 ("three stages, bf16 pieces", {"bwd_ws16": 0}, "bf16x3"),
                 ("three stages, six bf16 terms (bwd_precision = fp32)", {}, "fp32"))
 
@@ -387,6 +392,9 @@ def test_default_backward_against_float64_truth_at_the_benchmarked_mnist_size(de
     worst32 = max(six["dtheta"], ref32["dtheta"])
     assert dflt["dtheta"] <= max(1.5 * worst32, 1e-4), (dflt["dtheta"], six["dtheta"], ref32["dtheta"])
     assert dflt["dtheta"] < 4e-4 and dflt["dx0"] < 1e-4
+    saved = rep["z2 from the forward + stages B, C (the training path's default)"]
+    assert saved["dtheta"] <= max(1.5 * worst32, 1e-4) and saved["dtheta"] < 4e-4, (saved["dtheta"], worst32)
+    assert saved["dh_row_median"] <= 1.5 * six["dh_row_median"] + 1e-6
     # (a row of d_h is a SAMPLE here: 784 integrals x 51 nodes x 300 hidden units -- the typical row already contains a kink decision
     # inside float32 noise; measured 8.7e-6 default / 1.0e-5 six-term build)
     assert dflt["dh_row_median"] <= 1.5 * six["dh_row_median"] + 1e-6 and dflt["dh_rows_over_1e-4"] <= 2 * six["dh_rows_over_1e-4"] + 5
@@ -470,3 +478,30 @@ def test_overflow_protocol_through_the_stacked_blocks_and_bf16_storage(dev, rest
     assert Ff.dtype == torch.bfloat16 and torch.isfinite(Ff.float()).all() and torch.isfinite(ff.float()).all()
     assert torch.equal(Ff[:5], Fb[:5]) and torch.equal(ff[:5], fb[:5])
     assert float(((Ff.float() - Fb.float()).abs() / Fb.float().abs().clamp(min=1.0)).max()) < 1e-2      # (one bf16 ulp of the stored result)
+
+
+def test_training_pair_with_saved_z2_matches_the_recomputing_backward(dev, monkeypatch):
+    """umnn_flow_stack_block_forward_save + umnn_cc_backward_saved (31-100-50^4-1: the three-stage backward family) through the module
+    API: a training step of a two-block flow with the z_2 hand-over (default) against the same step with it disabled (the backward
+    recomputes z_2 in its stage A): same ll / z bit for bit (the forward arithmetic is the same kernel), every gradient to 1e-4 of its
+    largest entry (stage A scales its low weight piece, the forward does not: kink decisions inside rounding noise may differ), and
+    the kernel books show stage A gone."""
+    import umnn_amd
+    from umnn_amd import integral as I, _lib
+    torch.manual_seed(4)
+    model = umnn_amd.UMNNMAFFlow(nb_flow=2, nb_in=48, hidden_derivative=[100, 50, 50, 50, 50], hidden_embedding=[64, 64], embedding_s=30,
+                                 nb_steps=50, solver="CCParallel", device=str(dev)).to(dev).train()
+    x = torch.randn(96, 48, device=dev)
+    res = {}
+    for tag, cap in (("saved", 2 << 30), ("recomputed", 0)):
+        monkeypatch.setattr(I, "_Z2_MAX_BYTES", cap)
+        model.zero_grad(set_to_none=True)
+        n0 = _lib.lib().umnn_launch_count()
+        ll, z = model.compute_ll(x)
+        (-ll.mean()).backward()
+        torch.cuda.synchronize()
+        res[tag] = (ll.detach(), z.detach(), [p.grad.clone() for p in model.parameters() if p.requires_grad], _lib.lib().umnn_launch_count() - n0)
+        assert _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode().endswith("FRONT>")
+    assert torch.equal(res["saved"][0], res["recomputed"][0]) and torch.equal(res["saved"][1], res["recomputed"][1])
+    for a_, b_ in zip(res["saved"][2], res["recomputed"][2]):
+        assert float((a_ - b_).abs().max() / b_.abs().max().clamp(min=1e-30)) < 1e-4, a_.shape

@@ -86,6 +86,12 @@ SIGNATURES = {
     "umnn_profile_read_tag": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_ll),
                                              ctypes.POINTER(ctypes.c_double)]),
     "umnn_last_kernel_name_of": (ctypes.c_char_p, [ctypes.c_int]),
+    "umnn_cc_forward_z2_floats": (_ll, [ctypes.POINTER(MlpDesc), _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "umnn_flow_stack_block_forward_save": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                                          _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
+                                                          _fp, _fp, _fp, _fp, _fp, _ll, _fp]),
+    "umnn_cc_backward_saved": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                              _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _ll, _fp, _ll, _fp]),
     "umnn_flow_block_cotangents": (ctypes.c_int, [_fp, _fp, _fp, _fp, _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
     "umnn_flow_ll_forward": (ctypes.c_int, [_fp, _fp, _ll, ctypes.c_int, _fp, _fp]),
     "umnn_flow_ll_backward": (ctypes.c_int, [_fp, _fp, _ll, ctypes.c_int, _fp, _fp, _fp]),

@@ -821,11 +821,36 @@ extern "C" int umnn_cc_backward(const umnn_mlp* net, const float* x0, const floa
                                workspace, workspace_bytes, stream_);
 }
 
+static int backward_impl(const umnn_mlp* net, const umnn_io* io, const void* x0_, const void* x_, const void* h_,
+                         const void* g_, const void* g_fx_,
+                         const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E, int inv_f,
+                         void* dx0_, void* dx_, void* dh_, float* dtheta,
+                         void* workspace, long long workspace_bytes, void* stream_, const float* z2_saved);
 extern "C" int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const void* x0_, const void* x_, const void* h_,
                                    const void* g_, const void* g_fx_,
                                    const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E, int inv_f,
                                    void* dx0_, void* dx_, void* dh_, float* dtheta,
                                    void* workspace, long long workspace_bytes, void* stream_) {
+    return backward_impl(net, io, x0_, x_, h_, g_, g_fx_, cc_w, cc_s, nb_steps, B, d, E, inv_f, dx0_, dx_, dh_, dtheta, workspace,
+                         workspace_bytes, stream_, nullptr);
+}
+// umnn_cc_backward (lower limit 0, fp32 storage) with the z_2 buffer umnn_flow_stack_block_forward_save left: the three-stage family
+// skips its stage A.  z2_floats must be what umnn_cc_forward_z2_floats returned for the same (net, B, d, E, nb_steps).
+extern "C" int umnn_cc_backward_saved(const umnn_mlp* net, const float* x, const float* h, const float* g, const float* g_fx,
+                                      const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
+                                      float* dx, float* dh, float* dtheta, const float* z2_saved, long long z2_floats,
+                                      void* workspace, long long workspace_bytes, void* stream_) {
+    const long long need = umnn_cc_forward_z2_floats(net, B, d, E, nb_steps);
+    if (!z2_saved || need == 0 || z2_floats < need)
+        return umnn_fail(UMNN_EINVAL, "backward (z_2 saved): buffer missing, too small, or not the wide-first family / arithmetic mode");
+    return backward_impl(net, nullptr, nullptr, x, h, g, g_fx, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr, dx, dh, dtheta, workspace,
+                         workspace_bytes, stream_, z2_saved);
+}
+static int backward_impl(const umnn_mlp* net, const umnn_io* io, const void* x0_, const void* x_, const void* h_,
+                         const void* g_, const void* g_fx_,
+                         const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E, int inv_f,
+                         void* dx0_, void* dx_, void* dh_, float* dtheta,
+                         void* workspace, long long workspace_bytes, void* stream_, const float* z2_saved) {
     const float *x0 = (const float*)x0_, *x = (const float*)x_, *h = (const float*)h_, *g = (const float*)g_, *g_fx = (const float*)g_fx_;
     float *dx0 = (float*)dx0_, *dx = (float*)dx_, *dh = (float*)dh_;
     if (int rc = umnn_check_io(io)) return rc;
@@ -852,6 +877,8 @@ extern "C" int umnn_cc_backward_io(const umnn_mlp* net, const umnn_io* io, const
     a.partials = (float*)(ws + pl.ws_partials);
     a.dc = (float*)(ws + pl.ws_dc);
     a.scal = (unsigned*)(ws + pl.ws_scal);
+    a.z2_saved = (pl.ws_front_bytes > 0 && umnn_options().bwd_precision == UMNN_PRECISION_BF16X3) ? z2_saved : nullptr;
+    // (a call the three-stage kernels do not serve -- tiny batches, bwd_precision fp32 -- simply recomputes z_2: the buffer is ignored)
     float* p0 = (float*)(ws + pl.ws_p0);
     if (int rc = umnn_check(hipMemsetAsync(a.partials, 0, (size_t)pl.nwaves * a.n_params * 4, stream), "memset partials")) return rc;
 

@@ -41,6 +41,7 @@ struct FrontArgs {
     int nl2;                // live registers of hidden layer 2
     int accumulate;
     const unsigned* only_if;    // non-null: stage A runs only if *only_if != 0 (queued behind its fp16 build as the overflow fallback)
+    int tz_only;                // z_2 came with the call (BwdArgs::z2_saved): stage A only forms the tangent element of node 0 (g_fx term)
 };
 
 // fragment image of G1 = W[1] (hidden 1 -> hidden 2).  TRANSPOSED = false: rows = hidden-2 features (BT tiles, incl. the
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_fwd_kernel(const Front
         f32x4 c[T1];
         front_prologue<T1>(m, hb, E, d, g, p, c);
         const size_t frag0 = (size_t)item * (size_t)(n + 1) * nl2 * 64 + lane;
-        for (int k = 0; k <= n; ++k) {
+        for (int k = 0; k <= (fa.tz_only ? 0 : n); ++k) {
             const float u = a.ccs[k] + 1.f;
             const float tk = k == 0 ? xv : __fadd_rn(x0v, __fmul_rn(dxv, u) * 0.5f);
             f32x4 z1[T1], act[T1];
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_fwd_kernel(const Front
             for (int t = 0; t < BT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (4 * t + r < nl2) fa.z2[frag0 + ((size_t)k * nl2 + 4 * t + r) * 64] = z2[t][r];
+                    if (4 * t + r < nl2 && !fa.tz_only) fa.z2[frag0 + ((size_t)k * nl2 + 4 * t + r) * 64] = z2[t][r];
             if (k == 0 && fa.tz2) {       // d z2 / d t = G1 (W1[:,0] . act'(z1)): linear in the tangent, no bias
                 f32x4 ta[T1];
 #pragma unroll
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 2) void cc_front_fwd16_kernel(const Fro
         f32x4 c[T1];
         front_prologue<T1>(m, hb, E, d, g, p, c);
         const size_t frag0 = (size_t)item * (size_t)(n + 1) * nl2 * 64 + lane;
-        for (int k = 0; k <= n; ++k) {
+        for (int k = 0; k <= (fa.tz_only ? 0 : n); ++k) {
             const float u = a.ccs[k] + 1.f;
             const float tk = k == 0 ? xv : __fadd_rn(x0v, __fmul_rn(dxv, u) * 0.5f);
             f32x4 z2[BT];
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 2) void cc_front_fwd16_kernel(const Fro
             for (int t = 0; t < BT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (4 * t + r < nl2) fa.z2[frag0 + ((size_t)k * nl2 + 4 * t + r) * 64] = z2[t][r];
+                    if (4 * t + r < nl2 && !fa.tz_only) fa.z2[frag0 + ((size_t)k * nl2 + 4 * t + r) * 64] = z2[t][r];
             if (k == 0 && fa.tz2) {
                 f32x4 tz[BT];
                 front_gemm16<T1>(lds16, lane, [&](int t, int r) { return w1x[t][r] * (fmaf(w1x[t][r], tk, c[t][r]) > 0.f ? 1.f : slope); }, tz);
@@ -707,7 +708,9 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
     if (!fv || !mv) return UMNN_EUNSUPPORTED;
 
     const long long tiles = (base.NI + 15) / 16;
-    const long long per_tile = (2LL * (n + 1) + (base.gfx ? 1 : 0)) * nl2 * 64 * 4;
+    // (z_2 left by the training forward: the scratch holds delta_2 and the tangent only, stage A runs for the tangent element alone)
+    const bool saved = base.z2_saved != nullptr;
+    const long long per_tile = ((saved ? 1LL : 2LL) * (n + 1) + (base.gfx ? 1 : 0)) * nl2 * 64 * 4;
     long long chunk = scratch_bytes / per_tile;
     if (chunk < 1 || !scratch) return UMNN_EUNSUPPORTED;
     if (chunk > tiles) chunk = tiles;
@@ -772,6 +775,7 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
     FrontArgs fa;
     fa.b = base;
     fa.only_if = nullptr;
+    fa.tz_only = saved ? 1 : 0;
     fa.b.ns = 1;
     mid.b.ns = 1;
     mid.b.l_lo = 1;
@@ -781,8 +785,9 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
     umnn_prof_begin(stream);
     for (long long t0 = 0; t0 < tiles; t0 += chunk) {
         const long long nt = tiles - t0 < chunk ? tiles - t0 : chunk;
-        float* z2 = (float*)scratch;
-        float* d2 = z2 + (size_t)nt * (n + 1) * nl2 * 64;
+        float* z2 = saved ? const_cast<float*>(base.z2_saved) + (size_t)t0 * (n + 1) * nl2 * 64 : (float*)scratch;
+        float* d2 = saved ? (float*)scratch : z2 + (size_t)nt * (n + 1) * nl2 * 64;
+        const bool run_a = !saved || base.gfx != nullptr;      // stage A: everything, or (z_2 saved) the tangent element of the g_fx term
         float* tz2 = base.gfx ? d2 + (size_t)nt * (n + 1) * nl2 * 64 : nullptr;
         int nblocks = nblocks_max;
         if ((long long)nblocks * UMNN_WAVES_PER_BLOCK > nt) nblocks = (int)((nt + UMNN_WAVES_PER_BLOCK - 1) / UMNN_WAVES_PER_BLOCK);
@@ -793,22 +798,22 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
         if (hv) {
             // (stages A and B on fp16 pieces, then their bf16 builds behind them that only run if a piece overflowed -- the launch
             // flag, raised by the checks of stage B, which also see a non-finite z_2 from stage A: same outputs, rewritten)
-            hipLaunchKernelGGL(fv->fwd16, dim3(2 * nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);      // (two workgroups per CU)
+            if (run_a) hipLaunchKernelGGL(fv->fwd16, dim3(2 * nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);      // (two workgroups per CU)
             mid.scal = base.scal; mid.only_if = nullptr;
             if (int rc = umnn_ws16_front_launch(mid, nrl, nblocks_max, stream)) { umnn_prof_end(stream, 0.0, UMNN_PROF_BACKWARD); return rc; }
             fa.only_if = mid.only_if = base.scal + 3;            // (Ws16Scal::flag)
-            hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
+            if (run_a) hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
             hipLaunchKernelGGL(wv->fn, dim3(nblocks_max), dim3(64 * WS_WAVES), lds_ws, stream, mid);
             fa.only_if = nullptr;
             used_ws = true;
         } else if (wv && nt >= 4LL * nblocks_max) {
-            hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
+            if (run_a) hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
             hipLaunchKernelGGL(wv->fn, dim3(nblocks_max), dim3(64 * WS_WAVES), lds_ws, stream, mid);
             used_ws = true;
         } else
 #endif
         {
-            hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
+            if (run_a) hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
             hipLaunchKernelGGL(mv->fn, dim3(nblocks * (UMNN_WAVES_PER_BLOCK / wpb_mid)), dim3(64 * wpb_mid), lds_mid, stream, mid);
         }
         hipLaunchKernelGGL(fv->bwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_c, stream, fa);

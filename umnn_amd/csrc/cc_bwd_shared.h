@@ -31,6 +31,8 @@ struct BwdArgs {
     int n_params;
     int scratch_off;                // float offset of the per-wave scratch region in LDS
     int scratch_per_wave;           // floats
+    const float* z2_saved;          // nullable: hidden layer 2's pre-activations of every node, left by the training forward
+                                    // (umnn_flow_stack_block_forward_save) -- the three-stage backward then skips its stage A
     unsigned* scal;                 // 256 B of launch scalars in the workspace (cotangent scale / overflow flag of cc_bwd_ws16_kernel.h)
 };
 

@@ -247,7 +247,7 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
                           float* F, float* f_x, float* f_x0, float* z, float* log_jac, hipStream_t stream,
                           int reverse_z = 0, const float* log_jac_in = nullptr,
                           float* ll = nullptr, unsigned* row_cnt = nullptr, int ll_first = 0, int ll_last = 0,
-                          const umnn_io* io = nullptr) {
+                          const umnn_io* io = nullptr, float* z2_save = nullptr) {
     if (int rc = umnn_check_io(io)) return rc;
     FwdArgs a;
     int tmax = 0, ksu = 0;
@@ -268,6 +268,7 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
     if (ll && a.x_bf16) return umnn_fail(UMNN_EINVAL, "flow ll forward: z / log_jac scratch must be fp32");
     a.NI = B * (long long)d; a.d = d; a.E = E; a.n = nb_steps; a.inv_f = inv_f;
     a.ovf_mode = 0; a.ovf_flag = nullptr; a.ovf_gen = 0;
+    a.z2_save = z2_save; a.z2_nl2 = z2_save ? (net->widths[2] + 1 + 3) / 4 : 0;
 
     // ---- choose the variant: exact (compile-time K-steps) when all hidden layers share a width we
     // instantiated, otherwise the smallest generic tile count that fits
@@ -282,6 +283,8 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
     if (opt_p > 0) P = opt_p;
     if (opt_ns > 0) ns = opt_ns;
 
+    if (z2_save && (opt.fwd_precision == UMNN_PRECISION_FP32 || opt.fwd_precision == UMNN_PRECISION_BF16X6))
+        return umnn_fail(UMNN_EUNSUPPORTED, "forward (z_2 saved): two-piece arithmetic modes only");
     // bf16-split kernels (default): hidden GEMMs on the bf16 matrix cores; falls through to fp32 MFMA when the
     // shape does not fit them (a single hidden layer has no hidden->hidden GEMM at all)
     const int prec = opt.fwd_precision;
@@ -304,6 +307,7 @@ static int launch_forward(const umnn_mlp* net, const float* x0, const float* x, 
         const int rc = umnn_launch_forward_bf16(a, net, prec == UMNN_PRECISION_BF16X3 ? 2 : 3, P, ns, nb_steps, stream, nullptr);
         if (rc != UMNN_EUNSUPPORTED) return rc;
     }
+    if (z2_save) return umnn_fail(UMNN_EUNSUPPORTED, "forward (z_2 saved): this net / launch is not served by the wide-first kernels");
     // TAIL is possible when every hidden layer has the same width H with 16(T-1) <= H <= 16(T-1)+3
     const int H1w = net->widths[1];
     int want_tail = (ksu && ksu == 4 * (tmax - 1) + 1 && H1w - 16 * (tmax - 1) >= 0 && H1w - 16 * (tmax - 1) <= 3) ? 1 : 0;
@@ -371,6 +375,34 @@ extern "C" int umnn_flow_stack_block_forward(const umnn_mlp* net, const float* x
     if (z == x && reverse_z) return umnn_fail(UMNN_EINVAL, "flow forward: z must not alias x when reverse_z is set");
     return launch_forward(net, nullptr, x, h, scaling, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr, f_x, f_x0,
                           z, log_jac, (hipStream_t)stream, reverse_z != 0, log_jac_in);
+}
+
+// The training forward of a block whose backward will be the three-stage family (cc_backward_front.hip): as
+// umnn_flow_stack_block_forward, and the pre-activations of hidden layer 2 at every node are left in z2_save for umnn_cc_backward_saved.
+extern "C" long long umnn_cc_forward_z2_floats(const umnn_mlp* net, long long B, int d, int E, int nb_steps) {
+    MlpDev m;
+    int tmax = 0, ksu = 0;
+    if (umnn_prepare_mlp(net, E, &m, &tmax, &ksu) || B <= 0 || d < 1 || nb_steps < 1) return 0;
+    const int L = m.n_linear - 1;
+    if (L < 3 || L > 5 || m.t_out[1] < 5 || m.t_out[1] > 8) return 0;
+    for (int l = 2; l <= L; ++l) if (m.t_out[l] > 4) return 0;
+    const UmnnOptions& opt = umnn_options();
+    if (opt.fwd_precision == UMNN_PRECISION_FP32 || opt.fwd_precision == UMNN_PRECISION_BF16X6 || opt.bwd_precision != UMNN_PRECISION_BF16X3) return 0;
+    const long long tiles = (B * (long long)d + 15) / 16, nl2 = (net->widths[2] + 1 + 3) / 4;
+    return tiles * (nb_steps + 1) * nl2 * 64;
+}
+extern "C" int umnn_flow_stack_block_forward_save(const umnn_mlp* net, const float* x, const float* h, const float* scaling,
+                                                  const float* cc_w, const float* cc_s, int nb_steps,
+                                                  long long B, int d, int E, int reverse_z, const float* log_jac_in,
+                                                  float* z, float* log_jac, float* f_x, float* f_x0,
+                                                  float* z2_save, long long z2_floats, void* stream) {
+    if (!scaling) return umnn_fail(UMNN_EINVAL, "flow forward: scaling must be non-null");
+    if (z == x && reverse_z) return umnn_fail(UMNN_EINVAL, "flow forward: z must not alias x when reverse_z is set");
+    const long long need = umnn_cc_forward_z2_floats(net, B, d, E, nb_steps);
+    if (need == 0) return umnn_fail(UMNN_EUNSUPPORTED, "flow forward (z_2 saved): not the wide-first family / arithmetic mode");
+    if (!z2_save || z2_floats < need) return umnn_fail(UMNN_EINVAL, "flow forward (z_2 saved): buffer smaller than umnn_cc_forward_z2_floats()");
+    return launch_forward(net, nullptr, x, h, scaling, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr, f_x, f_x0,
+                          z, log_jac, (hipStream_t)stream, reverse_z != 0, log_jac_in, nullptr, nullptr, 0, 0, nullptr, z2_save);
 }
 
 extern "C" int umnn_cc_forward_io(const umnn_mlp* net, const umnn_io* io, const void* x0, const void* x, const void* h,

@@ -176,6 +176,7 @@ int FWD_LAUNCH(FwdArgs& a, const umnn_mlp* net, int nparts, int P, int ns, int n
             args.f = a;         // (not launched: fall through to the generic plan)
         }
     }
+    if (a.z2_save) return UMNN_EUNSUPPORTED;      // (only the wide-first kernels above know how to leave z_2 behind)
     int off16 = 0;
     for (int l = 1; l <= L; ++l) {
         args.pl.half_in[l] = wide ? (wide & 1) : 0;

@@ -747,6 +747,16 @@ __global__ __launch_bounds__(64 * WPB) void cc_fwd_bf16_kernel(const FwdBf16Args
                                     acc[pt][t] = pc_mfma_k16(wh[t][wa], hb[pt][ba], acc[pt][t]);
                         }
                 }
+                if constexpr (TREST > 0 && WIDE && !INV && P == 1) {
+                    if (a.z2_save) {          // (see FwdArgs::z2_save: P = 1, so the tile index is the group index)
+                        float* zs = a.z2_save + ((size_t)grp * (size_t)(n + 1) + k) * a.z2_nl2 * 64 + lane;
+#pragma unroll
+                        for (int t = 0; t < OT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (4 * t + r < a.z2_nl2) zs[(4 * t + r) * 64] = acc[0][t][r];
+                    }
+                }
 #pragma unroll
                 for (int pt = 0; pt < P; ++pt)
 #pragma unroll

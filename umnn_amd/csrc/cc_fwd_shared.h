@@ -38,6 +38,11 @@ struct FwdArgs {
     unsigned long long* ovf_flag;
     unsigned long long ovf_gen;
     int ovf_mode;
+    // training forward of the wide-first family (31-100-50-50-50-50-1): the pre-activations of hidden layer 2 of EVERY node leave for
+    // HBM in the register layout of the three-stage backward's middle stage -- [tile][node][register < z2_nl2][lane], cc_backward_front.hip
+    // -- so that its stage A (which recomputes exactly these) need not run (umnn_flow_stack_block_forward_save).  nullable.
+    float* z2_save;
+    int z2_nl2;
 };
 
 // the marker slot of integral q: element q of F when the launch writes F, else this integral's element of z

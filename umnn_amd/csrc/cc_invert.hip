@@ -94,7 +94,7 @@ int INV_IMPL(const umnn_mlp* net, const float* h, const float* z, const float* s
     a.F = a.fx = a.fx0 = nullptr; a.scaling = scaling; a.z = nullptr; a.logjac = nullptr; a.logjac_in = nullptr;
     a.reverse_z = 0; a.ll = nullptr; a.row_cnt = nullptr; a.ll_first = a.ll_last = 0;
     a.inv_z = z; a.inv_x = x_inv; a.inv_j = j; a.inv_iters = iters;
-    a.NI = B; a.d = d; a.E = E; a.n = nb_steps; a.inv_f = 0; a.ns = 1; a.x_bf16 = 0; a.h_bf16 = 0;
+    a.NI = B; a.d = d; a.E = E; a.n = nb_steps; a.inv_f = 0; a.ns = 1; a.x_bf16 = 0; a.h_bf16 = 0; a.z2_save = nullptr; a.z2_nl2 = 0;
 
     // ---- wide first hidden layer, every other layer at most four tiles: shape-exact family (as in cc_forward_bf16.hip)
     {

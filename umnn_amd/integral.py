@@ -241,11 +241,38 @@ def hip_forward(spec, x0, x, h, nb_steps, inv_f=False):
     return F, fx, fx0
 
 
-def hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z=False, log_jac_in=None):
+_Z2_MAX_BYTES = int(float(os.environ.get("UMNN_SAVE_Z2_MAX_GB", "2")) * (1 << 30))
+
+
+def hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z=False, log_jac_in=None, save_z2=False):
     """Fused block epilogue -> (z, log_jac, f_x, f_x0).  ``reverse_z``: z comes back with its dimensions reversed (the
-    flip between the blocks of a flow); ``log_jac_in``: running log_jac of the previous blocks, added in the kernel."""
+    flip between the blocks of a flow); ``log_jac_in``: running log_jac of the previous blocks, added in the kernel.
+    ``save_z2`` (training forward): -> (z, log_jac, f_x, f_x0, z2) where z2 is the buffer umnn_cc_backward_saved wants, or None when
+    the pair does not apply to this net / arithmetic mode or the buffer would exceed UMNN_SAVE_Z2_MAX_GB (default 2) per block."""
     lib = _lib.lib()
     B, d, E = _shape(spec, x, h)
+    if save_z2:
+        z2 = None
+        if x.dtype == torch.float32 and h.dtype == torch.float32:
+            desc, keep = _desc(spec)
+            nfl = int(lib.umnn_cc_forward_z2_floats(ctypes.byref(desc), B, d, E, int(nb_steps)))
+            if 0 < 4 * nfl <= _Z2_MAX_BYTES:
+                x, h, scaling = _f32c(x), _f32c(h), _f32c(scaling)
+                w, s = device_tables(nb_steps, x.device)
+                z2 = torch.empty(nfl, device=x.device, dtype=torch.float32)
+                z, lj, fx, fx0 = (torch.empty_like(x) for _ in range(4))
+                lj_in = _as(log_jac_in, torch.float32)
+                with torch.cuda.device(x.device):
+                    rc = lib.umnn_flow_stack_block_forward_save(ctypes.byref(desc), _ptr(x), _ptr(h), _ptr(scaling), _ptr(w), _ptr(s),
+                                                                int(nb_steps), B, d, E, 1 if reverse_z else 0, _ptr(lj_in), _ptr(z), _ptr(lj),
+                                                                _ptr(fx), _ptr(fx0), _ptr(z2), nfl,
+                                                                ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+                if rc == 0:
+                    _state.path = "hip"
+                    return z, lj, fx, fx0, z2
+                if rc != _lib.EUNSUPPORTED:
+                    _lib.check(rc, "umnn_flow_stack_block_forward_save")
+        return (*hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z, log_jac_in), None)
     out_dtype = x.dtype
     xd, hd, io = _io_prep(x, h)
     x, h, scaling = _as(x, xd), _as(h, hd), _f32c(scaling)
@@ -341,7 +368,7 @@ def hip_flow_ll_block(spec, x, h, scaling, nb_steps, reverse_z, first, last, ll,
     return z
 
 
-def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True), inv_f=False):
+def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True), inv_f=False, z2_saved=None):
     """-> (dx0, dx, dh, dtheta_flat); entries are None where need[...] is False.  dx0/dx come back in x's dtype, dh in
     h's, dtheta in fp32 (the weights' dtype).  inv_f: the operator integrated 1/f (ParallelNeuralIntegral.py:58-59,70-72)."""
     lib = _lib.lib()
@@ -360,7 +387,11 @@ def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True
         nbytes = lib.umnn_cc_backward_workspace_bytes(ctypes.byref(desc), B, d, E)
         ws = torch.empty(max(int(nbytes), 4), device=x.device, dtype=torch.uint8)
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        if io is None and not inv_f:
+        if z2_saved is not None and io is None and not inv_f and x0 is None and not need[0]:      # (that entry point has no d_x0 output)
+            rc = lib.umnn_cc_backward_saved(ctypes.byref(desc), _ptr(x), _ptr(h), _ptr(g), _ptr(g_fx), _ptr(w), _ptr(s), int(nb_steps),
+                                            B, d, E, _ptr(dx), _ptr(dh), _ptr(dtheta), _ptr(z2_saved), int(z2_saved.numel()),
+                                            _ptr(ws), int(nbytes), stream)
+        elif io is None and not inv_f:
             rc = lib.umnn_cc_backward(ctypes.byref(desc), _ptr(x0), _ptr(x), _ptr(h), _ptr(g), _ptr(g_fx),
                                       _ptr(w), _ptr(s), int(nb_steps), B, d, E,
                                       _ptr(dx0), _ptr(dx), _ptr(dh), _ptr(dtheta), _ptr(ws), int(nbytes), stream)
@@ -505,7 +536,9 @@ class FlowBlockTransform(torch.autograd.Function):
         spec = mlp_spec(integrand)
         ctx.spec, ctx.nb_steps, ctx.integrand, ctx.reverse_z = spec, nb_steps, integrand, bool(reverse_z)
         ctx.shapes = [p.shape for p in params]
-        z, lj, fx, _ = hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z, log_jac_in)
+        # (nets of the three-stage backward family: the forward leaves z_2 of every node for the backward, which then skips stage A)
+        z, lj, fx, _, ctx.z2 = hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z, log_jac_in,
+                                              save_z2=any(ctx.needs_input_grad[7:]) or ctx.needs_input_grad[0] or ctx.needs_input_grad[2])
         ctx.save_for_backward(x.clone(), h, fx, scaling)      # (x cloned: callers clamp z / reuse x in place, UMNNMAF.py:150)
         return z, lj
 
@@ -526,7 +559,8 @@ class FlowBlockTransform(torch.autograd.Function):
             _, dx, dh, dtheta = aten_backward_jac(ctx.integrand, torch.zeros_like(x), x, h, gF, gfx, ctx.nb_steps)
         else:
             need = (False, ctx.needs_input_grad[0], ctx.needs_input_grad[2], any(ctx.needs_input_grad[7:]))
-            _, dx, dh, dtheta = hip_backward(ctx.spec, None, x, h, gF, gfx, ctx.nb_steps, need)
+            _, dx, dh, dtheta = hip_backward(ctx.spec, None, x, h, gF, gfx, ctx.nb_steps, need, z2_saved=ctx.z2)
+            ctx.z2 = None
         if dh is not None:
             dh.view(B, -1, d)[:, 0, :].add_(gF)            # z carries h_0 = embedding row 0 (UMNNMAF.py:80)
         grads, o = [], 0
