@@ -505,3 +505,34 @@ def test_training_pair_with_saved_z2_matches_the_recomputing_backward(dev, monke
     assert torch.equal(res["saved"][0], res["recomputed"][0]) and torch.equal(res["saved"][1], res["recomputed"][1])
     for a_, b_ in zip(res["saved"][2], res["recomputed"][2]):
         assert float((a_ - b_).abs().max() / b_.abs().max().clamp(min=1e-30)) < 1e-4, a_.shape
+
+
+def test_graphed_train_step_with_the_z2_hand_over_inside_the_graph(dev):
+    """GraphedTrainStep on a flow of the three-stage backward family (31-100-50^4-1): the capture holds the forward that leaves z_2
+    (a buffer born inside the capture: the graph's private pool), its queued bf16 fallback, the backward that reads it.  Replays must
+    reproduce eager training: losses and parameters after three steps on changing batches."""
+    import copy
+    import umnn_amd
+    from umnn_amd import _lib
+    torch.manual_seed(33)
+    model_a = umnn_amd.UMNNMAFFlow(nb_flow=2, nb_in=48, hidden_derivative=[100, 50, 50, 50, 50], hidden_embedding=[64, 64], embedding_s=30,
+                                   nb_steps=50, device=dev).to(dev)
+    model_b = copy.deepcopy(model_a)
+    xs = [torch.randn(96, 48, device=dev) for _ in range(3)]
+    opt_a = torch.optim.Adam([p for p in model_a.parameters() if p.requires_grad], lr=1e-3, capturable=True)
+    opt_b = torch.optim.Adam([p for p in model_b.parameters() if p.requires_grad], lr=1e-3, capturable=True)
+    model_a.train(); model_b.train()
+    losses_a = []
+    for x in [xs[0]] + xs:
+        opt_a.zero_grad(set_to_none=True)
+        ll, _ = model_a.compute_ll(x)
+        loss = -ll.mean()
+        loss.backward()
+        opt_a.step()
+        losses_a.append(loss.item())
+    assert _lib.lib().umnn_last_kernel_name_of(_lib.PROF_BACKWARD).decode().endswith("FRONT>")
+    step = umnn_amd.GraphedTrainStep(model_b, opt_b, xs[0], warmup=1)
+    losses_b = [step(x).item() for x in xs]
+    assert max(abs(a - b) for a, b in zip(losses_a[1:], losses_b)) < 1e-5 * max(1.0, abs(losses_a[-1])), (losses_a, losses_b)
+    for (n, pa), (_, pb) in zip(model_a.named_parameters(), model_b.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6), n
