@@ -536,3 +536,50 @@ def test_graphed_train_step_with_the_z2_hand_over_inside_the_graph(dev):
     assert max(abs(a - b) for a, b in zip(losses_a[1:], losses_b)) < 1e-5 * max(1.0, abs(losses_a[-1])), (losses_a, losses_b)
     for (n, pa), (_, pb) in zip(model_a.named_parameters(), model_b.named_parameters()):
         assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6), n
+
+
+def test_sampling_computes_only_the_embedding_columns_it_reads(dev, monkeypatch):
+    """UMNNMAF.invert on a wide unconditional conditioner (d = 160, E = 30: 4800 output rows): per dimension the last masked linear
+    is evaluated on the 30 rows that dimension reads (MADE.raw_rows) instead of all 4800.  Same samples as the full conditioner
+    (to the search's own resolution: a 30-column GEMM may round differently from the 4800-column one), same d launches per block,
+    and a z -> x -> z round trip."""
+    import umnn_amd
+    from umnn_amd import _lib
+    torch.manual_seed(12)
+    model = umnn_amd.UMNNMAFFlow(nb_flow=1, nb_in=160, hidden_derivative=[50] * 4, hidden_embedding=[128, 128], embedding_s=30,
+                                 nb_steps=20, solver="CCParallel", device=str(dev)).to(dev).eval()
+    z = torch.randn(24, 160, device=dev) * 0.5
+    out = {}
+    with torch.no_grad():
+        for flag in ("1", "0"):
+            monkeypatch.setenv("UMNN_INVERT_ROWS", flag)
+            n0 = _lib.lib().umnn_launch_count()
+            out[flag] = model.invert(z, iter=8)
+            assert _lib.lib().umnn_launch_count() - n0 == 160
+        tol = 4 * 100.0 * (2.0 / 9.0) ** 8
+        assert float((out["1"] - out["0"]).abs().max()) < tol
+        assert float((model(out["1"]) - z).abs().max()) < 1e-2
+
+
+@pytest.mark.parametrize("hid", [[50] * 4, [100] * 4, [100, 50, 50, 50, 50]])
+def test_small_batch_sampling_splits_the_node_range_over_the_workgroup(hid, dev):
+    """umnn_flow_invert_dim at small batch: one sample per WORKGROUP, its node range split over all the workgroup's waves (partials
+    meet in LDS once per round).  The same samples searched inside a batch large enough for the one-sample-per-wave plan agree to the
+    search's own resolution (the partial sums add up in a different order), the launch count is unchanged, and the round trip closes.
+    Four-wave, eight-wave (100-wide: one workgroup of images per CU) and wide-first kernels."""
+    import umnn_amd
+    from umnn_amd import _lib
+    torch.manual_seed(len(hid) * 13 + hid[0])
+    model = umnn_amd.UMNNMAFFlow(nb_flow=1, nb_in=3, hidden_derivative=hid, hidden_embedding=[32, 32], embedding_s=8,
+                                 nb_steps=30, solver="CCParallel", device=str(dev)).to(dev).eval()
+    z_small = torch.randn(37, 3, device=dev)
+    z_big = torch.cat([z_small, torch.randn(3000, 3, device=dev)])
+    iters = 9
+    tol = 4 * 100.0 * (2.0 / 9.0) ** iters
+    with torch.no_grad():
+        n0 = _lib.lib().umnn_launch_count()
+        x_small = model.invert(z_small, iter=iters)
+        assert _lib.lib().umnn_launch_count() - n0 == 3
+        x_big = model.invert(z_big, iter=iters)[:37]
+        assert float((x_small - x_big).abs().max()) < tol
+        assert float((model(x_small) - z_small).abs().max()) < 50 * tol

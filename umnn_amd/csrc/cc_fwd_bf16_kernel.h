@@ -788,6 +788,18 @@ __global__ __launch_bounds__(64 * WPB) void cc_fwd_bf16_kernel(const FwdBf16Args
             }
         }
         if constexpr (INV) {
+            if (ns > 1) {
+                // small batches (cc_invert.hip): the node range of this sample's ten integrals is split over ALL waves of the workgroup
+                // (ns = waves per workgroup, one sample per workgroup: every wave of a live workgroup gets here, the barriers are
+                // uniform); partial sums meet in LDS once per round, summed in a fixed order; every wave then runs the same search
+                float* red = lds + m.lds_off[L];
+                if (g == 0) red[wid * 16 + p] = Facc[0];
+                __syncthreads();
+                float tot = 0.f;
+                for (int jj = 0; jj < ns; ++jj) tot += red[(sub * ns + jj) * 16 + p];
+                __syncthreads();
+                Facc[0] = tot;
+            }
             if constexpr (PC_F16) inv_bad = inv_bad || (p < 10 && !(__builtin_fabsf(Facc[0]) < __builtin_inff()));
             // image of every candidate, then argmin_p |z_est - target| over the ten candidate lanes (ties: lower p)
             const float z_est = inv_scale * (inv_off + Facc[0] * dxv[0] * 0.5f);
@@ -813,7 +825,7 @@ __global__ __launch_bounds__(64 * WPB) void cc_fwd_bf16_kernel(const FwdBf16Args
         if constexpr (INV) {
             // overflow protocol (cc_invert.hip): the sample is left to the queued bf16 build, its slot marked with a NaN
             const bool defer = a.ovf_mode == 1 && __any(inv_bad);
-            if (ok[0] && lane == 0) {
+            if (ok[0] && lane == 0 && part == 0) {
                 a.inv_x[qv[0] * d + a.inv_j] = defer ? __builtin_nanf("") : br_best;
                 if (defer) atomicMax(a.ovf_flag, a.ovf_gen);
             }

@@ -90,6 +90,12 @@ int INV_IMPL(const umnn_mlp* net, const float* h, const float* z, const float* s
         }
         return rc;
     };
+    // Small batches: one sample per WORKGROUP, its node range split over all the workgroup's waves (partials meet in LDS once per
+    // round) -- B waves of a 100-image sampling call leave nine SIMDs in ten idle, and every wave walks 10 rounds x (n + 1) nodes
+    // alone.  Taken while all B x wpb waves are resident at once (two per SIMD); the queued bf16 build gets the same plan.
+    auto split_over = [&](int wpb) -> int {
+        return (B * (long long)wpb <= (long long)umnn_num_cus() * 8 && wpb <= nb_steps + 1) ? wpb : 1;
+    };
     a.x0 = nullptr; a.x = nullptr; a.h = h; a.ccw = cc_w; a.ccs = cc_s;
     a.F = a.fx = a.fx0 = nullptr; a.scaling = scaling; a.z = nullptr; a.logjac = nullptr; a.logjac_in = nullptr;
     a.reverse_z = 0; a.ll = nullptr; a.row_cnt = nullptr; a.ll_first = a.ll_last = 0;
@@ -113,7 +119,8 @@ int INV_IMPL(const umnn_mlp* net, const float* h, const float* z, const float* s
                 o16 += 4 * (args.pl.ks32[l] * 2 * 512 + args.pl.half_in[l] * 2 * 256);
             }
             a.m.lds_off[L] = (((o16 + 1) / 2) + 3) & ~3;
-            const size_t lds_bytes = (size_t)a.m.lds_off[L] * sizeof(float);
+            a.ns = split_over(UMNN_WAVES_PER_BLOCK);
+            const size_t lds_bytes = ((size_t)a.m.lds_off[L] + (a.ns > 1 ? UMNN_WAVES_PER_BLOCK * 16 : 0)) * sizeof(float);
             int nrest = a.m.ks_in[2];           // live registers of the later layers when they all agree (13 = widths 48..51)
             for (int l = 2; l <= L; ++l) if (a.m.ks_in[l] != nrest) nrest = 0;
             if (nrest != 13) nrest = 0;
@@ -122,7 +129,8 @@ int INV_IMPL(const umnn_mlp* net, const float* h, const float* z, const float* s
             if (pick && lds_bytes <= 160 * 1024) {
                 if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
                 a.ngroups = (unsigned)B;
-                const unsigned nblk = (a.ngroups + UMNN_WAVES_PER_BLOCK - 1) / UMNN_WAVES_PER_BLOCK;
+                const unsigned gpb = UMNN_WAVES_PER_BLOCK / a.ns;
+                const unsigned nblk = (a.ngroups + gpb - 1) / gpb;
                 return launch(pick->fn, pick->name, nblk, lds_bytes);
             }
             return umnn_fail(UMNN_EUNSUPPORTED, "invert: weight images exceed 160 KiB of LDS");
@@ -166,10 +174,14 @@ int INV_IMPL(const umnn_mlp* net, const float* h, const float* z, const float* s
                 if (v.tmax == (ex ? T : (tmax <= 2 ? 2 : tmax <= 4 ? 4 : 8)) && v.exact == ex && v.nparts == nparts && v.wpb == (ex ? wpb : 4) &&
                     (pass == 0 ? (ex && nrl && v.nrl == nrl) : v.nrl == 0)) { pick = &v; break; }
     if (!pick) return umnn_fail(UMNN_EUNSUPPORTED, "invert: no kernel variant for this shape");
-    if (int rc = umnn_allow_lds((const void*)pick->fn, lds_bytes)) return rc;
-    a.ngroups = (unsigned)B;                                  // one tile (= one sample) per wave
-    const unsigned nblk = (a.ngroups + pick->wpb - 1) / pick->wpb;
-    return launch(pick->fn, pick->name, nblk, lds_bytes, 64 * pick->wpb);
+    a.ngroups = (unsigned)B;                                  // one tile (= one sample) per wave, or per workgroup (small batches)
+    a.ns = split_over(pick->wpb);
+    size_t lds_run = lds_bytes + (a.ns > 1 ? (size_t)pick->wpb * 16 * sizeof(float) : 0);
+    if (lds_run > 160 * 1024) { a.ns = 1; lds_run = lds_bytes; }
+    if (int rc = umnn_allow_lds((const void*)pick->fn, lds_run)) return rc;
+    const unsigned gpb = pick->wpb / a.ns;
+    const unsigned nblk = (a.ngroups + gpb - 1) / gpb;
+    return launch(pick->fn, pick->name, nblk, lds_run, 64 * pick->wpb);
 }
 
 #ifndef UMNN_FWD_PIECE_F16

@@ -230,10 +230,26 @@ class UMNNMAF(nn.Module):
                 x_inv = torch.zeros(B, d, device=dev)
                 scaling = self.scaling.detach().float().contiguous()
                 done = True
+                # Dimension j reads E of the E*d embedding entries.  Wide unconditional conditioners compute only those columns of
+                # their last layer (MADE.raw_rows: for d = 784 that layer is 23 520 rows of which 30 are read) into a standing buffer
+                made = self.net.made
+                E = made.nout // made.nin
+                restrict = (context is None and not isinstance(made, ConditionnalMADE) and self.net.embedding_dtype in (None, torch.float32)
+                            and os.environ.get("UMNN_INVERT_ROWS", "1") != "0")
+                rows_all = (torch.arange(E, device=dev) * d).view(1, E) + torch.arange(d, device=dev).view(d, 1) if restrict else None
+                h_buf = None
                 for j in range(self.input_size):
-                    # umnn_flow_invert_dim reads an fp32 embedding (it has no umnn_io descriptor): a bf16 embedding
-                    # (set_embedding_dtype, autocast) is widened here -- exact -- instead of being misread as fp32
-                    h = self.net.make_embeding(x_inv, context).float().contiguous()
+                    hj = made.raw_rows(x_inv, rows_all[j]) if restrict else None
+                    if hj is not None:
+                        if h_buf is None:
+                            h_buf = torch.zeros(B, E * d, device=dev)
+                        h_buf.view(B, E, d)[:, :, j] = hj
+                        h = h_buf
+                    else:
+                        restrict = False
+                        # umnn_flow_invert_dim reads an fp32 embedding (it has no umnn_io descriptor): a bf16 embedding
+                        # (set_embedding_dtype, autocast) is widened here -- exact -- instead of being misread as fp32
+                        h = self.net.make_embeding(x_inv, context).float().contiguous()
                     if not _I.hip_invert_dim(spec, h, z, scaling, self.nb_steps, j, iter, x_inv):
                         done = False
                         break

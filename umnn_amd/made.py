@@ -414,6 +414,33 @@ class MADE(nn.Module):
         out = self.net(x)
         return out.to(out_dtype) if out_dtype is not None and out.dtype != out_dtype else out
 
+    def raw_rows(self, x, rows):
+        """Output COLUMNS ``rows`` (an int64 device tensor) of ``raw(x)`` only -> [B, len(rows)] fp32, or None when this
+        conditioner / call is not one the restriction pays for (the caller then takes ``raw(x)``).  Sampling needs, per flow dimension
+        j, the E embedding entries of that dimension out of E*d (UMNNMAF.invert, UMNNMAF.py:195-231, recomputes the whole MADE per
+        dimension): for d = 784 the last masked linear is 23 520 rows of which 30 are read.  Inference path only (K-concatenated
+        bf16 GEMMs): hidden layers as in ``raw``, the last layer as [B, 3K+2] x [3K+2, len(rows)] on the selected rows of its cached
+        packed weight."""
+        layers = [l for l in self.net if isinstance(l, MaskedLinear)]
+        x = _to_weight_dtype(x, self.net[0])
+        if len(layers) < 2 or layers[-1].out_features < 4096 or not _fast_path_ok(x):
+            return None
+        from . import _lib
+        lib = _lib.lib()
+        raw = x.contiguous()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        with torch.cuda.device(x.device):
+            for i, layer in enumerate(layers):
+                last = i == len(layers) - 1
+                packed = layer.packed_bf16(None)
+                if last:
+                    packed = packed.index_select(0, rows)
+                op = torch.empty(raw.shape[0], packed.shape[1], dtype=torch.bfloat16, device=x.device)
+                _lib.check(lib.umnn_made_split3(raw.data_ptr(), raw.shape[0], raw.shape[1], 1 if i > 0 else 0,
+                                                op.data_ptr(), op.shape[1], stream), "made_split3")
+                raw = torch.mm(op, packed.t(), out_dtype=torch.float32)
+        return raw
+
     def forward(self, x, context=None):
         if self.nout == 2:       # reference quirk (made.py:114-118): nout == 2 means "Gaussian MADE"
             out = self.net(x)
