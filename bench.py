@@ -286,6 +286,7 @@ def main():
         opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, capturable=bool(args.graph),
                                fused=not args.no_fused_adam)
         step = make_train_step(model, opt, x, ctx, world)
+        eager_step = step
         graph_note = None
         if args.graph and world > 1 and dist.get_backend() == "nccl":
             # RCCL collectives cannot be captured in a hipGraph on this stack (umnn_amd/graphs.py): eager step instead
@@ -308,6 +309,8 @@ def main():
             graphed = umnn_amd.GraphedLL(model, x, context=ctx)
             step = lambda: graphed()        # noqa: E731  (x is already in the captured buffer)
 
+    collective = collective_self_check(model, rank, world, device) if world > 1 else None
+
     for _ in range(args.warmup):
         step()
     lib.umnn_profile_enable(1)
@@ -325,12 +328,14 @@ def main():
     bwd = _lib.profile_read(_lib.PROF_BACKWARD)
     fin = _lib.profile_read(_lib.PROF_FINISH)
     lib.umnn_profile_enable(0)
-    if args.graph and args.mode == "eval":      # launches inside a replayed graph carry no events: time them eagerly
+    if args.graph:      # launches inside a replayed graph carry no events: time them in an eager pass of the same step
         lib.umnn_profile_enable(1)
         for _ in range(max(3, args.steps // 4)):
             eager_step()
         torch.cuda.synchronize()
         fwd = _lib.profile_read(_lib.PROF_FORWARD)
+        bwd = _lib.profile_read(_lib.PROF_BACKWARD)
+        fin = _lib.profile_read(_lib.PROF_FINISH)
         lib.umnn_profile_enable(0)
     assert torch.isfinite(ll).all()
     kernel_name = lib.umnn_last_kernel_name_of(_lib.PROF_FORWARD if args.mode == "eval" else _lib.PROF_BACKWARD).decode()
@@ -488,6 +493,8 @@ def main():
                          "power_cap_w": telemetry.get("power_cap_w") if telemetry else None,
                          "telemetry": telemetry},
             "ranks_seen": len(ranks), "ranks": ranks,
+            "unique_pci_ids": len({r.get("pci_bus_id") for r in ranks}) == len(ranks) if all(r.get("pci_bus_id") is not None for r in ranks) else None,
+            "collective_check": collective,
             "dist": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
                      "backend": dist.get_backend() if dist.is_initialized() else None},
             "env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "set_by": _IPC_SET_BY},
@@ -521,6 +528,37 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def collective_self_check(model, rank, world, device, reps=10):
+    """First contact with a multi-GPU node validates itself (the driver's SCALE run is the first place RCCL with N > 1 executes):
+    before anything is timed, an all-reduce of rank + 1 (checks the sum every rank must see) and of a buffer the size of the
+    flattened gradient -- the ONE collective of the training step (sharding.allreduce_gradients) -- timed over `reps` calls.
+    -> the record bench.py prints as "collective_check"; raises on a wrong sum."""
+    import torch.distributed as dist
+    on_gpu = dist.get_backend() == "nccl"
+    cdev = device if on_gpu else torch.device("cpu")
+    one = torch.full((1,), float(rank + 1), device=cdev, dtype=torch.float64)
+    dist.all_reduce(one)
+    nparam = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    flat = torch.full((nparam,), float(rank + 1), device=cdev, dtype=torch.float32)
+    dist.all_reduce(flat)
+    if on_gpu:
+        torch.cuda.synchronize()
+    tc = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(flat)
+    if on_gpu:
+        torch.cuda.synchronize()
+    tc = (time.perf_counter() - tc) / reps
+    want = world * (world + 1) / 2
+    scale = float(world) ** reps                          # (the timed calls summed the already-reduced buffer `reps` more times)
+    ok = float(one.item()) == want and float(flat[0].item()) == want * scale and float(flat[-1].item()) == want * scale
+    rec = {"allreduce_ok": bool(ok), "allreduce_us": 1e6 * tc, "allreduce_bytes": 4 * nparam, "backend": dist.get_backend(),
+           "algbw_GBps": 4 * nparam / tc / 1e9}
+    if not ok:
+        raise RuntimeError(f"all-reduce self-check failed on rank {rank}: got {float(one.item())}, want {want}")
+    return rec
 
 
 def make_train_step(model, opt, x, ctx, world, clip_value=10.0):

@@ -232,6 +232,9 @@ def _world8_worker(rank, world, port, outdir):
             p.add_(0.01 * rank)
     sharding.broadcast_parameters(model, src=0)
     model.train()
+    # bench.py's first-contact check of the one collective the design depends on (round 6): sum of rank + 1 over 8 ranks = 36
+    rec = bench.collective_self_check(model, rank, world, torch.device("cpu"), reps=2)
+    assert rec["allreduce_ok"] and rec["allreduce_bytes"] == 4 * sum(p.numel() for p in model.parameters() if p.requires_grad)
     torch.manual_seed(21)
     x = torch.randn(40, 3) * 2                                  # the global batch (identical on every rank); 5 rows per rank
     xs = sharding.shard_rows(x, rank, world).contiguous()

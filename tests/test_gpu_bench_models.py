@@ -1,6 +1,6 @@
 """Parity of the EXACT models bench.py times (BASELINE configs C1-C4), at the benchmarked batch sizes, through the default
-arithmetic (bf16x3 quadrature kernels, K-concatenated bf16 conditioner GEMMs, the one-pass log-likelihood epilogue) against the
-pinned CPU oracle on sampled rows (rows are independent; the oracle needs seconds for 32 of them).
+arithmetic (f16x3 quadrature kernels -- the library default since round 5 --, K-concatenated bf16 conditioner GEMMs, the one-pass
+log-likelihood epilogue), and through bf16x3 / exact fp32, against the pinned CPU oracle on sampled rows (rows are independent; the oracle needs seconds for 32 of them).
 
 Reference arithmetic being matched: UMNNMAFFlow.compute_ll / compute_log_jac_bis (models/UMNN/UMNNMAFFlow.py:109-130),
 UMNNMAF.forward / compute_log_jac (models/UMNN/UMNNMAF.py:76-139).  Tolerance: the path's 1e-4 in every mode,
@@ -44,7 +44,7 @@ def _sample_rows(B, k=32, seed=5):
     return rows
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x3", "fp32"])
 @pytest.mark.parametrize("workload", ["bsds300", "power", "toy", "vae", "mnist"])
 def test_benchmarked_model_matches_oracle_at_full_batch(workload, precision, dev):
     import umnn_amd
@@ -53,6 +53,8 @@ def test_benchmarked_model_matches_oracle_at_full_batch(workload, precision, dev
     model = bench.build_model(cfg, dev)
     x, ctx = bench.make_inputs(cfg, cfg["rows"], dev, 1000)          # bench.py's own inputs for rank 0
     old = umnn_amd.get_forward_precision()
+    if precision == "f16x3":
+        assert old == "f16x3", "f16x3 is the library default: this case pins the arithmetic bench.py times"
     umnn_amd.set_precision(precision)
     try:
         launches = _lib.lib().umnn_launch_count()
@@ -64,7 +66,16 @@ def test_benchmarked_model_matches_oracle_at_full_batch(workload, precision, dev
             llb, _ = model.compute_ll_bis(x, context=ctx) if ctx is not None else model.compute_ll_bis(x)
         assert umnn_amd.path_taken() == "hip"
         kname = _lib.lib().umnn_last_kernel_name().decode()
-        assert ("bf16" in kname) == (precision != "fp32"), kname
+        if precision == "f16x3":
+            assert kname.startswith("cc_fwd_f16<"), kname
+            if workload == "toy":                      # 100-wide hidden layers: the eight-wave workgroups of round 5
+                assert "T=7" in kname and "WAVES=8" in kname, kname
+            if workload in ("bsds300", "power", "vae"):
+                assert "LIVE=13" in kname and "PIPE" in kname, kname
+            if workload == "mnist":
+                assert "T1=7,TREST=4" in kname, kname
+        else:
+            assert ("bf16" in kname) == (precision != "fp32"), kname
     finally:
         umnn_amd.set_precision(old)
     rows = _sample_rows(cfg["rows"], 8 if cfg["d"] > 128 else 32)       # (d = 784: 8 rows keep the oracle to seconds)

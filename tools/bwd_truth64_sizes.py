@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/r05/bwd_truth64_c3.txt / _mnist.txt: every backward route at the two benchmarked training shapes against the float64
+"""profiles/r06/bwd_truth64_c3.txt / _mnist.txt: every backward route at the two benchmarked training shapes against the float64
 evaluator of the reference algorithm (tests/_truth64.py), beside a float32 run of the reference's own materialised algorithm.
     python tools/bwd_truth64_sizes.py [outdir]      (GPU box; ~1 min)"""
 import json

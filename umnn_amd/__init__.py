@@ -39,6 +39,11 @@ def set_precision(name):
                handled, not assumed: a tile group in which a hidden activation leaves +-65504 is detected in its quadrature sum,
                writes nothing, and is recomputed by the bf16x3 build of the same kernel queued right behind the launch (idle cost:
                one scalar load per workgroup) -- those integrals come back at bf16x3 accuracy, never NaN, never a wrong number.
+               The BOTTOM of fp16's range is not guarded: the low piece of a hidden activation below ~1e-3 is an fp16 subnormal
+               (it vanishes below ~6e-5), so a net whose hidden activations are uniformly tiny loses relative accuracy on the part of
+               f the hidden layers carry -- measured (tests/test_gpu_round6.py, activations of order 1e-2 / 1e-3 / 1e-4): 1.1e-5 /
+               1.3e-4 / 1.5e-3 of that part, against 5.6e-6 / 5.4e-5 / 5.5e-4 for exact fp32 arithmetic; F and f(x) themselves stay
+               at 2e-7 of max(|ref|, 1).  Use 'bf16x6' or 'fp32' for such nets.
                Conditioner inference GEMMs as K-concatenated bf16 GEMMs (3e-6 of the output range).
     'fp32'   : exact fp32 products everywhere (fp32 MFMA kernels forward and backward, fp32 conditioner GEMMs) -- the
                reference's arithmetic, ~2.4x slower forward.

@@ -79,7 +79,10 @@ int umnn_ovf_slot(unsigned long long** flag, unsigned long long* gen) {
             hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
             (void)hipThreadExchangeStreamCaptureMode(&mode);
             hipError_t e = hipMalloc(&r, 256 * sizeof(unsigned long long));
+            // (hipMemset of device memory is asynchronous to the host and runs on the legacy null stream, which non-blocking streams --
+            // PyTorch's side streams -- are not ordered against: wait for it before the pointer is published)
             if (e == hipSuccess) e = hipMemset(r, 0, 256 * sizeof(unsigned long long));
+            if (e == hipSuccess) e = hipDeviceSynchronize();
             (void)hipThreadExchangeStreamCaptureMode(&mode);
             if (e != hipSuccess) return umnn_check(e, "overflow flag ring");
             __atomic_store_n(&ring[dev], r, __ATOMIC_RELEASE);

@@ -840,9 +840,12 @@ extern "C" int umnn_cc_backward_saved(const umnn_mlp* net, const float* x, const
                                       const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
                                       float* dx, float* dh, float* dtheta, const float* z2_saved, long long z2_floats,
                                       void* workspace, long long workspace_bytes, void* stream_) {
+    // `need` follows the CURRENT process-wide precision options: if they changed between the training forward and this call (need == 0:
+    // the pair no longer applies), the buffer is simply ignored and the backward recomputes z_2 -- as the comment in backward_impl says
     const long long need = umnn_cc_forward_z2_floats(net, B, d, E, nb_steps);
-    if (!z2_saved || need == 0 || z2_floats < need)
-        return umnn_fail(UMNN_EINVAL, "backward (z_2 saved): buffer missing, too small, or not the wide-first family / arithmetic mode");
+    if (need == 0) z2_saved = nullptr;
+    else if (!z2_saved || z2_floats < need)
+        return umnn_fail(UMNN_EINVAL, "backward (z_2 saved): buffer missing or smaller than umnn_cc_forward_z2_floats()");
     return backward_impl(net, nullptr, nullptr, x, h, g, g_fx, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr, dx, dh, dtheta, workspace,
                          workspace_bytes, stream_, z2_saved);
 }

@@ -45,6 +45,11 @@ struct FwdArgs {
     int z2_nl2;
 };
 
+// The marker of a deferred group is a NaN with a payload no arithmetic produces (hardware NaNs are 0x7fc00000, propagated input NaNs keep the
+// caller's payload; this one survives the bf16 round trip of the *_io entry points: 0x7fd5 as bf16).  A group that was NOT deferred but whose
+// z is legitimately NaN (exp(s) (F + h_0) = inf - inf with a finite quadrature sum) is therefore never mistaken for a marked one by the
+// fallback launch -- it would publish twice and count twice towards its rows' arrival counters.
+constexpr unsigned FWD_MARKER_BITS = 0x7fd50000u;
 // the marker slot of integral q: element q of F when the launch writes F, else this integral's element of z
 __device__ __forceinline__ float* fwd_marker(const FwdArgs& a, long long q, long long* idx) {
     if (a.F) { *idx = q; return a.F; }
@@ -64,7 +69,7 @@ __device__ __forceinline__ bool fwd_group_marked(const FwdArgs& a, unsigned grp,
         long long idx;
         float* mk = fwd_marker(a, q, &idx);
         const float v = io_ld(mk, idx, a.x_bf16);
-        m = m || v != v;
+        m = m || __float_as_uint(v) == FWD_MARKER_BITS;
     }
     return __any(m);
 }
@@ -115,7 +120,7 @@ __device__ __forceinline__ void fwd_epilogue(const FwdArgs& a, float* lds, float
                     if (!ok[pt]) continue;
                     long long idx;
                     float* mk = fwd_marker(a, qv[pt], &idx);
-                    io_st(mk, idx, __builtin_nanf(""), a.x_bf16);
+                    io_st(mk, idx, __uint_as_float(FWD_MARKER_BITS), a.x_bf16);
                 }
             }
             if (part == 0 && g == 0 && p == 0) atomicMax(a.ovf_flag, a.ovf_gen);

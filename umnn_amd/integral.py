@@ -22,6 +22,7 @@ Two execution paths, chosen per call, never silently:
 """
 import ctypes
 import os
+import weakref
 import threading
 import warnings
 
@@ -241,7 +242,17 @@ def hip_forward(spec, x0, x, h, nb_steps, inv_f=False):
     return F, fx, fx0
 
 
+# z_2 handed from the training forward to the backward (three-stage family): memory held from forward to backward.  Two caps: per
+# block (UMNN_SAVE_Z2_MAX_GB, default 2) and over everything alive at once -- all blocks of a flow between its forward and its
+# backward -- (UMNN_SAVE_Z2_TOTAL_GB, default 8; the 5-block MNISTExperiment flow at B = 100 holds 4.2 GB).  Above either, that block's
+# backward recomputes z_2 (its stage A) as before: a speed / peak-memory trade, never a different result.
 _Z2_MAX_BYTES = int(float(os.environ.get("UMNN_SAVE_Z2_MAX_GB", "2")) * (1 << 30))
+_Z2_TOTAL_BYTES = int(float(os.environ.get("UMNN_SAVE_Z2_TOTAL_GB", "8")) * (1 << 30))
+_z2_live = [0]
+
+
+def _z2_release(nbytes):
+    _z2_live[0] -= nbytes
 
 
 def hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z=False, log_jac_in=None, save_z2=False):
@@ -256,10 +267,12 @@ def hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z=False, log_jac_in=No
         if x.dtype == torch.float32 and h.dtype == torch.float32:
             desc, keep = _desc(spec)
             nfl = int(lib.umnn_cc_forward_z2_floats(ctypes.byref(desc), B, d, E, int(nb_steps)))
-            if 0 < 4 * nfl <= _Z2_MAX_BYTES:
+            if 0 < 4 * nfl <= _Z2_MAX_BYTES and _z2_live[0] + 4 * nfl <= _Z2_TOTAL_BYTES:
                 x, h, scaling = _f32c(x), _f32c(h), _f32c(scaling)
                 w, s = device_tables(nb_steps, x.device)
                 z2 = torch.empty(nfl, device=x.device, dtype=torch.float32)
+                _z2_live[0] += 4 * nfl
+                weakref.finalize(z2, _z2_release, 4 * nfl)
                 z, lj, fx, fx0 = (torch.empty_like(x) for _ in range(4))
                 lj_in = _as(log_jac_in, torch.float32)
                 with torch.cuda.device(x.device):
@@ -537,8 +550,10 @@ class FlowBlockTransform(torch.autograd.Function):
         ctx.spec, ctx.nb_steps, ctx.integrand, ctx.reverse_z = spec, nb_steps, integrand, bool(reverse_z)
         ctx.shapes = [p.shape for p in params]
         # (nets of the three-stage backward family: the forward leaves z_2 of every node for the backward, which then skips stage A)
-        z, lj, fx, _, ctx.z2 = hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z, log_jac_in,
-                                              save_z2=any(ctx.needs_input_grad[7:]) or ctx.needs_input_grad[0] or ctx.needs_input_grad[2])
+        want_z2 = any(ctx.needs_input_grad[7:]) or ctx.needs_input_grad[0] or ctx.needs_input_grad[2]
+        out = hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z, log_jac_in, save_z2=want_z2)
+        z, lj, fx = out[0], out[1], out[2]
+        ctx.z2 = out[4] if want_z2 else None          # (save_z2=False returns four values: only log_jac_in needs a gradient)
         ctx.save_for_backward(x.clone(), h, fx, scaling)      # (x cloned: callers clamp z / reuse x in place, UMNNMAF.py:150)
         return z, lj
 
