@@ -345,6 +345,14 @@ int umnn_made_mlp_forward_ex(const umnn_made_net* net, const float* x, long long
 int umnn_made_linear_forward(const void* W_frag, const float* bias, int K, int N, const float* x, const float* x2, int K1,
                              long long B, int relu_in, void* out, int out_bf16, int row_tiles, int feature_groups, void* stream);
 
+/* Training chain of the conditioner (csrc/made_train.hip; replaces, per masked linear, the ReluBackward / bias-reduction / mask
+ * product nodes PyTorch's autograd puts around F.linear in models/UMNN/made.py:16-27,113-119): g [B, N] fp32 is the gradient w.r.t.
+ * the layer's ReLU output `relu_out` (NULL for the last layer: no activation behind it).  In place g <- g . [relu_out > 0], and
+ * gb[c] <- sum_r g[r][c] by a two-stage reduction with a fixed order (bit-reproducible; no atomics).  `partial`: row_blocks x N floats
+ * of scratch, row_blocks from umnn_made_relu_bwd_bias_row_blocks(B, N). */
+int umnn_made_relu_bwd_bias_row_blocks(long long B, int N);
+int umnn_made_relu_bwd_bias(float* g, const float* relu_out, long long B, int N, float* partial, int row_blocks, float* gb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,3 +102,50 @@ def test_default_forward_at_small_activation_scales_against_float64(scale, dev):
         assert eF < TOL and ef < TOL, (mode, eF, ef)
     # the default is no worse than the two-piece bf16 mode on the hidden layers' share of the output at any of these scales + float32 floor
     assert rep["f16x3"][2] <= max(rep["bf16x3"][2], 50 * rep["fp32"][2], 1e-3), rep
+
+
+@pytest.mark.parametrize("cond", [0, 7])
+@pytest.mark.parametrize("B", [1, 37, 1000])
+def test_conditioner_training_chain_as_one_node_matches_the_autograd_chain(cond, B, dev):
+    """The MADE / ConditionnalMADE training path as ONE autograd node (made._MadeTrainChain: fp32 library GEMMs on the cached masked
+    weight, in-place ReLU, umnn_made_relu_bwd_bias for ReLU-backward + the bias gradient in a fixed order) against the same chain under
+    ordinary autograd -- the reference's composition, models/UMNN/made.py:16-27,113-119,165-168: outputs to fp32 rounding (same GEMMs),
+    every gradient (input, context, all weights and biases) to summation-order noise, masked weight entries exactly zero gradient, and
+    bit-identical gradients on a repeat."""
+    from umnn_amd import made as M
+    torch.manual_seed(3 + B)
+    nin, E = 6, 5
+    if cond:
+        net = M.ConditionnalMADE(nin, cond, [64, 48], (nin + cond) * E, natural_ordering=True).to(dev)
+    else:
+        net = M.MADE(nin, [64, 48], nin * E, natural_ordering=True).to(dev)
+    x = torch.randn(B, nin, device=dev)
+    ctx = torch.randn(B, cond, device=dev) if cond else None
+    w = torch.randn(B, nin * E, device=dev)
+    res = {}
+    for fused in (True, False, True):
+        M._TRAIN_FUSED["enabled"] = fused
+        try:
+            net.zero_grad(set_to_none=True)
+            xr = x.clone().requires_grad_()
+            cr = ctx.clone().requires_grad_() if cond else None
+            out = net.raw(xr, cr) if cond else net.raw(xr)
+            assert (type(out.grad_fn).__name__ == "_MadeTrainChainBackward") == fused, type(out.grad_fn).__name__
+            (out * w).sum().backward()
+            grads = [xr.grad.clone()] + ([cr.grad.clone()] if cond else []) + [p.grad.clone() for p in net.parameters()]
+        finally:
+            M._TRAIN_FUSED["enabled"] = True
+        key = "fused2" if (fused and "fused" in res) else ("fused" if fused else "plain")
+        res[key] = (out.detach().clone(), grads)
+    # (the same fp32 library GEMMs; the hidden layers take bias + ReLU in the GEMM epilogue, which may pick another hipBLASLt kernel and
+    # with it another summation order: fp32 rounding level, not bit equality)
+    assert float((res["fused"][0] - res["plain"][0]).abs().max()) <= 2e-6 * max(1.0, float(res["plain"][0].abs().max()))
+    assert torch.equal(res["fused"][0], res["fused2"][0])
+    for a, b in zip(res["fused"][1], res["plain"][1]):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), float((a - b).abs().max())
+    for a, b in zip(res["fused"][1], res["fused2"][1]):
+        assert torch.equal(a, b)
+    # the gradient of a masked-out weight entry is exactly zero (what keeps those entries where the initialisation left them)
+    layers = [l for l in net.net if isinstance(l, M.MaskedLinear)]
+    for l in layers:
+        assert float((l.weight.grad * (1 - l.mask)).abs().max()) == 0.0

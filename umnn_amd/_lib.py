@@ -97,6 +97,8 @@ SIGNATURES = {
     "umnn_flow_ll_backward": (ctypes.c_int, [_fp, _fp, _ll, ctypes.c_int, _fp, _fp, _fp]),
     "umnn_made_split3": (ctypes.c_int, [_fp, _ll, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]),
     "umnn_made_launch_count": (ctypes.c_longlong, []),
+    "umnn_made_relu_bwd_bias_row_blocks": (ctypes.c_int, [_ll, ctypes.c_int]),
+    "umnn_made_relu_bwd_bias": (ctypes.c_int, [_fp, _fp, _ll, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp]),
     "umnn_last_made_kernel_name": (ctypes.c_char_p, []),
     "umnn_made_mlp_forward": (ctypes.c_int, [ctypes.c_void_p, _fp, _ll, _fp, ctypes.c_int, _fp]),
     "umnn_made_mlp_forward_ex": (ctypes.c_int, [ctypes.c_void_p, _fp, _ll, _fp, ctypes.c_int, ctypes.c_int, _fp]),

@@ -33,15 +33,6 @@
 #pragma once
 #include "cc_bwd_ws_kernel.h"
 
-// -DUMNN_WS_EXP_NOCONFLICT: a TIMING-ONLY build (results wrong) in which every LDS read of a tile is bank-conflict free (lanes of a lane
-// group read one row: broadcast) -- the upper bound of what a conflict-free tile layout can buy (EXPERIMENTS.md, round 6)
-#ifdef UMNN_WS_EXP_NOCONFLICT
-#define WS16_OWNR (g * 16)
-#define WS16_TRB ((8 * (g >> 1)) * TRS + 16 * (g & 1) + 4 * (p & 3))
-#else
-#define WS16_OWNR own
-#define WS16_TRB trb
-#endif
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
@@ -396,7 +387,7 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
     }
     WsOps ops;
     {
-        const unsigned short* A3n = lds16 + WS_OFF_A3 + rA3 + WS16_TRB;
+        const unsigned short* A3n = lds16 + WS_OFF_A3 + rA3 + trb;
         W16_LOAD_B(ops, A3n);
     }
     auto step = [&](auto parc) __attribute__((always_inline)) {
@@ -414,7 +405,7 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
                     for (int r = 0; r < 4; ++r) z0[t][r] = zc[t][r];
             }
         }
-        const unsigned short* D4 = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + WS16_TRB;
+        const unsigned short* D4 = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + trb;
         unsigned short* const O1 = lds16 + WS_OFF_A1 + rO1 + own;
         // operands of dW_3: the a_3 half came in before the barrier, the delta_4 half (written last step) here
         W16_LOAD_A(ops, D4);
@@ -479,7 +470,7 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
         ws_adv<WS_NS3, WS_TILE>(rA3); ws_adv<2, WS_TILE>(rD4);
         ws_adv<WS_NS1, WS_TILE>(rO1);
         {   // next step's a_3 operand of dW_3 (a tile written four steps ago)
-            const unsigned short* A3n = lds16 + WS_OFF_A3 + rA3 + WS16_TRB;
+            const unsigned short* A3n = lds16 + WS_OFF_A3 + rA3 + trb;
             W16_LOAD_B(ops, A3n);
         }
         WS_T(t2);
@@ -537,8 +528,8 @@ __device__ __forceinline__ void ws16_role_Cb(const BwdBf16Args& args, unsigned s
     int rD3 = ws_ring0<2, WS_TILE>(9), rD2 = ws_ring0<2, WS_TILE>(10);
     int rS4 = ws_ring0<2, WS_P3>(7), rD4 = ws_ring0<2, WS_TILE>(7);
     WsOpsH o2, o1;
-    ws16_load_hB_all(o2, lds16 + WS_OFF_A2 + rA2 + WS16_TRB);          // (first step: the tiles are still zero)
-    ws16_load_hB_all(o1, lds16 + WS_OFF_A1 + rA1 + WS16_TRB);
+    ws16_load_hB_all(o2, lds16 + WS_OFF_A2 + rA2 + trb);          // (first step: the tiles are still zero)
+    ws16_load_hB_all(o1, lds16 + WS_OFF_A1 + rA1 + trb);
     for (int s = 0; s < S; ++s) {
         WS_T(t0);
         // delta_4 of element s - 7 from what F3 left a step ago, as micro-operations behind the matrix instructions below
@@ -546,10 +537,10 @@ __device__ __forceinline__ void ws16_role_Cb(const BwdBf16Args& args, unsigned s
         unsigned short* const D4o = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + own;
         u32x4 sg4[BKS];
 #pragma unroll
-        for (int s2 = 0; s2 < BKS; ++s2) sg4[s2] = *reinterpret_cast<const u32x4*>(S4 + WS16_OWNR + s2 * 8);
+        for (int s2 = 0; s2 < BKS; ++s2) sg4[s2] = *reinterpret_cast<const u32x4*>(S4 + own + s2 * 8);
         const float dout = *reinterpret_cast<const float*>(S4 + p * TRS + 64);
-        const unsigned short* D3 = lds16 + WS_OFF_D + 2 * WS_TILE + rD3 + WS16_TRB;
-        const unsigned short* D2 = lds16 + WS_OFF_D + 0 * WS_TILE + rD2 + WS16_TRB;
+        const unsigned short* D3 = lds16 + WS_OFF_D + 2 * WS_TILE + rD3 + trb;
+        const unsigned short* D2 = lds16 + WS_OFF_D + 0 * WS_TILE + rD2 + trb;
         // (the a_2 / a_1 halves of the operands came in before the barrier: only the cotangent halves, written last step, are fetched here)
         ws16_load_hA<1, 0>(o2, D3); ws16_load_hA<1, 1>(o2, D3);
         float d4[BT][4];
@@ -590,8 +581,8 @@ __device__ __forceinline__ void ws16_role_Cb(const BwdBf16Args& args, unsigned s
         ws_adv<2, WS_TILE>(rD3); ws_adv<2, WS_TILE>(rD2);
         ws_adv<2, WS_P3>(rS4); ws_adv<2, WS_TILE>(rD4);
         // next step's a_2 / a_1 operands (tiles written six and ten steps ago)
-        ws16_load_hB_all(o2, lds16 + WS_OFF_A2 + rA2 + WS16_TRB);
-        ws16_load_hB_all(o1, lds16 + WS_OFF_A1 + rA1 + WS16_TRB);
+        ws16_load_hB_all(o2, lds16 + WS_OFF_A2 + rA2 + trb);
+        ws16_load_hB_all(o1, lds16 + WS_OFF_A1 + rA1 + trb);
         WS_T(t2);
         __syncthreads();
         WS_T(t3);
@@ -702,14 +693,7 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
         for (int v = 0; v < 16; ++v) dWh[ti][v] = 0.f;
     int rAdw = ws_ring0<ws_a_ns(DWL), WS_TILE>(DD), rDdw = ws_ring0<2, WS_TILE>(DD);
     WsOpsH oh;
-    if constexpr (HAS_DW) ws16_load_hB_all(oh, lds16 + ws_a_off(DWL) + rAdw + WS16_TRB);
-#ifdef UMNN_WS_EXP_PREFETCH
-    BFrag<W16_NP> bf;
-#pragma unroll
-    for (int s2 = 0; s2 < BKS; ++s2)
-#pragma unroll
-        for (int k2 = 0; k2 < W16_NP; ++k2) bf.v[s2][k2] = u32x4{0u, 0u, 0u, 0u};
-#endif
+    if constexpr (HAS_DW) ws16_load_hB_all(oh, lds16 + ws_a_off(DWL) + rAdw + trb);
     for (int s = 0; s < S; ++s) {
         WS_T(t0);
         const bool liveP = s >= DP && cp.j < nit;
@@ -722,20 +706,18 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
             if (liveP && cp.e == 0) new_item_P();
         }
         const float nodef = (liveP && !tanP) ? 1.f : 0.f, k0f = kP == 0 ? 1.f : 0.f;
-        const unsigned short* Ain = lds16 + ws_a_off(LAYER) + rAin + WS16_OWNR;                  // a_l[s - DF]
+        const unsigned short* Ain = lds16 + ws_a_off(LAYER) + rAin + own;                  // a_l[s - DF]
         unsigned short* const Aout = lds16 + ws_a_off(LO) + rAout + own;                   // a_{l+1}[s - DP]
         unsigned short* const S4out = lds16 + W16_OFF_S4 + rD4;                            // F3: leading piece of a_4[s - 6], dout
-#ifndef UMNN_WS_EXP_PREFETCH
         BFrag<W16_NP> bf;
 #pragma unroll
         for (int s2 = 0; s2 < BKS; ++s2)
 #pragma unroll
             for (int k2 = 0; k2 < W16_NP; ++k2) bf.v[s2][k2] = *reinterpret_cast<const u32x4*>(Ain + k2 * 16 * TRS + s2 * 8);
         if constexpr (HAS_DW) {
-            const unsigned short* Ddw = lds16 + WS_OFF_D + (DWL + 1 - 2) * 2 * WS_TILE + rDdw + WS16_TRB;      // delta_{DWL+1}[s - DD]
+            const unsigned short* Ddw = lds16 + WS_OFF_D + (DWL + 1 - 2) * 2 * WS_TILE + rDdw + trb;      // delta_{DWL+1}[s - DD]
             ws16_load_hA<DWH, 0>(oh, Ddw); ws16_load_hA<DWH, 1>(oh, Ddw);
         }
-#endif
 
         // ---- micro-operations of the vector work of element s - DP
         auto act_reg = [&](auto ec, auto tanc) __attribute__((always_inline)) {
@@ -778,7 +760,7 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
         // a_L(node 0) is read back from the S4 tile this wave wrote a step ago, so that no activation value is carried from step
         // to step (the carried copy cost ~40 register moves per step on BOTH paths)
         auto out_dot_tangent = [&]() __attribute__((always_inline)) {
-            const unsigned short* S4prev = lds16 + W16_OFF_S4 + (rD4 ^ WS_P3) + WS16_OWNR;
+            const unsigned short* S4prev = lds16 + W16_OFF_S4 + (rD4 ^ WS_P3) + own;
             u32x4 sgp[BKS];
 #pragma unroll
             for (int s2 = 0; s2 < BKS; ++s2) sgp[s2] = *reinterpret_cast<const u32x4*>(S4prev + s2 * 8);
@@ -896,21 +878,8 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
         ws_adv<ws_a_ns(LO), WS_TILE>(rAout); ws_adv<2, WS_P3>(rD4);
         if constexpr (HAS_DW) {
             ws_adv<ws_a_ns(DWL), WS_TILE>(rAdw); ws_adv<2, WS_TILE>(rDdw);
-            ws16_load_hB_all(oh, lds16 + ws_a_off(DWL) + rAdw + WS16_TRB);      // next step's a_l operand of the dW half (an old tile)
+            ws16_load_hB_all(oh, lds16 + ws_a_off(DWL) + rAdw + trb);      // next step's a_l operand of the dW half (an old tile)
         }
-#ifdef UMNN_WS_EXP_PREFETCH
-        {   // TIMING ONLY (results wrong): every operand of the next step requested before the barrier, as a ring one slot deeper would allow
-            const unsigned short* Ain2 = lds16 + ws_a_off(LAYER) + rAin + WS16_OWNR;
-#pragma unroll
-            for (int s2 = 0; s2 < BKS; ++s2)
-#pragma unroll
-                for (int k2 = 0; k2 < W16_NP; ++k2) bf.v[s2][k2] = *reinterpret_cast<const u32x4*>(Ain2 + k2 * 16 * TRS + s2 * 8);
-            if constexpr (HAS_DW) {
-                const unsigned short* Ddw = lds16 + WS_OFF_D + (DWL + 1 - 2) * 2 * WS_TILE + rDdw + WS16_TRB;
-                ws16_load_hA<DWH, 0>(oh, Ddw); ws16_load_hA<DWH, 1>(oh, Ddw);
-            }
-        }
-#endif
         WS_T(t2);
         __syncthreads();
         WS_T(t3);
@@ -990,16 +959,6 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
         const float uu = ws16_ccs(lds16, kB) + 1.f;
         tkB = (kB == 0) ? xvB : __fadd_rn(x0vB, __fmul_rn(dxvB, uu) * 0.5f);
     }
-#ifdef UMNN_WS_EXP_PREFETCH
-    BFrag<W16_NP> bd;
-    u32x4 sg[BKS];
-#pragma unroll
-    for (int s2 = 0; s2 < BKS; ++s2) {
-        sg[s2] = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int k2 = 0; k2 < W16_NP; ++k2) bd.v[s2][k2] = u32x4{0u, 0u, 0u, 0u};
-    }
-#endif
     for (int s = 0; s < S; ++s) {
         WS_T(t0);
         const bool liveB = s >= DB && cb.j < nit;
@@ -1011,10 +970,9 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
             kBn = ws_node(sh, nxB);
             ccs_n = ws16_ccs(lds16, kBn);
         }
-        const unsigned short* Asg = lds16 + ws_a_off(LAYER) + rAsg + WS16_OWNR;                                  // a_l[s - DB]
-        const unsigned short* Din = lds16 + WS_OFF_D + (LAYER + 1 - 2) * 2 * WS_TILE + rDin + WS16_OWNR;         // delta_{l+1}[s - DB]
+        const unsigned short* Asg = lds16 + ws_a_off(LAYER) + rAsg + own;                                  // a_l[s - DB]
+        const unsigned short* Din = lds16 + WS_OFF_D + (LAYER + 1 - 2) * 2 * WS_TILE + rDin + own;         // delta_{l+1}[s - DB]
         unsigned short* const Dout = lds16 + WS_OFF_D + (LAYER >= 2 ? LAYER - 2 : 0) * 2 * WS_TILE + rDout + own;   // delta_l[s - DB]
-#ifndef UMNN_WS_EXP_PREFETCH
         BFrag<W16_NP> bd;
         u32x4 sg[BKS];
 #pragma unroll
@@ -1023,9 +981,6 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
             for (int k2 = 0; k2 < W16_NP; ++k2) bd.v[s2][k2] = *reinterpret_cast<const u32x4*>(Din + k2 * 16 * TRS + s2 * 8);
 #pragma unroll
         for (int s2 = 0; s2 < BKS; ++s2) sg[s2] = *reinterpret_cast<const u32x4*>(Asg + s2 * 8);
-#else
-        (void)Asg; (void)Din;
-#endif
         WS_T(t1);
         // ---- W_l^T GEMM (24 MFMAs, A operands = this wave's registers)
         f32x4 nd[BT];
@@ -1112,18 +1067,6 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
             }
         }
         ws_adv<ws_a_ns(LAYER), WS_TILE>(rAsg); ws_adv<2, WS_TILE>(rDin); ws_adv<2, WS_TILE>(rDout);
-#ifdef UMNN_WS_EXP_PREFETCH
-        {   // TIMING ONLY (results wrong): see wave F
-            const unsigned short* Asg2 = lds16 + ws_a_off(LAYER) + rAsg + WS16_OWNR;
-            const unsigned short* Din2 = lds16 + WS_OFF_D + (LAYER + 1 - 2) * 2 * WS_TILE + rDin + WS16_OWNR;
-#pragma unroll
-            for (int s2 = 0; s2 < BKS; ++s2)
-#pragma unroll
-                for (int k2 = 0; k2 < W16_NP; ++k2) bd.v[s2][k2] = *reinterpret_cast<const u32x4*>(Din2 + k2 * 16 * TRS + s2 * 8);
-#pragma unroll
-            for (int s2 = 0; s2 < BKS; ++s2) sg[s2] = *reinterpret_cast<const u32x4*>(Asg2 + s2 * 8);
-        }
-#endif
         WS_T(t2);
         __syncthreads();
         WS_T(t3);

@@ -346,6 +346,104 @@ def _layered_chain(a, layers, last_rows=None, out_dtype=None, a2=None):
     return cur
 
 
+# ---- training chain (round 6): the whole masked MLP as ONE autograd node ---------------------------------------------------------
+# Under autograd the reference's chain (made.py:16-27,113-119) is, per masked linear, a mask product + F.linear + ReLU forward and a
+# ReluBackward pass, two GEMMs, a column reduction for the bias gradient and the mask product's own backward: at the UCI shapes 15
+# bias reductions of 16 us, 30 mask products and 20 ReLU passes per training step.  Here the chain is one node: the forward
+# runs the same fp32 library GEMMs on the cached masked weight (one product per optimizer step, no autograd node), the ReLU in place;
+# the backward runs, per layer, ONE pass that applies the ReLU mask to the incoming gradient and reduces the bias gradient in a fixed
+# order (umnn_made_relu_bwd_bias: data-parallel replicas stay bit-identical), the two GEMMs, and the mask on the weight gradient in place.
+_TRAIN_FUSED = {"enabled": os.environ.get("UMNN_MADE_TRAIN_FUSED", "1") != "0"}
+_HAS_ADDMM_ACT = hasattr(torch, "_addmm_activation") and os.environ.get("UMNN_MADE_ADDMM_ACT", "1") != "0"
+
+
+def _train_chain_ok(a, layers):
+    if not (_TRAIN_FUSED["enabled"] and torch.is_grad_enabled() and a.is_cuda and a.dtype == torch.float32 and a.dim() == 2):
+        return False
+    if torch.is_autocast_enabled():
+        return False
+    if not all(l.weight.dtype == torch.float32 and l.bias is not None and l.weight.is_cuda for l in layers):
+        return False
+    return a.requires_grad or any(l.weight.requires_grad or l.bias.requires_grad for l in layers)
+
+
+class _MadeTrainChain(torch.autograd.Function):
+    """out = MaskedLinear_L(ReLU(... ReLU(MaskedLinear_1(a)))) [rows ``keep`` of the last layer only] as one node.
+    apply(a, layers, keep, W_1, b_1, ..., W_L, b_L): ``layers`` the MaskedLinear modules (for their masks / cached masked weights),
+    the parameters passed as tensors so that autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, a, layers, keep, *params):
+        acts, weffs = [a.contiguous()], []
+        cur = acts[0]
+        for i, layer in enumerate(layers):
+            last = i == len(layers) - 1
+            W, b = layer.masked_weight(), layer.bias.detach()        # (grad mode is off in here: the cached product, no autograd node)
+            if last and keep is not None:
+                W, b = W.index_select(0, keep), b.index_select(0, keep)
+            weffs.append(W)
+            if not last:
+                # bias + ReLU in the GEMM's epilogue (hipBLASLt): no separate activation pass over [B, N]
+                cur = y = torch._addmm_activation(b, cur, W.t(), use_gelu=False) if _HAS_ADDMM_ACT else torch.relu_(torch.addmm(b, cur, W.t()))
+                acts.append(cur)
+            else:
+                y = torch.addmm(b, cur, W.t())
+        ctx.layers, ctx.keep, ctx.n = layers, keep, len(layers)
+        ctx.save_for_backward(*acts, *weffs)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.lib()
+        L = ctx.n
+        acts, weffs = ctx.saved_tensors[:L], ctx.saved_tensors[L:]
+        layers, keep = ctx.layers, ctx.keep
+        g = g.contiguous()
+        B = g.shape[0]
+        grads = [None] * (2 * L)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
+        with torch.cuda.device(g.device):
+            for i in range(L - 1, -1, -1):
+                last = i == L - 1
+                layer = layers[i]
+                N = g.shape[1]
+                relu_out = None if last else acts[i + 1]
+                need_b = ctx.needs_input_grad[3 + 2 * i + 1]
+                if need_b or not last:
+                    rb = int(lib.umnn_made_relu_bwd_bias_row_blocks(B, N))
+                    partial = torch.empty(rb * N, device=g.device, dtype=torch.float32)
+                    gb = torch.empty(N, device=g.device, dtype=torch.float32)
+                    _lib.check(lib.umnn_made_relu_bwd_bias(g.data_ptr(), None if relu_out is None else relu_out.data_ptr(), B, N,
+                                                           partial.data_ptr(), rb, gb.data_ptr(), stream), "umnn_made_relu_bwd_bias")
+                    if need_b:
+                        if last and keep is not None:
+                            full = torch.zeros_like(layer.bias)
+                            full.index_copy_(0, keep, gb)
+                            gb = full
+                        grads[2 * i + 1] = gb
+                if ctx.needs_input_grad[3 + 2 * i]:
+                    gW = torch.mm(g.t(), acts[i])
+                    if last and keep is not None:
+                        full = torch.zeros_like(layer.weight)
+                        full.index_copy_(0, keep, gW.mul_(layer.mask.index_select(0, keep)))
+                        gW = full
+                    else:
+                        gW.mul_(layer.mask)
+                    grads[2 * i] = gW
+                if i > 0 or ctx.needs_input_grad[0]:
+                    g = torch.mm(g, weffs[i])
+        return (g if ctx.needs_input_grad[0] else None, None, None, *grads)
+
+
+def _train_chain(a, layers, keep=None):
+    params = []
+    for l in layers:
+        params += [l.weight, l.bias]
+    return _MadeTrainChain.apply(a, layers, keep, *params)
+
+
 def _to_weight_dtype(x, layer):
     """bf16 / fp16 activations handed to fp32 weights outside autocast: widen (exact) instead of failing in F.linear."""
     if x.dtype != layer.weight.dtype and not torch.is_autocast_enabled():
@@ -411,7 +509,8 @@ class MADE(nn.Module):
             if mode:
                 return _fused_chain(x, layers, out_dtype=out_dtype, mode=mode)
             return _fast_chain(x, layers, out_dtype=out_dtype)
-        out = self.net(x)
+        layers = [l for l in self.net if isinstance(l, MaskedLinear)]
+        out = _train_chain(x, layers) if _train_chain_ok(x, layers) else self.net(x)
         return out.to(out_dtype) if out_dtype is not None and out.dtype != out_dtype else out
 
     def raw_rows(self, x, rows):
@@ -503,11 +602,15 @@ class ConditionnalMADE(MADE):
             if mode:
                 return _fused_chain(a, layers, self._kept_rows(a.device), out_dtype, mode=mode)
             return _fast_chain(a, layers, self._kept_rows(a.device), out_dtype)
+        keep = self._kept_rows(a.device)
+        mlayers = [l for l in self.net if isinstance(l, MaskedLinear)]
+        if _train_chain_ok(a, mlayers):
+            out = _train_chain(a, mlayers, keep)
+            return out.to(out_dtype) if out_dtype is not None and out.dtype != out_dtype else out
         layers = list(self.net)
         for layer in layers[:-1]:
             a = layer(a)
         last = layers[-1]
-        keep = self._kept_rows(a.device)
         out = F.linear(a, last.masked_weight().index_select(0, keep), last.bias.index_select(0, keep))
         return out.to(out_dtype) if out_dtype is not None and out.dtype != out_dtype else out
 
