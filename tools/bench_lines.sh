@@ -13,11 +13,16 @@ fast --workload toy
 fast --workload toy --graph
 fast --workload vae
 fast --workload vae --graph
+fast --workload vae --embedding bf16
 fast --workload mnist
+fast --workload mnist --embedding bf16
 run --workload bsds300 --mode train
 run --workload power --mode train
 run --workload vae --mode train
 run --workload mnist --mode train
+run --workload vae --mode train --embedding bf16
+run --workload mnist --mode train --embedding bf16
+run --workload bsds300 --mode train --graph
 fast --workload power --mode train --rows 100 --graph
 python - <<PY
 import json

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Energy per tile-node of the C3 forward launch under micro-variants of the kernel -- run on the GPU box:
 
+    git apply tools/fwd_energy_probes.patch      (the probe switches are not kept in the product header)
     tools/build_fwd_variant.sh fnr1 -DUMNN_FWD_EXP_NORELOAD=1; ... fnr2 ...=2; ... fdup -DUMNN_FWD_EXP_DUPPAD      (build container)
+    git checkout umnn_amd/csrc/cc_fwd_bf16_kernel.h
     python tools/fwd_energy_table.py [--seconds 5] [--out gpurun_out/fwd_energy.json]
 
 One child process per library build (UMNN_CC_LIB), each launching the C3 forward (8192 x 63 integrals, n = 100, 31-50^4-1, f16x3)

@@ -86,6 +86,9 @@ report, lines = {}, [f"# Roofline report (rocprofv3, round {RND[1:]}) -- kernels
                      "the CSV / JSON summaries it read are the `bench_<tag>_*` files next to this report.", ""]
 for tag, title in (("bsds300", "C3 BSDS300-shaped eval (8192 x 63 integrals per launch, n=100, 31-50^4-1)"),
                    ("power", "C2 POWER-shaped eval (10000 x 6 integrals per launch)"),
+                   ("toy", "C1 2-moons eval (4096 x 2 integrals per launch, n=50, 11-100^4-1)"),
+                   ("vae", "C4 VAE prior flow eval (1024 x 64 integrals per launch, n=50, cond 320)"),
+                   ("mnist", "MNISTExperiment-shaped eval (100 x 784 integrals per launch, n=50, 31-100-50^4-1; the d=784 shape BASELINE config 5 quotes)"),
                    ("bsds300_train", "C3 training step (forward + HIP backward + Adam)"),
                    ("mnist_train", "MNISTExperiment-shaped training step (d=784, 31-100-50-50-50-50-1, batch 100; three-stage backward)")):
     got = load(tag)

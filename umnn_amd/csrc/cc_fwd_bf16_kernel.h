@@ -144,10 +144,6 @@ __device__ __forceinline__ void stage_bf16_images(const MlpDev& m, const int* ks
         // weight of (output feature fo, input feature fi) incl. the bias column and the constant-one carrier
         auto wv = [&](int fo, int fi) {
             float v = 0.f;
-#ifdef UMNN_FWD_EXP_DUPPAD        // ENERGY PROBE ONLY (results wrong): padded rows / k-slots hold copies of live weights instead of zeros
-            if (fo > Hout) fo -= 16;
-            if (fi > Hin) fi -= 16;
-#endif
             if (fo < Hout) {
                 if (fi < Hin) v = W[fo * Hin + fi];
                 else if (fi == Hin) v = b[fo];
@@ -421,10 +417,6 @@ __global__ __launch_bounds__(64 * WPB) void cc_fwd_bf16_kernel(const FwdBf16Args
             // fragment of the layer that runs next into its registers
             auto reload_slot = [&](auto ic, int lnext) {
                 constexpr int i = decltype(ic)::value;
-#ifdef UMNN_FWD_EXP_NORELOAD      // ENERGY PROBE ONLY (results wrong): 1 = the fragments of layer 2 are never fetched (layer 2 runs on layer 1's:
-                // a third of the LDS fragment reads gone -- what a register-resident layer would save); 2 = no fragment is ever re-read
-                if (UMNN_FWD_EXP_NORELOAD == 2 || lnext == 2) return;
-#endif
                 if constexpr (MERGE) {
                     constexpr int step = i / 4, t = i % 4;            // last uses: step 1, 2, 3, 4
                     if constexpr (step >= 1) wf[t][step >= 3][(step - 1) & 1] = frag(lnext, t, step >= 3, (step - 1) & 1);
