@@ -415,21 +415,24 @@ __global__ __launch_bounds__(UMNN_BLOCK, 2) void cc_front_fwd16_kernel(const Fro
 #endif
 
 // ---------------------------------------------------------------------------------------------- stage C
-template <int T1, int NL2>
-__global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const FrontArgs fa) {
-    constexpr int KS1 = (T1 + 1) / 2;          // K-steps of 32 hidden-1 features (the last one half empty when T1 is odd)
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// The body works on the hidden-1 feature tiles [T0, T0 + TN) of a tile of 16 integrals: its columns of dG_1, its rows of
+// delta_1 = (G_1^T delta_2) . act'(z_1), its entries of dc and dW_1[:, 0].  TN = T1: one wave does the whole tile (the kernel of
+// rounds 2-5: 480 registers, one wave per SIMD, 39 % of the matrix pipe).  Round 6: the tiles of a_1 are INDEPENDENT of each other in
+// everything this stage computes -- only delta_2 is common -- so two waves share a tile of integrals, tiles [0, 4) and [4, T1) of the
+// hidden-1 features (two whole K-steps of 32 features first, so the halves stay K-step aligned), each at <= 256 registers, two per
+// SIMD: the second wave of a SIMD fills the first one's split / activation phases and dependency stalls.  Nothing is exchanged between
+// the halves; both fetch and split delta_2 (13 registers), and they write DISJOINT entries of the same d_theta slice and of dc.
+template <int T1, int NL2, int T0, int TN>
+__device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsigned short* lds16, unsigned slot_global, unsigned nslots) {
+    constexpr int KSN = (TN + 1) / 2;          // K-steps of 32 hidden-1 features of THIS wave's tiles (the last one half empty when TN is odd)
+    static_assert((T0 & 1) == 0 && T0 + TN <= T1, "feature-tile range: K-step aligned, inside the layer");
     const BwdArgs& a = fa.b;
     const MlpDev& m = a.m;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
     const int g = lane >> 4, p = lane & 15;
     const int H1 = m.width[1], H2 = m.width[2];
     const int E = a.E, d = a.d, n = a.n, nl2 = NL2 > 0 ? NL2 : fa.nl2;
     const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
-    unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
-    stage_g1_image<T1, true, NPB>(m, lds16, tid, blockDim.x);
-    __syncthreads();
     const unsigned short* frag_base = lds16 + lane * 8;
 
     u32x4 sel[2];        // selection fragments of the matrix-core transpose (see cc_bwd_bf16_kernel)
@@ -441,28 +444,26 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
         sel[0] = u32x4{w0, w1, 0u, 0u};
         sel[1] = u32x4{0u, 0u, w0, w1};
     }
-    float w1x[T1][4];
+    float w1x[TN][4];
     {
         const float* __restrict__ W0 = m.W[0];
 #pragma unroll
-        for (int t = 0; t < T1; ++t)
+        for (int t = 0; t < TN; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int f = feat_of(t, r, g);
+                const int f = feat_of(T0 + t, r, g);
                 w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
             }
     }
-    f32x4 dG1[BT][T1], dW1x[T1];
+    f32x4 dG1[BT][TN], dW1x[TN];
 #pragma unroll
     for (int to = 0; to < BT; ++to)
 #pragma unroll
-        for (int ti = 0; ti < T1; ++ti) dG1[to][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ti = 0; ti < TN; ++ti) dG1[to][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < T1; ++t) dW1x[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TN; ++t) dW1x[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + wid;
-    const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
-    for (unsigned item = wave_global; item < a.ngroups; item += nwaves) {
+    for (unsigned item = slot_global; item < a.ngroups; item += nslots) {
         const unsigned grp = fa.grp0 + item;
         const long long q = (long long)grp * 16 + p;
         const bool ok = q < a.NI;
@@ -472,10 +473,16 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
         const float dxv = xv - x0v;
         const long long bi = qq / d;
         const IoView hb = IoView{a.h, a.h_bf16} + (bi * ((long long)E * d) + (qq - bi * d));
-        f32x4 c[T1], dcs[T1];
-        front_prologue<T1>(m, hb, E, d, g, p, c);
+        f32x4 c[TN], dcs[TN];
+        {
+            // (the hoisted first-layer term of THIS wave's tiles: the products of the other tiles have no user and are not emitted)
+            f32x4 call[T1];
+            front_prologue<T1>(m, hb, E, d, g, p, call);
 #pragma unroll
-        for (int t = 0; t < T1; ++t) dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < TN; ++t) c[t] = call[T0 + t];
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         const size_t frag0 = (size_t)item * (size_t)(n + 1) * nl2 * 64 + lane;
         // delta_2 of node k, register j: fetched UNCONDITIONALLY (register index clamped, value masked afterwards) -- a guarded
         // load per register turns into a branch and a full memory wait each, which is what this kernel used to spend half its
@@ -494,9 +501,9 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
         for (int k = 0; k <= n; ++k) {
             const float u = a.ccs[k] + 1.f;
             const float tk = k == 0 ? xv : __fadd_rn(x0v, __fmul_rn(dxv, u) * 0.5f);
-            f32x4 a1[T1], delta2[BT];
+            f32x4 a1[TN], delta2[BT];
 #pragma unroll
-            for (int t = 0; t < T1; ++t)
+            for (int t = 0; t < TN; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a1[t][r] = hidden_act_f(fmaf(w1x[t][r], tk, c[t][r]), slope);
 #pragma unroll
@@ -508,18 +515,18 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dnext[t][r] = ld_d2(kn, t, r);
             }
-            // ---- packed two-piece fragments: delta_2 as a BFrag (two K-steps), a_1 as KS1 K-steps
+            // ---- packed two-piece fragments: delta_2 as a BFrag (two K-steps), a_1 as KSN K-steps
             BFrag<NPB> bd;
             split_regs<0, NPB>(delta2, bd);
-            u32x4 ba[KS1][NPB];
+            u32x4 ba[KSN][NPB];
 #pragma unroll
-            for (int s = 0; s < KS1; ++s) {
+            for (int s = 0; s < KSN; ++s) {
                 unsigned q0[NPB], q1[NPB], q2[NPB], q3[NPB];
 #pragma unroll
                 for (int k2 = 0; k2 < NPB; ++k2) q2[k2] = q3[k2] = 0u;
                 split_pair<NPB>(a1[2 * s][0], a1[2 * s][1], q0);
                 split_pair<NPB>(a1[2 * s][2], a1[2 * s][3], q1);
-                if (2 * s + 1 < T1) {
+                if (2 * s + 1 < TN) {
                     split_pair<NPB>(a1[2 * s + 1][0], a1[2 * s + 1][1], q2);
                     split_pair<NPB>(a1[2 * s + 1][2], a1[2 * s + 1][3], q3);
                 }
@@ -528,13 +535,13 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
             }
             // ---- dG1 += delta_2 (x) a_1 over the 16 points (operands transposed on the matrix core)
             {
-                u32x2 dT[BT][NPB], aT[T1][NPB];
+                u32x2 dT[BT][NPB], aT[TN][NPB];
                 transpose_pieces(bd, sel, dT);
 #pragma unroll
-                for (int s = 0; s < KS1; ++s)
+                for (int s = 0; s < KSN; ++s)
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
-                        if (2 * s + hh >= T1) continue;
+                        if (2 * s + hh >= TN) continue;
 #pragma unroll
                         for (int part = 0; part < NPB; ++part) {
                             const f32x4 tr = mfma_bf16(ba[s][part], sel[hh], f32x4{0.f, 0.f, 0.f, 0.f});
@@ -551,21 +558,21 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
 #pragma unroll
                         for (int to = 0; to < BT; ++to)
 #pragma unroll
-                            for (int ti = 0; ti < T1; ++ti) dG1[to][ti] = mfma_bf16_k16(dT[to][wa], aT[ti][bb], dG1[to][ti]);
+                            for (int ti = 0; ti < TN; ++ti) dG1[to][ti] = mfma_bf16_k16(dT[to][wa], aT[ti][bb], dG1[to][ti]);
                     }
             }
             // ---- delta_1 = (G1^T delta_2) . act'(z_1)
-            f32x4 nd[T1];
+            f32x4 nd[TN];
             {
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < BKS; ++s) {
 #pragma unroll
-                    for (int t = 0; t < T1; ++t) {
+                    for (int t = 0; t < TN; ++t) {
                         u32x4 wf[NPB];
 #pragma unroll
                         for (int k2 = 0; k2 < NPB; ++k2)
-                            wf[k2] = *reinterpret_cast<const u32x4*>(frag_base + ((t * BKS + s) * NPB + k2) * FRAG);
+                            wf[k2] = *reinterpret_cast<const u32x4*>(frag_base + (((T0 + t) * BKS + s) * NPB + k2) * FRAG);
 #pragma unroll
                         for (int wa = 0; wa < NPB; ++wa)
 #pragma unroll
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
                 }
             }
 #pragma unroll
-            for (int t = 0; t < T1; ++t)
+            for (int t = 0; t < TN; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float dl = nd[t][r] * (a1[t][r] > 0.f ? 1.f : slope);
@@ -588,41 +595,66 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
         }
         if (ok) {
 #pragma unroll
-            for (int t = 0; t < T1; ++t)
+            for (int t = 0; t < TN; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int f = feat_of(t, r, g);
+                    const int f = feat_of(T0 + t, r, g);
                     if (f < H1) a.dc[q * H1 + f] = dcs[t][r];
                 }
         }
     }
-    // ---- this wave's partial d_theta: G1 (weights + bias column) and the x-column of W1
-    float* part = a.partials + (size_t)wave_global * a.n_params;
+    // ---- this slot's partial d_theta: the G1 columns (weights + bias column) and the entries of the x-column of W1 that belong to
+    // these feature tiles
+    float* part = a.partials + (size_t)slot_global * a.n_params;
 #pragma unroll
     for (int to = 0; to < BT; ++to)
 #pragma unroll
-        for (int ti = 0; ti < T1; ++ti)
+        for (int ti = 0; ti < TN; ++ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int fo = 16 * to + 4 * g + r, fi = 16 * ti + (lane & 15);
+                const int fo = 16 * to + 4 * g + r, fi = 16 * (T0 + ti) + (lane & 15);
                 if (fo < H2) {
                     const int idx = fi < H1 ? a.poffW[1] + fo * H1 + fi : (fi == H1 ? a.poffb[1] + fo : -1);
                     if (idx >= 0) part[idx] = (fa.accumulate ? part[idx] : 0.f) + dG1[to][ti][r];
                 }
             }
 #pragma unroll
-    for (int t = 0; t < T1; ++t)
+    for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v1 = dW1x[t][r];
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) v1 += __shfl_xor(v1, o);
-            const int f = feat_of(t, r, g);
+            const int f = feat_of(T0 + t, r, g);
             if (p == 0 && f < H1) {
                 const int idx = a.poffW[0] + f * (1 + E);
                 part[idx] = (fa.accumulate ? part[idx] : 0.f) + v1;
             }
         }
+}
+
+// one wave per tile of integrals (what bwd_precision = fp32 runs: the six-term build does not fit 256 registers in halves either)
+template <int T1, int NL2>
+__global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const FrontArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
+    stage_g1_image<T1, true, NPB>(fa.b.m, lds16, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    front_bwd_body<T1, NL2, 0, T1>(fa, lds16, blockIdx.x * (blockDim.x >> 6) + wid, gridDim.x * (blockDim.x >> 6));
+}
+
+// two waves per tile of integrals (eight per workgroup; waves w and w + 4 share a SIMD and a tile): feature tiles [0, 4) and [4, T1)
+template <int T1, int NL2>
+__global__ __launch_bounds__(2 * UMNN_BLOCK, 1) void cc_front_bwd2_kernel(const FrontArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
+    stage_g1_image<T1, true, NPB>(fa.b.m, lds16, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned slot = blockIdx.x * UMNN_WAVES_PER_BLOCK + (wid & (UMNN_WAVES_PER_BLOCK - 1)), nslots = gridDim.x * UMNN_WAVES_PER_BLOCK;
+    if (wid < UMNN_WAVES_PER_BLOCK) front_bwd_body<T1, NL2, 0, 4>(fa, lds16, slot, nslots);
+    else front_bwd_body<T1, NL2, 4, T1 - 4>(fa, lds16, slot, nslots);
 }
 
 }  // namespace UMNN_BWD_NS
@@ -631,11 +663,11 @@ __global__ __launch_bounds__(UMNN_BLOCK, 1) void cc_front_bwd_kernel(const Front
 typedef void (*front_kernel_t)(const FrontArgs);
 typedef void (*mid_kernel_t)(const BwdBf16Args);
 #if UMNN_BWD_NPB == 2
-struct FrontVariant { int t1, nl2; front_kernel_t fwd, bwd, fwd16; };
-#define FRONT_VARIANT(T, N) {T, N, cc_front_fwd_kernel<T, N>, cc_front_bwd_kernel<T, N>, cc_front_fwd16_kernel<T, N>}
+struct FrontVariant { int t1, nl2; front_kernel_t fwd, bwd, fwd16, bwd2; };
+#define FRONT_VARIANT(T, N) {T, N, cc_front_fwd_kernel<T, N>, cc_front_bwd_kernel<T, N>, cc_front_fwd16_kernel<T, N>, cc_front_bwd2_kernel<T, N>}
 #else
-struct FrontVariant { int t1, nl2; front_kernel_t fwd, bwd, fwd16; };
-#define FRONT_VARIANT(T, N) {T, N, cc_front_fwd_kernel<T, N>, cc_front_bwd_kernel<T, N>, nullptr}
+struct FrontVariant { int t1, nl2; front_kernel_t fwd, bwd, fwd16, bwd2; };
+#define FRONT_VARIANT(T, N) {T, N, cc_front_fwd_kernel<T, N>, cc_front_bwd_kernel<T, N>, nullptr, nullptr}
 #endif
 static const FrontVariant kFrontVariants[] = {
     FRONT_VARIANT(5, 13), FRONT_VARIANT(6, 13), FRONT_VARIANT(7, 13), FRONT_VARIANT(8, 13),
@@ -753,6 +785,9 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
     if (fv->fwd16) { if (int rc = umnn_allow_lds((const void*)fv->fwd16, lds_a)) return rc; }
     if (int rc = umnn_allow_lds((const void*)mv->fn, lds_mid)) return rc;
     if (int rc = umnn_allow_lds((const void*)fv->bwd, lds_c)) return rc;
+    // stage C with two waves per tile (two-piece build): UMNN_FRONT_BWD2=0 / option front_bwd2 = 0 keeps one wave per tile
+    const bool c2 = fv->bwd2 != nullptr && umnn_options().front_bwd2 != 0;
+    if (c2) { if (int rc = umnn_allow_lds((const void*)fv->bwd2, lds_c)) return rc; }
     const MidVariant* wv = nullptr;
     size_t lds_ws = 0;
 #if UMNN_BWD_NPB == 2
@@ -816,7 +851,8 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
             if (run_a) hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
             hipLaunchKernelGGL(mv->fn, dim3(nblocks * (UMNN_WAVES_PER_BLOCK / wpb_mid)), dim3(64 * wpb_mid), lds_mid, stream, mid);
         }
-        hipLaunchKernelGGL(fv->bwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_c, stream, fa);
+        if (c2) hipLaunchKernelGGL(fv->bwd2, dim3(nblocks), dim3(2 * UMNN_BLOCK), lds_c, stream, fa);
+        else hipLaunchKernelGGL(fv->bwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_c, stream, fa);
     }
     umnn_prof_end(stream, 3.0 * umnn_cc_forward_flops_per_integral(net, n) * (double)base.NI, UMNN_PROF_BACKWARD);
     umnn_note_launch(hv ? hv : used_ws ? wv->name : mv->name);
