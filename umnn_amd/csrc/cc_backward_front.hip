@@ -422,8 +422,20 @@ __global__ __launch_bounds__(UMNN_BLOCK, 2) void cc_front_fwd16_kernel(const Fro
 // hidden-1 features (two whole K-steps of 32 features first, so the halves stay K-step aligned), each at <= 256 registers, two per
 // SIMD: the second wave of a SIMD fills the first one's split / activation phases and dependency stalls.  Nothing is exchanged between
 // the halves; both fetch and split delta_2 (13 registers), and they write DISJOINT entries of the same d_theta slice and of dc.
+// The two-wave form (TN < T1, two-piece build) also takes dG_1 the way the workgroup pipelines take their dW products: the packed
+// fragments of delta_2 and of this wave's a_1 go into a wave-private pair of LDS tiles ([piece][point][slot], 9 KB), come back as
+// transposed operands (ds_read_b64_tr_b16) and meet on v_mfma_f32_32x32x16 (K = the 16 points) -- 24 matrix instructions of 32 cycles
+// per tile-node for both halves together.  The one-wave form transposes on the matrix core (22 MFMAs + 44 conversions) and accumulates
+// on the K = 16 16x16 instruction, which gfx950 runs at HALF rate (16 cycles for 8 k FLOP: counters, round 6): 84 of them were 53 % of
+// this stage's matrix time.
 template <int T1, int NL2, int T0, int TN>
-__device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsigned short* lds16, unsigned slot_global, unsigned nslots) {
+__device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsigned short* lds16, unsigned slot_global, unsigned nslots,
+                                               unsigned short* wave_tiles = nullptr) {
+#if UMNN_BWD_NPB == 2
+    constexpr bool LDSDW = TN < T1;
+#else
+    constexpr bool LDSDW = false;
+#endif
     constexpr int KSN = (TN + 1) / 2;          // K-steps of 32 hidden-1 features of THIS wave's tiles (the last one half empty when TN is odd)
     static_assert((T0 & 1) == 0 && T0 + TN <= T1, "feature-tile range: K-step aligned, inside the layer");
     const BwdArgs& a = fa.b;
@@ -455,11 +467,21 @@ __device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsign
                 w1x[t][r] = f < H1 ? W0[f * (1 + E)] : 0.f;
             }
     }
-    f32x4 dG1[BT][TN], dW1x[TN];
+    f32x4 dG1[LDSDW ? 1 : BT][LDSDW ? 1 : TN], dW1x[TN];
 #pragma unroll
-    for (int to = 0; to < BT; ++to)
+    for (int to = 0; to < (LDSDW ? 1 : BT); ++to)
 #pragma unroll
-        for (int ti = 0; ti < TN; ++ti) dG1[to][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ti = 0; ti < (LDSDW ? 1 : TN); ++ti) dG1[to][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if UMNN_BWD_NPB == 2
+    ws_f32x16 dGw[2][2];                         // (LDSDW) rows: slots of the delta_2 tile, columns: slots of this wave's a_1 tile
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) dGw[to][ti][v] = 0.f;
+    const int trb = (8 * (g >> 1) + (p >> 2)) * TRS + 16 * (g & 1) + 4 * (p & 3);
+#endif
 #pragma unroll
     for (int t = 0; t < TN; ++t) dW1x[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -533,7 +555,23 @@ __device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsign
 #pragma unroll
                 for (int k2 = 0; k2 < NPB; ++k2) ba[s][k2] = u32x4{q0[k2], q1[k2], q2[k2], q3[k2]};
             }
-            // ---- dG1 += delta_2 (x) a_1 over the 16 points (operands transposed on the matrix core)
+            // ---- dG1 += delta_2 (x) a_1 over the 16 points
+#if UMNN_BWD_NPB == 2
+            if constexpr (LDSDW) {
+                unsigned short* Dt = wave_tiles;
+                unsigned short* At = wave_tiles + WS_TILE;
+                BFrag<NPB> af;                                  // this wave's a_1 as two K-steps (TN = 3: the last half K-step empty)
+#pragma unroll
+                for (int s2 = 0; s2 < BKS; ++s2)
+#pragma unroll
+                    for (int k2 = 0; k2 < NPB; ++k2) af.v[s2][k2] = s2 < KSN ? ba[s2 < KSN ? s2 : 0][k2] : u32x4{0u, 0u, 0u, 0u};
+                tr_tile_store(bd, Dt, g, p);
+                tr_tile_store(af, At, g, p);
+                WsOps ops;
+                swp_static_for<8>([&](auto ic) { ws_load_op<decltype(ic)::value>(ops, Dt + trb, At + trb); });
+                swp_static_for<12>([&](auto ic) { ws_dw_mfma<decltype(ic)::value>(dGw, ops); });
+            } else
+#endif
             {
                 u32x2 dT[BT][NPB], aT[TN][NPB];
                 transpose_pieces(bd, sel, dT);
@@ -606,6 +644,25 @@ __device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsign
     // ---- this slot's partial d_theta: the G1 columns (weights + bias column) and the entries of the x-column of W1 that belong to
     // these feature tiles
     float* part = a.partials + (size_t)slot_global * a.n_params;
+#if UMNN_BWD_NPB == 2
+    if constexpr (LDSDW) {
+        // 32 x 32 result layout (ws_write_dw): column lane & 31, register v = 4 i + r <-> row 8 i + 4 (lane >> 5) + r; rows / columns run
+        // over tile SLOTS (slot_feature), the columns being the features of THIS wave's tiles
+#pragma unroll
+        for (int to = 0; to < 2; ++to)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int fo = slot_feature(32 * to + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3));
+                    const int fi = 16 * T0 + slot_feature(32 * ti + (lane & 31));
+                    if (fo < H2) {
+                        const int idx = fi < H1 ? a.poffW[1] + fo * H1 + fi : (fi == H1 ? a.poffb[1] + fo : -1);
+                        if (idx >= 0) part[idx] = (fa.accumulate ? part[idx] : 0.f) + dGw[to][ti][v];
+                    }
+                }
+    } else
+#endif
 #pragma unroll
     for (int to = 0; to < BT; ++to)
 #pragma unroll
@@ -653,8 +710,10 @@ __global__ __launch_bounds__(2 * UMNN_BLOCK, 1) void cc_front_bwd2_kernel(const 
     __syncthreads();
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned slot = blockIdx.x * UMNN_WAVES_PER_BLOCK + (wid & (UMNN_WAVES_PER_BLOCK - 1)), nslots = gridDim.x * UMNN_WAVES_PER_BLOCK;
-    if (wid < UMNN_WAVES_PER_BLOCK) front_bwd_body<T1, NL2, 0, 4>(fa, lds16, slot, nslots);
-    else front_bwd_body<T1, NL2, 4, T1 - 4>(fa, lds16, slot, nslots);
+    // (behind the G1^T image: a pair of operand tiles per wave)
+    unsigned short* wave_tiles = lds16 + T1 * BKS * NPB * FRAG + wid * 2 * (NPB * 16 * TRS);
+    if (wid < UMNN_WAVES_PER_BLOCK) front_bwd_body<T1, NL2, 0, 4>(fa, lds16, slot, nslots, wave_tiles);
+    else front_bwd_body<T1, NL2, 4, T1 - 4>(fa, lds16, slot, nslots, wave_tiles);
 }
 
 }  // namespace UMNN_BWD_NS
@@ -787,7 +846,8 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
     if (int rc = umnn_allow_lds((const void*)fv->bwd, lds_c)) return rc;
     // stage C with two waves per tile (two-piece build): UMNN_FRONT_BWD2=0 / option front_bwd2 = 0 keeps one wave per tile
     const bool c2 = fv->bwd2 != nullptr && umnn_options().front_bwd2 != 0;
-    if (c2) { if (int rc = umnn_allow_lds((const void*)fv->bwd2, lds_c)) return rc; }
+    const size_t lds_c2 = lds_c + (size_t)2 * UMNN_WAVES_PER_BLOCK * 2 * (NPB * 16 * TRS) * sizeof(unsigned short);      // + the waves' operand tiles
+    if (c2) { if (lds_c2 > 160 * 1024) return UMNN_EUNSUPPORTED; if (int rc = umnn_allow_lds((const void*)fv->bwd2, lds_c2)) return rc; }
     const MidVariant* wv = nullptr;
     size_t lds_ws = 0;
 #if UMNN_BWD_NPB == 2
@@ -851,7 +911,7 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
             if (run_a) hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
             hipLaunchKernelGGL(mv->fn, dim3(nblocks * (UMNN_WAVES_PER_BLOCK / wpb_mid)), dim3(64 * wpb_mid), lds_mid, stream, mid);
         }
-        if (c2) hipLaunchKernelGGL(fv->bwd2, dim3(nblocks), dim3(2 * UMNN_BLOCK), lds_c, stream, fa);
+        if (c2) hipLaunchKernelGGL(fv->bwd2, dim3(nblocks), dim3(2 * UMNN_BLOCK), lds_c2, stream, fa);
         else hipLaunchKernelGGL(fv->bwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_c, stream, fa);
     }
     umnn_prof_end(stream, 3.0 * umnn_cc_forward_flops_per_integral(net, n) * (double)base.NI, UMNN_PROF_BACKWARD);
