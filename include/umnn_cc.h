@@ -287,7 +287,8 @@ int umnn_get_backward_precision(void);
  * cc_bwd_ws16_kernel.h -- three-term recompute, cotangents scaled by a per-launch power of two, overflow flag + queued bf16
  * fallback: 1, default: launches of >= 2^21 node evaluations; 2: whenever the pipeline is eligible; 0: never), "front_bwd2" (1,
  * default: the last stage of the three-stage backward runs two waves per tile of integrals, each on half of the wide first hidden
- * layer's feature tiles; 0: one wave per tile);
+ * layer's feature tiles -- on fp16 pieces behind the fp16 middle stage, its bf16 build queued as the overflow fallback; 2: two waves,
+ * bf16 pieces always; 0: one wave per tile);
  * -1 = automatic for the tuning knobs.  "fwd_precision" defaults to UMNN_PRECISION_F16X3 (see above). */
 int umnn_set_option(const char* name, int value);
 int umnn_get_option(const char* name, int* value);

@@ -134,7 +134,7 @@ static void load_env(UmnnOptions& o) {
     o.bwd_swp = env_int("UMNN_BWD_SWP", 1) != 0;
     o.bwd_ws = env_int("UMNN_BWD_WS", 1) != 0;
     v = env_int("UMNN_BWD_WS16", 1); o.bwd_ws16 = v >= 0 && v <= 2 ? v : 1;
-    o.front_bwd2 = env_int("UMNN_FRONT_BWD2", 1) != 0;
+    v = env_int("UMNN_FRONT_BWD2", 1); o.front_bwd2 = v >= 0 && v <= 2 ? v : 1;
 }
 UmnnOptions& umnn_options() {
     static UmnnOptions opts;
@@ -176,7 +176,7 @@ static bool option_value_ok(const char* name, int v) {
     if (!strcmp(name, "bwd_swp")) return v == 0 || v == 1;
     if (!strcmp(name, "bwd_ws")) return v == 0 || v == 1;
     if (!strcmp(name, "bwd_ws16")) return v >= 0 && v <= 2;
-    if (!strcmp(name, "front_bwd2")) return v == 0 || v == 1;
+    if (!strcmp(name, "front_bwd2")) return v >= 0 && v <= 2;
     return true;
 }
 extern "C" int umnn_set_option(const char* name, int value) {

@@ -412,6 +412,23 @@ __global__ __launch_bounds__(UMNN_BLOCK, 2) void cc_front_fwd16_kernel(const Fro
         }
     }
 }
+// fragment image of G1^T on two fp16 pieces (stage C on fp16 pieces): rows = hidden-1 features (T1 tiles), K = hidden-2 features (two
+// K-steps), nothing through the constant feature; the low piece plain (ws16_stage_image<TRANSPOSED = true>: the delta chain's convention)
+template <int T1>
+__device__ __forceinline__ void stage_g1t_image16(const MlpDev& m, unsigned short* img, int tid, int nthreads) {
+    const int Hin = m.width[1], Hout = m.width[2];
+    const float* __restrict__ W = m.W[1];
+    for (int idx = tid; idx < T1 * BKS * FRAG; idx += nthreads) {
+        const int j = idx & 7, ln = (idx >> 3) & 63, ts = idx >> 9;
+        const int s = ts % BKS, t = ts / BKS;
+        const int frow = fout_of(t, ln & 15);
+        const int fk = feat_of(2 * s + (j >> 2), j & 3, ln >> 4);
+        const float v = (fk < Hout && frow < Hin) ? W[fk * Hin + frow] : 0.f;
+        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+        img[(ts * 2 + 0) * FRAG + ln * 8 + j] = __builtin_bit_cast(unsigned short, hi);
+        img[(ts * 2 + 1) * FRAG + ln * 8 + j] = __builtin_bit_cast(unsigned short, lo);
+    }
+}
 #endif
 
 // ---------------------------------------------------------------------------------------------- stage C
@@ -428,7 +445,13 @@ __global__ __launch_bounds__(UMNN_BLOCK, 2) void cc_front_fwd16_kernel(const Fro
 // per tile-node for both halves together.  The one-wave form transposes on the matrix core (22 MFMAs + 44 conversions) and accumulates
 // on the K = 16 16x16 instruction, which gfx950 runs at HALF rate (16 cycles for 8 k FLOP: counters, round 6): 84 of them were 53 % of
 // this stage's matrix time.
-template <int T1, int NL2, int T0, int TN>
+// F16 (two-wave form only, behind the fp16 middle stage): every matrix operand on two fp16 pieces instead of two bf16 pieces -- a
+// four-instruction split per pair instead of eleven (with the transposes gone, 308 of this stage's ~600 vector instructions per tile-node
+// are splits).  delta_2 arrives un-scaled from the middle stage and is multiplied by the launch's power-of-two sigma (cc_bwd_ws16_kernel.h:
+// the cotangent scale of the fp16 pipeline) before it is split; dG_1, dc and dW_1[:, 0] leave times 1 / sigma (exact).  A piece beyond
+// fp16's range reaches a dc sum or a dG_1 accumulator as inf / NaN: checked (once per tile / once per launch) and raised in the launch
+// flag, behind which the bf16 build of this stage is queued with "run only if the flag is set" -- same outputs, rewritten.
+template <int T1, int NL2, int T0, int TN, bool F16 = false>
 __device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsigned short* lds16, unsigned slot_global, unsigned nslots,
                                                unsigned short* wave_tiles = nullptr) {
 #if UMNN_BWD_NPB == 2
@@ -436,6 +459,7 @@ __device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsign
 #else
     constexpr bool LDSDW = false;
 #endif
+    static_assert(!F16 || LDSDW, "fp16 pieces: the two-wave form of the two-piece build");
     constexpr int KSN = (TN + 1) / 2;          // K-steps of 32 hidden-1 features of THIS wave's tiles (the last one half empty when TN is odd)
     static_assert((T0 & 1) == 0 && T0 + TN <= T1, "feature-tile range: K-step aligned, inside the layer");
     const BwdArgs& a = fa.b;
@@ -456,6 +480,23 @@ __device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsign
         sel[0] = u32x4{w0, w1, 0u, 0u};
         sel[1] = u32x4{0u, 0u, w0, w1};
     }
+    float sigma = 1.f, inv_sigma = 1.f;
+    bool bad = false;
+#if UMNN_BWD_NPB == 2
+    if constexpr (F16) sigma = ws16_sigma(reinterpret_cast<const Ws16Scal*>(a.scal), inv_sigma);
+#endif
+    auto mm32 = [&](u32x4 x, u32x4 y, f32x4 z) __attribute__((always_inline)) {      // the 16x16x32 instruction of the piece type
+#if UMNN_BWD_NPB == 2
+        if constexpr (F16) return mfma_f16(x, y, z);
+#endif
+        return mfma_bf16(x, y, z);
+    };
+    auto split2 = [&](float x0, float x1, unsigned (&q)[NPB]) __attribute__((always_inline)) {
+#if UMNN_BWD_NPB == 2
+        if constexpr (F16) { q[0] = h16_split_stage(x0, x1); q[1] = h16_split_last(x0, x1); return; }
+#endif
+        split_pair<NPB>(x0, x1, q);
+    };
     float w1x[TN][4];
     {
         const float* __restrict__ W0 = m.W[0];
@@ -529,7 +570,7 @@ __device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsign
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a1[t][r] = hidden_act_f(fmaf(w1x[t][r], tk, c[t][r]), slope);
 #pragma unroll
-            for (int t = 0; t < BT; ++t) delta2[t] = dnext[t];
+            for (int t = 0; t < BT; ++t) delta2[t] = F16 ? dnext[t] * sigma : dnext[t];
             {
                 const int kn = k < n ? k + 1 : n;         // (the last node re-reads itself: harmless, and no branch)
 #pragma unroll
@@ -539,18 +580,27 @@ __device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsign
             }
             // ---- packed two-piece fragments: delta_2 as a BFrag (two K-steps), a_1 as KSN K-steps
             BFrag<NPB> bd;
-            split_regs<0, NPB>(delta2, bd);
+#pragma unroll
+            for (int s2 = 0; s2 < BKS; ++s2) {
+                unsigned q0[NPB], q1[NPB], q2[NPB], q3[NPB];
+                split2(delta2[2 * s2][0], delta2[2 * s2][1], q0);
+                split2(delta2[2 * s2][2], delta2[2 * s2][3], q1);
+                split2(delta2[2 * s2 + 1][0], delta2[2 * s2 + 1][1], q2);
+                split2(delta2[2 * s2 + 1][2], delta2[2 * s2 + 1][3], q3);
+#pragma unroll
+                for (int k2 = 0; k2 < NPB; ++k2) bd.v[s2][k2] = u32x4{q0[k2], q1[k2], q2[k2], q3[k2]};
+            }
             u32x4 ba[KSN][NPB];
 #pragma unroll
             for (int s = 0; s < KSN; ++s) {
                 unsigned q0[NPB], q1[NPB], q2[NPB], q3[NPB];
 #pragma unroll
                 for (int k2 = 0; k2 < NPB; ++k2) q2[k2] = q3[k2] = 0u;
-                split_pair<NPB>(a1[2 * s][0], a1[2 * s][1], q0);
-                split_pair<NPB>(a1[2 * s][2], a1[2 * s][3], q1);
+                split2(a1[2 * s][0], a1[2 * s][1], q0);
+                split2(a1[2 * s][2], a1[2 * s][3], q1);
                 if (2 * s + 1 < TN) {
-                    split_pair<NPB>(a1[2 * s + 1][0], a1[2 * s + 1][1], q2);
-                    split_pair<NPB>(a1[2 * s + 1][2], a1[2 * s + 1][3], q3);
+                    split2(a1[2 * s + 1][0], a1[2 * s + 1][1], q2);
+                    split2(a1[2 * s + 1][2], a1[2 * s + 1][3], q3);
                 }
 #pragma unroll
                 for (int k2 = 0; k2 < NPB; ++k2) ba[s][k2] = u32x4{q0[k2], q1[k2], q2[k2], q3[k2]};
@@ -569,7 +619,8 @@ __device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsign
                 tr_tile_store(af, At, g, p);
                 WsOps ops;
                 swp_static_for<8>([&](auto ic) { ws_load_op<decltype(ic)::value>(ops, Dt + trb, At + trb); });
-                swp_static_for<12>([&](auto ic) { ws_dw_mfma<decltype(ic)::value>(dGw, ops); });
+                if constexpr (F16) swp_static_for<12>([&](auto ic) { ws16_dw_mfma<decltype(ic)::value>(dGw, ops); });
+                else swp_static_for<12>([&](auto ic) { ws_dw_mfma<decltype(ic)::value>(dGw, ops); });
             } else
 #endif
             {
@@ -617,7 +668,7 @@ __device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsign
                             for (int bb = 0; bb < NPB; ++bb) {
                                 if (wa + bb >= NPB) continue;
                                 const bool first = s == 0 && wa == 0 && bb == 0;
-                                nd[t] = mfma_bf16(wf[wa], bd.v[s][bb], first ? zero : nd[t]);
+                                nd[t] = mm32(wf[wa], bd.v[s][bb], first ? zero : nd[t]);
                             }
                     }
                 }
@@ -631,16 +682,37 @@ __device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsign
                     dW1x[t][r] = fmaf(dl, tk, dW1x[t][r]);
                 }
         }
+        if constexpr (F16) {
+            float chk = 0.f;
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) chk = fmaf(dcs[t][r], 0.f, chk);         // (NaN iff some entry is inf / NaN)
+            bad = bad || !(chk == 0.f);
+        }
         if (ok) {
 #pragma unroll
             for (int t = 0; t < TN; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int f = feat_of(T0 + t, r, g);
-                    if (f < H1) a.dc[q * H1 + f] = dcs[t][r];
+                    if (f < H1) a.dc[q * H1 + f] = dcs[t][r] * inv_sigma;
                 }
         }
     }
+#if UMNN_BWD_NPB == 2
+    if constexpr (F16) {
+        float chk = 0.f;
+#pragma unroll
+        for (int to = 0; to < 2; ++to)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) chk = fmaf(dGw[to][ti][v], 0.f, chk);
+        bad = bad || !(chk == 0.f);
+        if (__any(bad) && lane == 0) atomicOr(&reinterpret_cast<Ws16Scal*>(a.scal)->flag, 1u);
+    }
+#endif
     // ---- this slot's partial d_theta: the G1 columns (weights + bias column) and the entries of the x-column of W1 that belong to
     // these feature tiles
     float* part = a.partials + (size_t)slot_global * a.n_params;
@@ -658,7 +730,7 @@ __device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsign
                     const int fi = 16 * T0 + slot_feature(32 * ti + (lane & 31));
                     if (fo < H2) {
                         const int idx = fi < H1 ? a.poffW[1] + fo * H1 + fi : (fi == H1 ? a.poffb[1] + fo : -1);
-                        if (idx >= 0) part[idx] = (fa.accumulate ? part[idx] : 0.f) + dGw[to][ti][v];
+                        if (idx >= 0) part[idx] = (fa.accumulate ? part[idx] : 0.f) + dGw[to][ti][v] * inv_sigma;
                     }
                 }
     } else
@@ -685,7 +757,7 @@ __device__ __forceinline__ void front_bwd_body(const FrontArgs& fa, const unsign
             const int f = feat_of(T0 + t, r, g);
             if (p == 0 && f < H1) {
                 const int idx = a.poffW[0] + f * (1 + E);
-                part[idx] = (fa.accumulate ? part[idx] : 0.f) + v1;
+                part[idx] = (fa.accumulate ? part[idx] : 0.f) + v1 * inv_sigma;
             }
         }
 }
@@ -706,6 +778,7 @@ template <int T1, int NL2>
 __global__ __launch_bounds__(2 * UMNN_BLOCK, 1) void cc_front_bwd2_kernel(const FrontArgs fa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
+    if (fa.only_if && *fa.only_if == 0) return;      // queued as the fallback of the fp16 build: nothing overflowed
     stage_g1_image<T1, true, NPB>(fa.b.m, lds16, threadIdx.x, blockDim.x);
     __syncthreads();
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -716,17 +789,33 @@ __global__ __launch_bounds__(2 * UMNN_BLOCK, 1) void cc_front_bwd2_kernel(const 
     else front_bwd_body<T1, NL2, 4, T1 - 4>(fa, lds16, slot, nslots, wave_tiles);
 }
 
+#if UMNN_BWD_NPB == 2
+// the same on fp16 pieces (behind the fp16 middle stage only: the launch's sigma and flag are its)
+template <int T1, int NL2>
+__global__ __launch_bounds__(2 * UMNN_BLOCK, 1) void cc_front_bwd16_kernel(const FrontArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned short* lds16 = reinterpret_cast<unsigned short*>(lds);
+    stage_g1t_image16<T1>(fa.b.m, lds16, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned slot = blockIdx.x * UMNN_WAVES_PER_BLOCK + (wid & (UMNN_WAVES_PER_BLOCK - 1)), nslots = gridDim.x * UMNN_WAVES_PER_BLOCK;
+    unsigned short* wave_tiles = lds16 + T1 * BKS * NPB * FRAG + wid * 2 * (NPB * 16 * TRS);
+    if (wid < UMNN_WAVES_PER_BLOCK) front_bwd_body<T1, NL2, 0, 4, true>(fa, lds16, slot, nslots, wave_tiles);
+    else front_bwd_body<T1, NL2, 4, T1 - 4, true>(fa, lds16, slot, nslots, wave_tiles);
+}
+#endif
+
 }  // namespace UMNN_BWD_NS
 
 // ------------------------------------------------------------------------------------------ host side
 typedef void (*front_kernel_t)(const FrontArgs);
 typedef void (*mid_kernel_t)(const BwdBf16Args);
 #if UMNN_BWD_NPB == 2
-struct FrontVariant { int t1, nl2; front_kernel_t fwd, bwd, fwd16, bwd2; };
-#define FRONT_VARIANT(T, N) {T, N, cc_front_fwd_kernel<T, N>, cc_front_bwd_kernel<T, N>, cc_front_fwd16_kernel<T, N>, cc_front_bwd2_kernel<T, N>}
+struct FrontVariant { int t1, nl2; front_kernel_t fwd, bwd, fwd16, bwd2, bwd16; };
+#define FRONT_VARIANT(T, N) {T, N, cc_front_fwd_kernel<T, N>, cc_front_bwd_kernel<T, N>, cc_front_fwd16_kernel<T, N>, cc_front_bwd2_kernel<T, N>, cc_front_bwd16_kernel<T, N>}
 #else
-struct FrontVariant { int t1, nl2; front_kernel_t fwd, bwd, fwd16, bwd2; };
-#define FRONT_VARIANT(T, N) {T, N, cc_front_fwd_kernel<T, N>, cc_front_bwd_kernel<T, N>, nullptr, nullptr}
+struct FrontVariant { int t1, nl2; front_kernel_t fwd, bwd, fwd16, bwd2, bwd16; };
+#define FRONT_VARIANT(T, N) {T, N, cc_front_fwd_kernel<T, N>, cc_front_bwd_kernel<T, N>, nullptr, nullptr, nullptr}
 #endif
 static const FrontVariant kFrontVariants[] = {
     FRONT_VARIANT(5, 13), FRONT_VARIANT(6, 13), FRONT_VARIANT(7, 13), FRONT_VARIANT(8, 13),
@@ -848,6 +937,9 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
     const bool c2 = fv->bwd2 != nullptr && umnn_options().front_bwd2 != 0;
     const size_t lds_c2 = lds_c + (size_t)2 * UMNN_WAVES_PER_BLOCK * 2 * (NPB * 16 * TRS) * sizeof(unsigned short);      // + the waves' operand tiles
     if (c2) { if (lds_c2 > 160 * 1024) return UMNN_EUNSUPPORTED; if (int rc = umnn_allow_lds((const void*)fv->bwd2, lds_c2)) return rc; }
+    // ... and on fp16 pieces behind the fp16 middle stage (front_bwd2 = 2 keeps bf16 pieces there)
+    const bool c16 = c2 && fv->bwd16 != nullptr && umnn_options().front_bwd2 == 1;
+    if (c16) { if (int rc = umnn_allow_lds((const void*)fv->bwd16, lds_c2)) return rc; }
     const MidVariant* wv = nullptr;
     size_t lds_ws = 0;
 #if UMNN_BWD_NPB == 2
@@ -911,7 +1003,13 @@ int UMNN_FRONT_LAUNCH(const BwdArgs& base, const umnn_mlp* net, int nblocks_max,
             if (run_a) hipLaunchKernelGGL(fv->fwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_a, stream, fa);
             hipLaunchKernelGGL(mv->fn, dim3(nblocks * (UMNN_WAVES_PER_BLOCK / wpb_mid)), dim3(64 * wpb_mid), lds_mid, stream, mid);
         }
-        if (c2) hipLaunchKernelGGL(fv->bwd2, dim3(nblocks), dim3(2 * UMNN_BLOCK), lds_c2, stream, fa);
+        if (c16 && hv && used_ws) {
+            // (fp16 pieces, then the bf16 build that only runs if the launch flag is up -- raised by stage B's checks or by this stage's own)
+            hipLaunchKernelGGL(fv->bwd16, dim3(nblocks), dim3(2 * UMNN_BLOCK), lds_c2, stream, fa);
+            fa.only_if = base.scal + 3;            // (Ws16Scal::flag)
+            hipLaunchKernelGGL(fv->bwd2, dim3(nblocks), dim3(2 * UMNN_BLOCK), lds_c2, stream, fa);
+            fa.only_if = nullptr;
+        } else if (c2) hipLaunchKernelGGL(fv->bwd2, dim3(nblocks), dim3(2 * UMNN_BLOCK), lds_c2, stream, fa);
         else hipLaunchKernelGGL(fv->bwd, dim3(nblocks), dim3(UMNN_BLOCK), lds_c, stream, fa);
     }
     umnn_prof_end(stream, 3.0 * umnn_cc_forward_flops_per_integral(net, n) * (double)base.NI, UMNN_PROF_BACKWARD);

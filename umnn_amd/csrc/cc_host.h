@@ -28,7 +28,7 @@ struct UmnnOptions {
     std::atomic<int> bwd_ns{-1};         // UMNN_BWD_NS: node-range split of the backward (1..32)
     std::atomic<int> bwd_ws{1};          // UMNN_BWD_WS: weight-stationary workgroup pipeline for four-hidden-layer nets at large batch (cc_bwd_ws_kernel.h)
     std::atomic<int> bwd_ws16{1};        // UMNN_BWD_WS16: that pipeline on fp16 pieces (cc_bwd_ws16_kernel.h: three-term recompute): 1 = for launches of >= 2^21 node evaluations, 2 = whenever eligible, 0 = never (the bf16 pipeline)
-    std::atomic<int> front_bwd2{1};      // UMNN_FRONT_BWD2: stage C of the three-stage backward with two waves per tile of integrals (cc_backward_front.hip); 0 = one
+    std::atomic<int> front_bwd2{1};      // UMNN_FRONT_BWD2: stage C of the three-stage backward with two waves per tile of integrals (cc_backward_front.hip; 1: on fp16 pieces behind the fp16 middle stage, 2: bf16 pieces always); 0 = one
     std::atomic<int> bwd_swp{1};         // UMNN_BWD_SWP: software-pipelined one-pass bf16 backward (cc_bwd_swp_kernel.h); 0 = round-2 loop
 };
 UmnnOptions& umnn_options();
