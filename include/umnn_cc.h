@@ -181,6 +181,16 @@ int umnn_cc_backward_saved(const umnn_mlp* net, const float* x, const float* h, 
                            const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
                            float* dx, float* dh, float* dtheta, const float* z2_saved, long long z2_floats,
                            void* workspace, long long workspace_bytes, void* stream);
+/* The pair with bf16 or fp32 activation storage (umnn_io; io may be null = fp32): configuration C4's bf16 embedding on the training path. */
+int umnn_flow_stack_block_forward_save_io(const umnn_mlp* net, const umnn_io* io, const void* x, const void* h, const float* scaling,
+                                          const float* cc_w, const float* cc_s, int nb_steps,
+                                          long long B, int d, int E, int reverse_z, const void* log_jac_in,
+                                          void* z, void* log_jac, void* f_x, void* f_x0,
+                                          float* z2_save, long long z2_floats, void* stream);
+int umnn_cc_backward_saved_io(const umnn_mlp* net, const umnn_io* io, const void* x, const void* h, const void* g, const void* g_fx,
+                              const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
+                              void* dx, void* dh, float* dtheta, const float* z2_saved, long long z2_floats,
+                              void* workspace, long long workspace_bytes, void* stream);
 
 /* Elementwise glue of a block's TRAINING path (umnn_amd/csrc/cc_flow_glue.hip), one launch each.
  * umnn_flow_block_cotangents: backward of the block epilogue (UMNNMAF.py:80-83,134,138-139)

@@ -92,6 +92,11 @@ SIGNATURES = {
                                                           _fp, _fp, _fp, _fp, _fp, _ll, _fp]),
     "umnn_cc_backward_saved": (ctypes.c_int, [ctypes.POINTER(MlpDesc), _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                               _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _ll, _fp, _ll, _fp]),
+    "umnn_flow_stack_block_forward_save_io": (ctypes.c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(IoDesc), _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                                             _ll, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
+                                                             _fp, _fp, _fp, _fp, _fp, _ll, _fp]),
+    "umnn_cc_backward_saved_io": (ctypes.c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(IoDesc), _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                                 _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _ll, _fp, _ll, _fp]),
     "umnn_flow_block_cotangents": (ctypes.c_int, [_fp, _fp, _fp, _fp, _ll, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
     "umnn_flow_ll_forward": (ctypes.c_int, [_fp, _fp, _ll, ctypes.c_int, _fp, _fp]),
     "umnn_flow_ll_backward": (ctypes.c_int, [_fp, _fp, _ll, ctypes.c_int, _fp, _fp, _fp]),

@@ -849,6 +849,17 @@ extern "C" int umnn_cc_backward_saved(const umnn_mlp* net, const float* x, const
     return backward_impl(net, nullptr, nullptr, x, h, g, g_fx, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr, dx, dh, dtheta, workspace,
                          workspace_bytes, stream_, z2_saved);
 }
+extern "C" int umnn_cc_backward_saved_io(const umnn_mlp* net, const umnn_io* io, const void* x, const void* h, const void* g, const void* g_fx,
+                                         const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E,
+                                         void* dx, void* dh, float* dtheta, const float* z2_saved, long long z2_floats,
+                                         void* workspace, long long workspace_bytes, void* stream_) {
+    const long long need = umnn_cc_forward_z2_floats(net, B, d, E, nb_steps);
+    if (need == 0) z2_saved = nullptr;
+    else if (!z2_saved || z2_floats < need)
+        return umnn_fail(UMNN_EINVAL, "backward (z_2 saved): buffer missing or smaller than umnn_cc_forward_z2_floats()");
+    return backward_impl(net, io, nullptr, x, h, g, g_fx, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr, dx, dh, dtheta, workspace,
+                         workspace_bytes, stream_, z2_saved);
+}
 static int backward_impl(const umnn_mlp* net, const umnn_io* io, const void* x0_, const void* x_, const void* h_,
                          const void* g_, const void* g_fx_,
                          const float* cc_w, const float* cc_s, int nb_steps, long long B, int d, int E, int inv_f,

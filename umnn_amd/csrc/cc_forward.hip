@@ -405,6 +405,22 @@ extern "C" int umnn_flow_stack_block_forward_save(const umnn_mlp* net, const flo
                           z, log_jac, (hipStream_t)stream, reverse_z != 0, log_jac_in, nullptr, nullptr, 0, 0, nullptr, z2_save);
 }
 
+// ... with bf16 or fp32 activation storage (configuration C4's embedding in bf16: z_2 itself stays fp32 -- it is scratch between two kernels)
+extern "C" int umnn_flow_stack_block_forward_save_io(const umnn_mlp* net, const umnn_io* io, const void* x, const void* h, const float* scaling,
+                                                     const float* cc_w, const float* cc_s, int nb_steps,
+                                                     long long B, int d, int E, int reverse_z, const void* log_jac_in,
+                                                     void* z, void* log_jac, void* f_x, void* f_x0,
+                                                     float* z2_save, long long z2_floats, void* stream) {
+    if (!scaling) return umnn_fail(UMNN_EINVAL, "flow forward: scaling must be non-null");
+    if (z == x && reverse_z) return umnn_fail(UMNN_EINVAL, "flow forward: z must not alias x when reverse_z is set");
+    const long long need = umnn_cc_forward_z2_floats(net, B, d, E, nb_steps);
+    if (need == 0) return umnn_fail(UMNN_EUNSUPPORTED, "flow forward (z_2 saved): not the wide-first family / arithmetic mode");
+    if (!z2_save || z2_floats < need) return umnn_fail(UMNN_EINVAL, "flow forward (z_2 saved): buffer smaller than umnn_cc_forward_z2_floats()");
+    return launch_forward(net, nullptr, (const float*)x, (const float*)h, scaling, cc_w, cc_s, nb_steps, B, d, E, 0, nullptr,
+                          (float*)f_x, (float*)f_x0, (float*)z, (float*)log_jac, (hipStream_t)stream, reverse_z != 0,
+                          (const float*)log_jac_in, nullptr, nullptr, 0, 0, io, z2_save);
+}
+
 extern "C" int umnn_cc_forward_io(const umnn_mlp* net, const umnn_io* io, const void* x0, const void* x, const void* h,
                                   const float* cc_w, const float* cc_s, int nb_steps,
                                   long long B, int d, int E, int inv_f, void* F, void* f_x, void* f_x0, void* stream) {

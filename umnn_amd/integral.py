@@ -264,11 +264,13 @@ def hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z=False, log_jac_in=No
     B, d, E = _shape(spec, x, h)
     if save_z2:
         z2 = None
-        if x.dtype == torch.float32 and h.dtype == torch.float32:
+        # (fp32 x-class tensors; the embedding h in fp32 or -- configuration C4 -- bf16, loaded as such by the kernels)
+        if x.dtype == torch.float32 and h.dtype in (torch.float32, torch.bfloat16):
             desc, keep = _desc(spec)
             nfl = int(lib.umnn_cc_forward_z2_floats(ctypes.byref(desc), B, d, E, int(nb_steps)))
             if 0 < 4 * nfl <= _Z2_MAX_BYTES and _z2_live[0] + 4 * nfl <= _Z2_TOTAL_BYTES:
-                x, h, scaling = _f32c(x), _f32c(h), _f32c(scaling)
+                _, _, io = _io_prep(x, h)
+                x, h, scaling = _f32c(x), h.detach().contiguous(), _f32c(scaling)
                 w, s = device_tables(nb_steps, x.device)
                 z2 = torch.empty(nfl, device=x.device, dtype=torch.float32)
                 _z2_live[0] += 4 * nfl
@@ -276,10 +278,15 @@ def hip_flow_block(spec, x, h, scaling, nb_steps, reverse_z=False, log_jac_in=No
                 z, lj, fx, fx0 = (torch.empty_like(x) for _ in range(4))
                 lj_in = _as(log_jac_in, torch.float32)
                 with torch.cuda.device(x.device):
-                    rc = lib.umnn_flow_stack_block_forward_save(ctypes.byref(desc), _ptr(x), _ptr(h), _ptr(scaling), _ptr(w), _ptr(s),
-                                                                int(nb_steps), B, d, E, 1 if reverse_z else 0, _ptr(lj_in), _ptr(z), _ptr(lj),
-                                                                _ptr(fx), _ptr(fx0), _ptr(z2), nfl,
-                                                                ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+                    stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+                    if io is None:
+                        rc = lib.umnn_flow_stack_block_forward_save(ctypes.byref(desc), _ptr(x), _ptr(h), _ptr(scaling), _ptr(w), _ptr(s),
+                                                                    int(nb_steps), B, d, E, 1 if reverse_z else 0, _ptr(lj_in), _ptr(z), _ptr(lj),
+                                                                    _ptr(fx), _ptr(fx0), _ptr(z2), nfl, stream)
+                    else:
+                        rc = lib.umnn_flow_stack_block_forward_save_io(ctypes.byref(desc), ctypes.byref(io), _ptr(x), _ptr(h), _ptr(scaling),
+                                                                       _ptr(w), _ptr(s), int(nb_steps), B, d, E, 1 if reverse_z else 0,
+                                                                       _ptr(lj_in), _ptr(z), _ptr(lj), _ptr(fx), _ptr(fx0), _ptr(z2), nfl, stream)
                 if rc == 0:
                     _state.path = "hip"
                     return z, lj, fx, fx0, z2
@@ -400,7 +407,11 @@ def hip_backward(spec, x0, x, h, g, g_fx, nb_steps, need=(True, True, True, True
         nbytes = lib.umnn_cc_backward_workspace_bytes(ctypes.byref(desc), B, d, E)
         ws = torch.empty(max(int(nbytes), 4), device=x.device, dtype=torch.uint8)
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        if z2_saved is not None and io is None and not inv_f and x0 is None and not need[0]:      # (that entry point has no d_x0 output)
+        if z2_saved is not None and io is not None and not inv_f and x0 is None and not need[0]:
+            rc = lib.umnn_cc_backward_saved_io(ctypes.byref(desc), ctypes.byref(io), _ptr(x), _ptr(h), _ptr(g), _ptr(g_fx), _ptr(w), _ptr(s),
+                                               int(nb_steps), B, d, E, _ptr(dx), _ptr(dh), _ptr(dtheta), _ptr(z2_saved), int(z2_saved.numel()),
+                                               _ptr(ws), int(nbytes), stream)
+        elif z2_saved is not None and io is None and not inv_f and x0 is None and not need[0]:      # (that entry point has no d_x0 output)
             rc = lib.umnn_cc_backward_saved(ctypes.byref(desc), _ptr(x), _ptr(h), _ptr(g), _ptr(g_fx), _ptr(w), _ptr(s), int(nb_steps),
                                             B, d, E, _ptr(dx), _ptr(dh), _ptr(dtheta), _ptr(z2_saved), int(z2_saved.numel()),
                                             _ptr(ws), int(nbytes), stream)
@@ -615,8 +626,9 @@ class FlowLogLikelihood(torch.autograd.Function):
 
 
 def fused_block_ok(x, h, scaling, x0, want_jac):
-    """The one-node training path of a block applies: fp32 storage, lower limit 0, log_jac wanted, frozen scaling, no autocast."""
-    return (x0 is None and want_jac and x.dtype == torch.float32 and h.dtype == torch.float32 and x.dim() == 2
+    """The one-node training path of a block applies: fp32 x-class storage (the embedding h in fp32 or bf16), lower limit 0, log_jac
+    wanted, frozen scaling, no autocast."""
+    return (x0 is None and want_jac and x.dtype == torch.float32 and h.dtype in (torch.float32, torch.bfloat16) and x.dim() == 2
             and not scaling.requires_grad and not torch.is_autocast_enabled() and os.environ.get("UMNN_FUSED_TRAIN", "1") != "0")
 
 
