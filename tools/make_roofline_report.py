@@ -115,8 +115,10 @@ for tag, title in (("bsds300", "C3 BSDS300-shaped eval (8192 x 63 integrals per 
                               (next((k for k in ("cc_bwd_ws16_kernel", "cc_bwd_ws_kernel") if any(k in r["Name"] for r in stats)), "cc_bwd_bf16_kernel"),
                                "stage B: flagship kernel on the net from hidden layer 2 on (FRONT; the workgroup pipeline, round 4: on fp16 pieces -- "
                                "the cc_bwd_ws_kernel launches next to it are the queued overflow fallback returning at once)"),
-                              (next((k for k in ("cc_front_bwd2_kernel",) if any(k in r["Name"] for r in stats)), "cc_front_bwd_kernel"),
-                               "stage C: front backward (dG1, delta_1; round 6: two waves per tile of integrals, cc_front_bwd2_kernel)")):
+                              (next((k for k in ("cc_front_bwd16_kernel", "cc_front_bwd2_kernel") if any(k in r["Name"] for r in stats)), "cc_front_bwd_kernel"),
+                               "stage C: front backward (dG1, delta_1; round 6: two waves per tile of integrals, dG1 on 32x32x16 through LDS-transposed "
+                               "operands, on fp16 pieces -- cc_front_bwd16_kernel; the cc_front_bwd2_kernel launches next to it are its queued bf16 "
+                               "fallback returning at once)")):
                 e = kernel_entry(stats, pmc, part, fl)
                 e["algorithmic_flops_per_launch"] = None
                 report[tag][part] = e
