@@ -1091,6 +1091,172 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
     }
 }
 
+// ============================================================================================================ wave B1, software-pipelined (round 6)
+// B1 is the LAST role of the pipeline: nothing downstream waits for its result, so its vector tail -- act'(a_1), the dc sums, dW_1[:, 0]:
+// 65 instructions per step that ran un-shadowed behind the 24 matrix instructions of its GEMM -- can lag the GEMM by one step at no cost
+// in rings or latency.  Step s: W_1^T GEMM of element s - 10 into one of two alternating accumulator sets, with the tail of element
+// s - 11 (the OTHER set, and the a_1 signs fetched a step ago) as fillers behind its matrix instructions.  Timing-only ablations had
+// put B1 (with F3) on the critical path: its two accumulations alone were 2.9 % of the kernel (EXPERIMENTS.md).  Same arithmetic, same
+// summation order per integral: results are bit-identical to the un-pipelined role.
+template <int NRL>
+__device__ __forceinline__ void ws16_role_B1p(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
+    constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
+    constexpr int LAYER = 1, DB = 11 - LAYER, DT = DB + 1;        // GEMM on element s - DB, tail on element s - DT
+    const BwdArgs& a = args.b;
+    const MlpDev& m = a.m;
+    const int lane = threadIdx.x & 63, g = lane >> 4, p = lane & 15;
+    const int H1 = m.width[1], E = a.E;
+    const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
+    const int own = p * TRS + g * 16;
+    const int nit = sh.nit;
+    u32x4 WT[BT][BKS][W16_NP];
+    {
+        const unsigned short* imt = lds16 + (3 + LAYER - 1) * W16_IMG + lane * 8;
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < BKS; ++s2)
+#pragma unroll
+                for (int k2 = 0; k2 < W16_NP; ++k2) WT[t][s2][k2] = *reinterpret_cast<const u32x4*>(imt + ((t * BKS + s2) * W16_NP + k2) * FRAG);
+    }
+    ws16_clear_tiles(lds16);
+    float inv_sigma;
+    (void)ws16_sigma(reinterpret_cast<const Ws16Scal*>(args.scal), inv_sigma);
+
+    f32x4 dW1x[BT], dcs[BT];
+#pragma unroll
+    for (int t = 0; t < BT; ++t) { dW1x[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    bool bad = false;
+    WsCursor cb{0, 0};                                  // the element of the TAIL (s - DT)
+    float xvB = 0.f, x0vB = 0.f, dxvB = 0.f;
+    auto new_item_B = [&]() __attribute__((always_inline)) {
+        const long long q = (long long)(args.grp0 + ws_grp(cb)) * 16 + p;
+        const long long qq = q < a.NI ? q : a.NI - 1;
+        xvB = io_ld(a.x, qq, a.x_bf16);
+        x0vB = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
+        dxvB = xvB - x0vB;
+    };
+    if (nit > 0) new_item_B();
+
+    WS_TIMING_DECL;
+    int rAsg = ws_ring0<ws_a_ns(LAYER), WS_TILE>(DB), rDin = ws_ring0<2, WS_TILE>(DB);
+    float tkB = 0.f;
+    {
+        const int kB = ws_node(sh, cb);
+        const float uu = ws16_ccs(lds16, kB) + 1.f;
+        tkB = (kB == 0) ? xvB : __fadd_rn(x0vB, __fmul_rn(dxvB, uu) * 0.5f);
+    }
+    f32x4 nds[2][BT];
+    u32x4 sgs[2][BKS];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int t = 0; t < BT; ++t) nds[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < BKS; ++s2) sgs[q][s2] = u32x4{0u, 0u, 0u, 0u};
+    }
+    int sstep = 0;
+    auto step = [&](auto parc) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(parc)::value;
+        f32x4 (&nd)[BT] = nds[PAR];                     // this step's GEMM output (element s - DB)
+        const f32x4 (&ndp)[BT] = nds[PAR ^ 1];          // last step's: the tail's input (element s - DT)
+        const u32x4 (&sgp)[BKS] = sgs[PAR ^ 1];
+        const int s = sstep;
+        WS_T(t0);
+        const bool liveB = s >= DT && cb.j < nit;
+        WsCursor nxB = cb;
+        if (liveB) nxB = ws_next(sh, cb);
+        const int kBn = ws_node(sh, nxB);
+        const float ccs_n = ws16_ccs(lds16, kBn);
+        const unsigned short* Asg = lds16 + ws_a_off(LAYER) + rAsg + own;                                  // a_1[s - DB]
+        const unsigned short* Din = lds16 + WS_OFF_D + (LAYER + 1 - 2) * 2 * WS_TILE + rDin + own;         // delta_2[s - DB]
+        BFrag<W16_NP> bd;
+#pragma unroll
+        for (int s2 = 0; s2 < BKS; ++s2)
+#pragma unroll
+            for (int k2 = 0; k2 < W16_NP; ++k2) bd.v[s2][k2] = *reinterpret_cast<const u32x4*>(Din + k2 * 16 * TRS + s2 * 8);
+#pragma unroll
+        for (int s2 = 0; s2 < BKS; ++s2) sgs[PAR][s2] = *reinterpret_cast<const u32x4*>(Asg + s2 * 8);
+        WS_T(t1);
+        // the tail of element s - DT, one register per micro-operation (5 vector instructions), behind the matrix instructions below
+        auto tail_reg = [&](auto ec) __attribute__((always_inline)) {
+            constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
+            if constexpr (e < NLIVE) {
+                const float dl = ndp[t][r] * act_grad_q(sgp, t, r, slope);
+                dcs[t][r] += dl;
+                dW1x[t][r] = fmaf(dl, tkB, dW1x[t][r]);
+            }
+        };
+        {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            swp_static_for<24>([&](auto nc) {
+                constexpr int nn = decltype(nc)::value;
+                WS_MARK(nn, 24);
+                // the matrix instructions in the order of the un-pipelined role (K-step, then cross term, tiles innermost)
+                constexpr int s2 = nn / 12, term = (nn % 12) / 4, t = nn % 4;
+                if constexpr (term < 2) nd[t] = mfma_f16(WT[t][s2][0], bd.v[s2][term], (s2 == 0 && term == 0) ? zero : nd[t]);
+                else nd[t] = mfma_f16(WT[t][s2][1], bd.v[s2][0], nd[t]);
+                // (the first operand fetch of the step is still in flight behind slot 0: the tail starts at slot 2, a register every
+                // slot and a half)
+                if constexpr (nn >= 2 && nn < 22 && ws_op_of_slot(nn - 2) >= 0) tail_reg(std::integral_constant<int, ws_op_of_slot(nn - 2)>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        // ---- what only some elements of a tile do (uniform branches outside the scheduled region): the tail's element is the one in `cb`
+        if (liveB && cb.e == sh.ne - 1) {
+            const long long q = (long long)(args.grp0 + ws_grp(cb)) * 16 + p;
+            float chk = 0.f;
+#pragma unroll
+            for (int t = 0; t < BT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) chk = fmaf(dcs[t][r], 0.f, chk);         // (NaN iff some entry is inf / NaN)
+            bad = bad || !(chk == 0.f);
+            if (q < a.NI) {
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = feat_of(t, r, g);
+                        if (f < H1) a.dc[q * H1 + f] = dcs[t][r] * inv_sigma;
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < BT; ++t) dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (liveB) {
+            const bool crossed = nxB.j != cb.j;
+            cb = nxB;
+            if (crossed && cb.j < nit) new_item_B();
+            const float uu = ccs_n + 1.f;
+            tkB = (kBn == 0) ? xvB : __fadd_rn(x0vB, __fmul_rn(dxvB, uu) * 0.5f);
+        }
+        ws_adv<ws_a_ns(LAYER), WS_TILE>(rAsg); ws_adv<2, WS_TILE>(rDin);
+        WS_T(t2);
+        __syncthreads();
+        WS_T(t3);
+        WS_TIMING_ACC(t0, t1, t2, t3);
+        ++sstep;
+    };
+    // (S + 1 steps of tail work in S + 1 iterations would need one more barrier than the other roles run: the tail of the LAST element
+    // that can be live -- GEMM'd at step S - 2, element nit * ne - 1 = S - 2 - DB -- runs at step S - 1: inside the S steps)
+    for (int s = 0; s < S; s += 2) {
+        step(std::integral_constant<int, 0>{});
+        if (s + 1 < S) step(std::integral_constant<int, 1>{});
+    }
+    WS_TIMING_OUT(S);
+#pragma unroll
+    for (int t = 0; t < BT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = dW1x[t][r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+            const int f = feat_of(t, r, g);
+            if (p == 0 && f < H1) part[a.poffW[0] + f * (1 + E)] = v * inv_sigma;
+        }
+    if (__any(bad) && lane == 0) atomicOr(&reinterpret_cast<Ws16Scal*>(args.scal)->flag, 1u);
+}
+
 // wave -> role.  Waves w and w + 4 share a SIMD: Ca + Cb, F1 + B1, F2 + B2, F3 + B3.
 template <int NRL, bool FRONT = false>
 __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws16_kernel(const BwdBf16Args args) {
@@ -1129,7 +1295,10 @@ __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws16_kernel(const Bwd
         else ws16_role_F<NRL, 3>(args, lds16, S, sh, part);
     } else {
         if (role == 0) ws16_role_Cb<NRL>(args, lds16, S, sh, part);
-        else if (role == 1) ws16_role_B<NRL, 1, FRONT>(args, lds16, S, sh, part);
+        else if (role == 1) {
+            if constexpr (FRONT) ws16_role_B<NRL, 1, FRONT>(args, lds16, S, sh, part);
+            else ws16_role_B1p<NRL>(args, lds16, S, sh, part);
+        }
         else if (role == 2) ws16_role_B<NRL, 2, FRONT>(args, lds16, S, sh, part);
         else ws16_role_B<NRL, 3, FRONT>(args, lds16, S, sh, part);
     }
