@@ -1098,7 +1098,9 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
 // s - 11 (the OTHER set, and the a_1 signs fetched a step ago) as fillers behind its matrix instructions.  Timing-only ablations had
 // put B1 (with F3) on the critical path: its two accumulations alone were 2.9 % of the kernel (EXPERIMENTS.md).  Same arithmetic, same
 // summation order per integral: results are bit-identical to the un-pipelined role.
-template <int NRL>
+// FRONT (middle stage of the three-stage backward): the tail is act'(a_2) and the un-scaling of delta_2 as fillers; its 13 stores to HBM
+// and the finiteness check stay one uniform block behind the schedule.
+template <int NRL, bool FRONT>
 __device__ __forceinline__ void ws16_role_B1p(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
     constexpr int LAYER = 1, DB = 11 - LAYER, DT = DB + 1;        // GEMM on element s - DB, tail on element s - DT
@@ -1130,6 +1132,7 @@ __device__ __forceinline__ void ws16_role_B1p(const BwdBf16Args& args, unsigned 
     WsCursor cb{0, 0};                                  // the element of the TAIL (s - DT)
     float xvB = 0.f, x0vB = 0.f, dxvB = 0.f;
     auto new_item_B = [&]() __attribute__((always_inline)) {
+        if constexpr (FRONT) return;
         const long long q = (long long)(args.grp0 + ws_grp(cb)) * 16 + p;
         const long long qq = q < a.NI ? q : a.NI - 1;
         xvB = io_ld(a.x, qq, a.x_bf16);
@@ -1141,7 +1144,12 @@ __device__ __forceinline__ void ws16_role_B1p(const BwdBf16Args& args, unsigned 
     WS_TIMING_DECL;
     int rAsg = ws_ring0<ws_a_ns(LAYER), WS_TILE>(DB), rDin = ws_ring0<2, WS_TILE>(DB);
     float tkB = 0.f;
-    {
+    float d2v[BT][4];                                   // (FRONT) delta_2 of the tail's element, un-scaled, on its way to HBM
+#pragma unroll
+    for (int t = 0; t < BT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d2v[t][r] = 0.f;
+    if constexpr (!FRONT) {
         const int kB = ws_node(sh, cb);
         const float uu = ws16_ccs(lds16, kB) + 1.f;
         tkB = (kB == 0) ? xvB : __fadd_rn(x0vB, __fmul_rn(dxvB, uu) * 0.5f);
@@ -1167,7 +1175,8 @@ __device__ __forceinline__ void ws16_role_B1p(const BwdBf16Args& args, unsigned 
         WsCursor nxB = cb;
         if (liveB) nxB = ws_next(sh, cb);
         const int kBn = ws_node(sh, nxB);
-        const float ccs_n = ws16_ccs(lds16, kBn);
+        float ccs_n = 0.f;
+        if constexpr (!FRONT) ccs_n = ws16_ccs(lds16, kBn);
         const unsigned short* Asg = lds16 + ws_a_off(LAYER) + rAsg + own;                                  // a_1[s - DB]
         const unsigned short* Din = lds16 + WS_OFF_D + (LAYER + 1 - 2) * 2 * WS_TILE + rDin + own;         // delta_2[s - DB]
         BFrag<W16_NP> bd;
@@ -1183,8 +1192,12 @@ __device__ __forceinline__ void ws16_role_B1p(const BwdBf16Args& args, unsigned 
             constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
             if constexpr (e < NLIVE) {
                 const float dl = ndp[t][r] * act_grad_q(sgp, t, r, slope);
-                dcs[t][r] += dl;
-                dW1x[t][r] = fmaf(dl, tkB, dW1x[t][r]);
+                if constexpr (FRONT) {
+                    d2v[t][r] = dl * inv_sigma;
+                } else {
+                    dcs[t][r] += dl;
+                    dW1x[t][r] = fmaf(dl, tkB, dW1x[t][r]);
+                }
             }
         };
         {
@@ -1203,6 +1216,22 @@ __device__ __forceinline__ void ws16_role_B1p(const BwdBf16Args& args, unsigned 
             });
         }
         // ---- what only some elements of a tile do (uniform branches outside the scheduled region): the tail's element is the one in `cb`
+        if constexpr (FRONT) {
+            // delta_2 = dL/dz_2 of this node goes back to HBM for the front-backward kernel (not for the tangent element); a non-finite
+            // value (an overflowed cotangent piece) raises the flag
+            if (liveB && !ws_is_tan(sh, cb)) {
+                const int nl2 = NRL > 0 ? NRL : args.nl2;
+                const size_t base = ((size_t)ws_grp(cb) * (size_t)(a.n + 1) + (size_t)ws_node(sh, cb)) * nl2 * 64 + lane;
+                float chk = 0.f;
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * t + r < NLIVE && 4 * t + r < nl2) { args.d2[base + (size_t)(4 * t + r) * 64] = d2v[t][r]; chk = fmaf(d2v[t][r], 0.f, chk); }
+                bad = bad || !(chk == 0.f);
+            }
+            if (liveB) cb = nxB;
+        } else {
         if (liveB && cb.e == sh.ne - 1) {
             const long long q = (long long)(args.grp0 + ws_grp(cb)) * 16 + p;
             float chk = 0.f;
@@ -1230,6 +1259,7 @@ __device__ __forceinline__ void ws16_role_B1p(const BwdBf16Args& args, unsigned 
             const float uu = ccs_n + 1.f;
             tkB = (kBn == 0) ? xvB : __fadd_rn(x0vB, __fmul_rn(dxvB, uu) * 0.5f);
         }
+        }
         ws_adv<ws_a_ns(LAYER), WS_TILE>(rAsg); ws_adv<2, WS_TILE>(rDin);
         WS_T(t2);
         __syncthreads();
@@ -1244,16 +1274,18 @@ __device__ __forceinline__ void ws16_role_B1p(const BwdBf16Args& args, unsigned 
         if (s + 1 < S) step(std::integral_constant<int, 1>{});
     }
     WS_TIMING_OUT(S);
+    if constexpr (!FRONT) {
 #pragma unroll
-    for (int t = 0; t < BT; ++t)
+        for (int t = 0; t < BT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = dW1x[t][r];
+            for (int r = 0; r < 4; ++r) {
+                float v = dW1x[t][r];
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
-            const int f = feat_of(t, r, g);
-            if (p == 0 && f < H1) part[a.poffW[0] + f * (1 + E)] = v * inv_sigma;
-        }
+                for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+                const int f = feat_of(t, r, g);
+                if (p == 0 && f < H1) part[a.poffW[0] + f * (1 + E)] = v * inv_sigma;
+            }
+    }
     if (__any(bad) && lane == 0) atomicOr(&reinterpret_cast<Ws16Scal*>(args.scal)->flag, 1u);
 }
 
@@ -1295,10 +1327,7 @@ __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws16_kernel(const Bwd
         else ws16_role_F<NRL, 3>(args, lds16, S, sh, part);
     } else {
         if (role == 0) ws16_role_Cb<NRL>(args, lds16, S, sh, part);
-        else if (role == 1) {
-            if constexpr (FRONT) ws16_role_B<NRL, 1, FRONT>(args, lds16, S, sh, part);
-            else ws16_role_B1p<NRL>(args, lds16, S, sh, part);
-        }
+        else if (role == 1) ws16_role_B1p<NRL, FRONT>(args, lds16, S, sh, part);
         else if (role == 2) ws16_role_B<NRL, 2, FRONT>(args, lds16, S, sh, part);
         else ws16_role_B<NRL, 3, FRONT>(args, lds16, S, sh, part);
     }
