@@ -30,6 +30,8 @@
 // FRONT = the middle stage of the three-stage backward (cc_backward_front.hip; MNISTExperiment's 31-100-50^4-1): wave Ca takes
 // z_2 from HBM instead of computing layer 1, wave B1 writes delta_2 (un-scaled) back instead of dc / dW_1; single-chunk calls
 // only, because d_theta slices are written here and the fallback must be able to rewrite them (1.26 -> 1.15 ms per MNIST block).
+// Round 6: the three B waves are software-pipelined (tail of element u - 1 behind the GEMM of element u: ws16_role_Bp, ws16_role_B1p),
+// which moves this kernel's timetable and rings off cc_bwd_ws_kernel.h's -- see "Rings of this kernel" below.
 #pragma once
 #include "cc_bwd_ws_kernel.h"
 
@@ -40,9 +42,26 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 #define WS16_T 8                                  // the launch's largest root cotangent lands in [2^(T-1), 2^T)
 #endif
 constexpr int W16_NP = 2;                         // fp16 pieces of every matrix operand (three cross terms)
-constexpr int W16_OFF_S4 = WS_OFF_P3;             // (no third-piece tiles: the S4 tiles follow the cotangent tiles)
+// Rings of this kernel (round 6): waves B3 and B2 are software-pipelined like B1 (their tails one step behind their GEMMs: ws16_role_Bp), so
+// delta_3 / delta_2 and everything behind them run one / two steps later than in cc_bwd_ws_kernel.h's timetable: a_2 lives nine steps, a_1
+// thirteen (a_3 still five: a pipelined B wave fetches its signs with the GEMM and holds them a step), fourteen steps from Ca to B1's tail.
+//   step u      Ca: a_1[u]          u+1/2  F1 -> a_2[u]        u+3/4  F2 -> a_3[u]        u+5/6  F3 -> S4[u]        u+7  Cb: delta_4[u]
+//   step u+8    B3: GEMM;  Ca: dW_3          u+9   B3: tail -> delta_3[u]
+//   step u+10   B2: GEMM;  dW_2 (Cb, F2)     u+11  B2: tail -> delta_2[u]
+//   step u+12   B1: GEMM;  dW_1 (Cb, F1)     u+13  B1: tail (dc, dW_1[:,0])
+// LDS: 33 activation / cotangent tiles of 4.5 KB + the S4 pair + the quadrature tables (W16_MAX_NODES = 256 nodes: longer rules run the bf16
+// pipeline) = 155 KB.
+constexpr int W16_NS1 = 13, W16_NS2 = 9, W16_NS3 = 5;
+constexpr int W16_OFF_A1 = 0;
+constexpr int W16_OFF_A2 = W16_OFF_A1 + W16_NS1 * WS_TILE;
+constexpr int W16_OFF_A3 = W16_OFF_A2 + W16_NS2 * WS_TILE;
+constexpr int W16_OFF_D = W16_OFF_A3 + W16_NS3 * WS_TILE;      // delta_l, l = 2..4: tile (l - 2) * 2 + (u & 1)
+constexpr int W16_OFF_S4 = W16_OFF_D + 6 * WS_TILE;            // (no third-piece tiles: the S4 tiles follow the cotangent tiles)
+constexpr int W16_DEPTH = 13;                                  // steps between an element entering (Ca) and leaving (B1's tail)
+__host__ __device__ constexpr int w16_a_off(int l) { return l == 1 ? W16_OFF_A1 : (l == 2 ? W16_OFF_A2 : W16_OFF_A3); }
+__host__ __device__ constexpr int w16_a_ns(int l) { return l == 1 ? W16_NS1 : (l == 2 ? W16_NS2 : W16_NS3); }
 constexpr int W16_TILE_USHORTS = W16_OFF_S4 + 2 * WS_P3;          // everything ws16_clear_tiles zeroes
-constexpr int W16_MAX_NODES = 1024;               // quadrature tables in LDS: w_k at float k, s_k at float W16_MAX_NODES + k
+constexpr int W16_MAX_NODES = 256;                // quadrature tables in LDS: w_k at float k, s_k at float W16_MAX_NODES + k (n + 1 above it: the bf16 pipeline)
 constexpr int W16_OFF_TAB = W16_TILE_USHORTS;
 constexpr int W16_LDS_USHORTS = W16_OFF_TAB + 2 * W16_MAX_NODES * 2;
 constexpr int W16_IMG = BT * BKS * W16_NP * FRAG; // staging image of one weight matrix (start of the launch only)
@@ -375,8 +394,8 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
         for (int r = 0; r < 4; ++r) actF[t][r] = 0.f;
 
     WS_TIMING_DECL;
-    int rA3 = ws_ring0<WS_NS3, WS_TILE>(8), rD4 = ws_ring0<2, WS_TILE>(8);
-    int rO1 = ws_ring0<WS_NS1, WS_TILE>(0);
+    int rA3 = ws_ring0<W16_NS3, WS_TILE>(8), rD4 = ws_ring0<2, WS_TILE>(8);
+    int rO1 = ws_ring0<W16_NS1, WS_TILE>(0);
     bool live = cu.j < nit;
     bool is_tan = live && ws_is_tan(sh, cu);
     float tk = 0.f;
@@ -387,7 +406,7 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
     }
     WsOps ops;
     {
-        const unsigned short* A3n = lds16 + WS_OFF_A3 + rA3 + trb;
+        const unsigned short* A3n = lds16 + W16_OFF_A3 + rA3 + trb;
         W16_LOAD_B(ops, A3n);
     }
     auto step = [&](auto parc) __attribute__((always_inline)) {
@@ -405,8 +424,8 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
                     for (int r = 0; r < 4; ++r) z0[t][r] = zc[t][r];
             }
         }
-        const unsigned short* D4 = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + trb;
-        unsigned short* const O1 = lds16 + WS_OFF_A1 + rO1 + own;
+        const unsigned short* D4 = lds16 + W16_OFF_D + 4 * WS_TILE + rD4 + trb;
+        unsigned short* const O1 = lds16 + W16_OFF_A1 + rO1 + own;
         // operands of dW_3: the a_3 half came in before the barrier, the delta_4 half (written last step) here
         W16_LOAD_A(ops, D4);
         // layer 1 of element s (tangent element: w1 . act'(z_1) of node 0)
@@ -467,10 +486,10 @@ __device__ __forceinline__ void ws16_role_Ca(const BwdBf16Args& args, unsigned s
                 tk = (kn == 0) ? xv : __fadd_rn(x0v, __fmul_rn(dxv, uu) * 0.5f);
             }
         }
-        ws_adv<WS_NS3, WS_TILE>(rA3); ws_adv<2, WS_TILE>(rD4);
-        ws_adv<WS_NS1, WS_TILE>(rO1);
+        ws_adv<W16_NS3, WS_TILE>(rA3); ws_adv<2, WS_TILE>(rD4);
+        ws_adv<W16_NS1, WS_TILE>(rO1);
         {   // next step's a_3 operand of dW_3 (a tile written four steps ago)
-            const unsigned short* A3n = lds16 + WS_OFF_A3 + rA3 + trb;
+            const unsigned short* A3n = lds16 + W16_OFF_A3 + rA3 + trb;
             W16_LOAD_B(ops, A3n);
         }
         WS_T(t2);
@@ -524,23 +543,23 @@ __device__ __forceinline__ void ws16_role_Cb(const BwdBf16Args& args, unsigned s
 #pragma unroll
     for (int j = 0; j < 8; ++j) { rb0[j] = rb1[j] = 0.f; q4[j][0] = q4[j][1] = 0u; }
     WS_TIMING_DECL;
-    int rA2 = ws_ring0<WS_NS2, WS_TILE>(9), rA1 = ws_ring0<WS_NS1, WS_TILE>(10);
-    int rD3 = ws_ring0<2, WS_TILE>(9), rD2 = ws_ring0<2, WS_TILE>(10);
+    int rA2 = ws_ring0<W16_NS2, WS_TILE>(10), rA1 = ws_ring0<W16_NS1, WS_TILE>(12);
+    int rD3 = ws_ring0<2, WS_TILE>(10), rD2 = ws_ring0<2, WS_TILE>(12);
     int rS4 = ws_ring0<2, WS_P3>(7), rD4 = ws_ring0<2, WS_TILE>(7);
     WsOpsH o2, o1;
-    ws16_load_hB_all(o2, lds16 + WS_OFF_A2 + rA2 + trb);          // (first step: the tiles are still zero)
-    ws16_load_hB_all(o1, lds16 + WS_OFF_A1 + rA1 + trb);
+    ws16_load_hB_all(o2, lds16 + W16_OFF_A2 + rA2 + trb);          // (first step: the tiles are still zero)
+    ws16_load_hB_all(o1, lds16 + W16_OFF_A1 + rA1 + trb);
     for (int s = 0; s < S; ++s) {
         WS_T(t0);
         // delta_4 of element s - 7 from what F3 left a step ago, as micro-operations behind the matrix instructions below
         const unsigned short* S4 = lds16 + W16_OFF_S4 + rS4;
-        unsigned short* const D4o = lds16 + WS_OFF_D + 4 * WS_TILE + rD4 + own;
+        unsigned short* const D4o = lds16 + W16_OFF_D + 4 * WS_TILE + rD4 + own;
         u32x4 sg4[BKS];
 #pragma unroll
         for (int s2 = 0; s2 < BKS; ++s2) sg4[s2] = *reinterpret_cast<const u32x4*>(S4 + own + s2 * 8);
         const float dout = *reinterpret_cast<const float*>(S4 + p * TRS + 64);
-        const unsigned short* D3 = lds16 + WS_OFF_D + 2 * WS_TILE + rD3 + trb;
-        const unsigned short* D2 = lds16 + WS_OFF_D + 0 * WS_TILE + rD2 + trb;
+        const unsigned short* D3 = lds16 + W16_OFF_D + 2 * WS_TILE + rD3 + trb;
+        const unsigned short* D2 = lds16 + W16_OFF_D + 0 * WS_TILE + rD2 + trb;
         // (the a_2 / a_1 halves of the operands came in before the barrier: only the cotangent halves, written last step, are fetched here)
         ws16_load_hA<1, 0>(o2, D3); ws16_load_hA<1, 1>(o2, D3);
         float d4[BT][4];
@@ -577,12 +596,12 @@ __device__ __forceinline__ void ws16_role_Cb(const BwdBf16Args& args, unsigned s
             if constexpr (nn == 18 || nn == 19) store_d4(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 18>{});
             __builtin_amdgcn_sched_barrier(0);
         });
-        ws_adv<WS_NS2, WS_TILE>(rA2); ws_adv<WS_NS1, WS_TILE>(rA1);
+        ws_adv<W16_NS2, WS_TILE>(rA2); ws_adv<W16_NS1, WS_TILE>(rA1);
         ws_adv<2, WS_TILE>(rD3); ws_adv<2, WS_TILE>(rD2);
         ws_adv<2, WS_P3>(rS4); ws_adv<2, WS_TILE>(rD4);
-        // next step's a_2 / a_1 operands (tiles written six and ten steps ago)
-        ws16_load_hB_all(o2, lds16 + WS_OFF_A2 + rA2 + trb);
-        ws16_load_hB_all(o1, lds16 + WS_OFF_A1 + rA1 + trb);
+        // next step's a_2 / a_1 operands (tiles written eight and twelve steps ago)
+        ws16_load_hB_all(o2, lds16 + W16_OFF_A2 + rA2 + trb);
+        ws16_load_hB_all(o1, lds16 + W16_OFF_A1 + rA1 + trb);
         WS_T(t2);
         __syncthreads();
         WS_T(t3);
@@ -607,7 +626,7 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
     constexpr bool IS_OUT = LAYER == 3;
     constexpr int LO = LAYER < 3 ? LAYER + 1 : 3;      // layer of the activation tile this wave writes (F3 writes the S4 tile instead)
     constexpr bool HAS_DW = LAYER < 3;                 // half a dW product: layer DWL, 32-row block DWH, element s - DD
-    constexpr int DWL = LAYER == 1 ? 1 : 2, DWH = LAYER == 1 ? 1 : 0, DD = 11 - DWL;
+    constexpr int DWL = LAYER == 1 ? 1 : 2, DWH = LAYER == 1 ? 1 : 0, DD = DWL == 1 ? 12 : 10;
     const BwdArgs& a = args.b;
     const MlpDev& m = a.m;
     const int lane = threadIdx.x & 63, g = lane >> 4, p = lane & 15;
@@ -682,8 +701,8 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
     float sc_a = 0.f, sc_sd = 0.f, sc_ex = 0.f, sc_f = 0.f, sc_fp = 0.f;      // (ELU + 1 outputs only: the launcher keeps sigmoid nets on the bf16 pipeline)
 
     WS_TIMING_DECL;
-    int rAin = ws_ring0<ws_a_ns(LAYER), WS_TILE>(DF);
-    int rAout = ws_ring0<ws_a_ns(LO), WS_TILE>(DP), rD4 = ws_ring0<2, WS_P3>(DP);
+    int rAin = ws_ring0<w16_a_ns(LAYER), WS_TILE>(DF);
+    int rAout = ws_ring0<w16_a_ns(LO), WS_TILE>(DP), rD4 = ws_ring0<2, WS_P3>(DP);
     float ccwP = 0.f;
     if constexpr (IS_OUT) ccwP = ws16_ccw(lds16, ws_node(sh, cp));
     ws_f32x16 dWh[2];
@@ -691,9 +710,9 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int v = 0; v < 16; ++v) dWh[ti][v] = 0.f;
-    int rAdw = ws_ring0<ws_a_ns(DWL), WS_TILE>(DD), rDdw = ws_ring0<2, WS_TILE>(DD);
+    int rAdw = ws_ring0<w16_a_ns(DWL), WS_TILE>(DD), rDdw = ws_ring0<2, WS_TILE>(DD);
     WsOpsH oh;
-    if constexpr (HAS_DW) ws16_load_hB_all(oh, lds16 + ws_a_off(DWL) + rAdw + trb);
+    if constexpr (HAS_DW) ws16_load_hB_all(oh, lds16 + w16_a_off(DWL) + rAdw + trb);
     for (int s = 0; s < S; ++s) {
         WS_T(t0);
         const bool liveP = s >= DP && cp.j < nit;
@@ -706,8 +725,8 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
             if (liveP && cp.e == 0) new_item_P();
         }
         const float nodef = (liveP && !tanP) ? 1.f : 0.f, k0f = kP == 0 ? 1.f : 0.f;
-        const unsigned short* Ain = lds16 + ws_a_off(LAYER) + rAin + own;                  // a_l[s - DF]
-        unsigned short* const Aout = lds16 + ws_a_off(LO) + rAout + own;                   // a_{l+1}[s - DP]
+        const unsigned short* Ain = lds16 + w16_a_off(LAYER) + rAin + own;                  // a_l[s - DF]
+        unsigned short* const Aout = lds16 + w16_a_off(LO) + rAout + own;                   // a_{l+1}[s - DP]
         unsigned short* const S4out = lds16 + W16_OFF_S4 + rD4;                            // F3: leading piece of a_4[s - 6], dout
         BFrag<W16_NP> bf;
 #pragma unroll
@@ -715,7 +734,7 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
 #pragma unroll
             for (int k2 = 0; k2 < W16_NP; ++k2) bf.v[s2][k2] = *reinterpret_cast<const u32x4*>(Ain + k2 * 16 * TRS + s2 * 8);
         if constexpr (HAS_DW) {
-            const unsigned short* Ddw = lds16 + WS_OFF_D + (DWL + 1 - 2) * 2 * WS_TILE + rDdw + trb;      // delta_{DWL+1}[s - DD]
+            const unsigned short* Ddw = lds16 + W16_OFF_D + (DWL + 1 - 2) * 2 * WS_TILE + rDdw + trb;      // delta_{DWL+1}[s - DD]
             ws16_load_hA<DWH, 0>(oh, Ddw); ws16_load_hA<DWH, 1>(oh, Ddw);
         }
 
@@ -874,11 +893,11 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
         }
         cp = nxP;
         ccwP = ccw_n;
-        ws_adv<ws_a_ns(LAYER), WS_TILE>(rAin);
-        ws_adv<ws_a_ns(LO), WS_TILE>(rAout); ws_adv<2, WS_P3>(rD4);
+        ws_adv<w16_a_ns(LAYER), WS_TILE>(rAin);
+        ws_adv<w16_a_ns(LO), WS_TILE>(rAout); ws_adv<2, WS_P3>(rD4);
         if constexpr (HAS_DW) {
-            ws_adv<ws_a_ns(DWL), WS_TILE>(rAdw); ws_adv<2, WS_TILE>(rDdw);
-            ws16_load_hB_all(oh, lds16 + ws_a_off(DWL) + rAdw + trb);      // next step's a_l operand of the dW half (an old tile)
+            ws_adv<w16_a_ns(DWL), WS_TILE>(rAdw); ws_adv<2, WS_TILE>(rDdw);
+            ws16_load_hB_all(oh, lds16 + w16_a_off(DWL) + rAdw + trb);      // next step's a_l operand of the dW half (an old tile)
         }
         WS_T(t2);
         __syncthreads();
@@ -905,21 +924,23 @@ __device__ __forceinline__ void ws16_role_F(const BwdBf16Args& args, unsigned sh
     }
 }
 
-// ============================================================================================================ waves B1..B3
-// W_l^T (two fp16 pieces, 64 registers): per step 24 MFMAs, then delta_l = (W_l^T delta_{l+1}) . act'(a_l), split, stored for the
-// next wave down.  B1 ends in the tail (dc, dW1[:,0]), un-scaled on the way out.
-template <int NRL, int LAYER, bool FRONT>
-__device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
+// ============================================================================================================ wave B3, software-pipelined (round 6)
+// After B1 (below) had been pipelined, F3 alone paced the step, and F3 shares its SIMD with B3 -- whose 72-instruction tail ran un-shadowed
+// behind its GEMM.  B3's result IS waited for (by B2 and the dW_2 products), so lagging its tail by a step moves everything behind it one step
+// later: two more ring slots (a_2: 9, a_1: 12), nothing else -- the signs of a_3 are fetched with the GEMM and held, so a_3's ring stays.
+// Step s: W_3^T GEMM of element s - 8 into one of two alternating accumulator sets; behind its matrix instructions the tail of element
+// s - 9 from the other set: act'(a_3), the two-piece split, the four stores of delta_3.  Same arithmetic in the same order: bit-identical.
+// LAYER = 2 (wave B2) the same one step on: GEMM of element s - 10, tail -> delta_2 of element s - 11 (one more slot for a_1).
+template <int NRL, int LAYER>
+__device__ __forceinline__ void ws16_role_Bp(const BwdBf16Args& args, unsigned short* lds16, int S) {
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
-    constexpr int DB = 11 - LAYER;                     // element s - DB: W_l^T GEMM, then its vector work, in the same step
-    constexpr bool IS_TAIL = LAYER == 1;
-    const BwdArgs& a = args.b;
-    const MlpDev& m = a.m;
+    constexpr int NPAIR = (NLIVE + 1) / 2;
+    static_assert(LAYER == 3 || LAYER == 2, "the pipelined middle B waves");
+    constexpr int DB = LAYER == 3 ? 8 : 10, DT = DB + 1;          // GEMM on element s - DB, tail (-> delta_LAYER) on element s - DT
+    const MlpDev& m = args.b.m;
     const int lane = threadIdx.x & 63, g = lane >> 4, p = lane & 15;
-    const int H1 = m.width[1], E = a.E;
     const float slope = m.hidden_act == UMNN_ACT_RELU ? 0.f : 0.01f;
     const int own = p * TRS + g * 16;
-    const int nit = sh.nit;
     u32x4 WT[BT][BKS][W16_NP];
     {
         const unsigned short* imt = lds16 + (3 + LAYER - 1) * W16_IMG + lane * 8;
@@ -931,171 +952,95 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
                 for (int k2 = 0; k2 < W16_NP; ++k2) WT[t][s2][k2] = *reinterpret_cast<const u32x4*>(imt + ((t * BKS + s2) * W16_NP + k2) * FRAG);
     }
     ws16_clear_tiles(lds16);
-    float inv_sigma;
-    (void)ws16_sigma(reinterpret_cast<const Ws16Scal*>(args.scal), inv_sigma);
-
-    f32x4 dW1x[BT], dcs[BT];
-#pragma unroll
-    for (int t = 0; t < BT; ++t) { dW1x[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    bool bad = false;                                   // an inf / NaN reached a dc sum: some cotangent piece overflowed
-    WsCursor cb{0, 0};
-    float xvB = 0.f, x0vB = 0.f, dxvB = 0.f;
-    auto new_item_B = [&]() __attribute__((always_inline)) {
-        if constexpr (IS_TAIL && !FRONT) {
-            const long long q = (long long)(args.grp0 + ws_grp(cb)) * 16 + p;
-            const long long qq = q < a.NI ? q : a.NI - 1;
-            xvB = io_ld(a.x, qq, a.x_bf16);
-            x0vB = a.x0 ? io_ld(a.x0, qq, a.x_bf16) : 0.f;
-            dxvB = xvB - x0vB;
-        }
-    };
-    if (nit > 0) new_item_B();
-
     WS_TIMING_DECL;
-    int rAsg = ws_ring0<ws_a_ns(LAYER), WS_TILE>(DB), rDin = ws_ring0<2, WS_TILE>(DB), rDout = ws_ring0<2, WS_TILE>(DB);
-    float tkB = 0.f;
-    if constexpr (IS_TAIL && !FRONT) {
-        const int kB = ws_node(sh, cb);
-        const float uu = ws16_ccs(lds16, kB) + 1.f;
-        tkB = (kB == 0) ? xvB : __fadd_rn(x0vB, __fmul_rn(dxvB, uu) * 0.5f);
+    int rAsg = ws_ring0<w16_a_ns(LAYER), WS_TILE>(DB), rDin = ws_ring0<2, WS_TILE>(DB), rDout = ws_ring0<2, WS_TILE>(DT);
+    f32x4 nds[2][BT];
+    u32x4 sgs[2][BKS];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int t = 0; t < BT; ++t) nds[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < BKS; ++s2) sgs[q][s2] = u32x4{0u, 0u, 0u, 0u};
     }
-    for (int s = 0; s < S; ++s) {
+    float dl[BT][4];
+    unsigned q3[8][W16_NP];
+    float rb0[8], rb1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { rb0[j] = rb1[j] = 0.f; q3[j][0] = q3[j][1] = 0u; }
+#pragma unroll
+    for (int t = 0; t < BT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dl[t][r] = 0.f;
+    auto step = [&](auto parc) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(parc)::value;
+        f32x4 (&nd)[BT] = nds[PAR];
+        const f32x4 (&ndp)[BT] = nds[PAR ^ 1];
+        const u32x4 (&sgp)[BKS] = sgs[PAR ^ 1];
         WS_T(t0);
-        const bool liveB = s >= DB && cb.j < nit;
-        WsCursor nxB = cb;
-        float ccs_n = 0.f;
-        int kBn = 0;
-        if constexpr (IS_TAIL) {
-            if (liveB) nxB = ws_next(sh, cb);
-            kBn = ws_node(sh, nxB);
-            ccs_n = ws16_ccs(lds16, kBn);
-        }
-        const unsigned short* Asg = lds16 + ws_a_off(LAYER) + rAsg + own;                                  // a_l[s - DB]
-        const unsigned short* Din = lds16 + WS_OFF_D + (LAYER + 1 - 2) * 2 * WS_TILE + rDin + own;         // delta_{l+1}[s - DB]
-        unsigned short* const Dout = lds16 + WS_OFF_D + (LAYER >= 2 ? LAYER - 2 : 0) * 2 * WS_TILE + rDout + own;   // delta_l[s - DB]
+        const unsigned short* Asg = lds16 + w16_a_off(LAYER) + rAsg + own;                                 // a_l[s - DB]
+        const unsigned short* Din = lds16 + W16_OFF_D + (LAYER + 1 - 2) * 2 * WS_TILE + rDin + own;        // delta_{l+1}[s - DB]
+        unsigned short* const Dout = lds16 + W16_OFF_D + (LAYER - 2) * 2 * WS_TILE + rDout + own;          // delta_l[s - DT]
         BFrag<W16_NP> bd;
-        u32x4 sg[BKS];
 #pragma unroll
         for (int s2 = 0; s2 < BKS; ++s2)
 #pragma unroll
             for (int k2 = 0; k2 < W16_NP; ++k2) bd.v[s2][k2] = *reinterpret_cast<const u32x4*>(Din + k2 * 16 * TRS + s2 * 8);
 #pragma unroll
-        for (int s2 = 0; s2 < BKS; ++s2) sg[s2] = *reinterpret_cast<const u32x4*>(Asg + s2 * 8);
+        for (int s2 = 0; s2 < BKS; ++s2) sgs[PAR][s2] = *reinterpret_cast<const u32x4*>(Asg + s2 * 8);
         WS_T(t1);
-        // ---- W_l^T GEMM (24 MFMAs, A operands = this wave's registers)
-        f32x4 nd[BT];
+        auto dl_reg = [&](auto ec) __attribute__((always_inline)) {
+            constexpr int e = decltype(ec)::value, t = e / 4, r = e % 4;
+            if constexpr (e < NLIVE) dl[t][r] = ndp[t][r] * act_grad_q(sgp, t, r, slope);
+            else dl[t][r] = 0.f;
+        };
+        auto pair3 = [&](auto jc, auto stc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value, st = decltype(stc)::value, t = j / 2, r = 2 * (j & 1);
+            if constexpr (j < NPAIR) {
+                if constexpr (st == 0) { rb0[j] = dl[t][r]; rb1[j] = dl[t][r + 1]; q3[j][0] = h16_split_stage(rb0[j], rb1[j]); }
+                if constexpr (st == 1) q3[j][1] = h16_split_last(rb0[j], rb1[j]);
+            }
+        };
+        auto store_d3 = [&](auto sc, auto kc) __attribute__((always_inline)) {
+            constexpr int ks = decltype(sc)::value, k2 = decltype(kc)::value;
+            *reinterpret_cast<u32x4*>(Dout + k2 * 16 * TRS + ks * 8) = u32x4{q3[4 * ks][k2], q3[4 * ks + 1][k2], q3[4 * ks + 2][k2], q3[4 * ks + 3][k2]};
+        };
         {
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s2 = 0; s2 < BKS; ++s2) {
-#pragma unroll
-                for (int ba = 0; ba < W16_NP; ++ba)
-#pragma unroll
-                    for (int t = 0; t < BT; ++t) nd[t] = mfma_f16(WT[t][s2][0], bd.v[s2][ba], (s2 == 0 && ba == 0) ? zero : nd[t]);
-#pragma unroll
-                for (int t = 0; t < BT; ++t) nd[t] = mfma_f16(WT[t][s2][1], bd.v[s2][0], nd[t]);
-            }
+            swp_static_for<24>([&](auto nc) {
+                constexpr int nn = decltype(nc)::value;
+                WS_MARK(nn, 24);
+                constexpr int s2 = nn / 12, term = (nn % 12) / 4, t = nn % 4;
+                if constexpr (term < 2) nd[t] = mfma_f16(WT[t][s2][0], bd.v[s2][term], (s2 == 0 && term == 0) ? zero : nd[t]);
+                else nd[t] = mfma_f16(WT[t][s2][1], bd.v[s2][0], nd[t]);
+                // the tail of element s - DT (wave Cb's slot plan): one register per slot, pair j split at slots 2j + 2 / 2j + 3, its K-steps
+                // stored at 10, 11 / 18, 19
+                if constexpr (nn < 16) dl_reg(std::integral_constant<int, nn>{});
+                if constexpr (nn >= 2 && nn < 18 && (nn % 2) == 0) pair3(std::integral_constant<int, (nn - 2) / 2>{}, std::integral_constant<int, 0>{});
+                if constexpr (nn >= 3 && nn < 19 && (nn % 2) == 1) pair3(std::integral_constant<int, (nn - 3) / 2>{}, std::integral_constant<int, 1>{});
+                if constexpr (nn == 10 || nn == 11) store_d3(std::integral_constant<int, 0>{}, std::integral_constant<int, nn - 10>{});
+                if constexpr (nn == 18 || nn == 19) store_d3(std::integral_constant<int, 1>{}, std::integral_constant<int, nn - 18>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
-        WS_MARK_HERE();
-        // ---- delta_l = (W_l^T delta_{l+1}) . act'(a_l); B1: the tail of the node; B2, B3: split and store for the wave below
-        f32x4 dl[BT];
-#pragma unroll
-        for (int t = 0; t < BT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (4 * t + r < NLIVE) {
-                    dl[t][r] = nd[t][r] * act_grad_q(sg, t, r, slope);
-                    if constexpr (IS_TAIL && !FRONT) {
-                        dcs[t][r] += dl[t][r];
-                        dW1x[t][r] = fmaf(dl[t][r], tkB, dW1x[t][r]);
-                    }
-                } else {
-                    dl[t][r] = 0.f;
-                }
-            }
-        if constexpr (!IS_TAIL) {
-            BFrag<W16_NP> q;
-            h16_split_regs<NRL>(dl, q);
-#pragma unroll
-            for (int s2 = 0; s2 < BKS; ++s2)
-#pragma unroll
-                for (int k2 = 0; k2 < W16_NP; ++k2) *reinterpret_cast<u32x4*>(Dout + k2 * 16 * TRS + s2 * 8) = q.v[s2][k2];
-        }
-        if constexpr (IS_TAIL && FRONT) {
-            // middle stage: delta_2 = dL/dz_2 of this node goes back to HBM for the front-backward kernel (not for the tangent
-            // element), un-scaled; a non-finite value (an overflowed cotangent piece) raises the flag
-            if (liveB && !ws_is_tan(sh, cb)) {
-                const int nl2 = NRL > 0 ? NRL : args.nl2;
-                const size_t base = ((size_t)ws_grp(cb) * (size_t)(a.n + 1) + (size_t)ws_node(sh, cb)) * nl2 * 64 + lane;
-                float chk = 0.f;
-#pragma unroll
-                for (int t = 0; t < BT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (4 * t + r < NLIVE && 4 * t + r < nl2) { args.d2[base + (size_t)(4 * t + r) * 64] = dl[t][r] * inv_sigma; chk = fmaf(dl[t][r], 0.f, chk); }
-                bad = bad || !(chk == 0.f);
-            }
-            if (liveB) cb = nxB;
-        }
-        if constexpr (IS_TAIL && !FRONT) {
-            if (liveB && cb.e == sh.ne - 1) {
-                const long long q = (long long)(args.grp0 + ws_grp(cb)) * 16 + p;
-                float chk = 0.f;
-#pragma unroll
-                for (int t = 0; t < BT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) chk = fmaf(dcs[t][r], 0.f, chk);         // (NaN iff some entry is inf / NaN)
-                bad = bad || !(chk == 0.f);
-                if (q < a.NI) {
-#pragma unroll
-                    for (int t = 0; t < BT; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int f = feat_of(t, r, g);
-                            if (f < H1) a.dc[q * H1 + f] = dcs[t][r] * inv_sigma;
-                        }
-                }
-#pragma unroll
-                for (int t = 0; t < BT; ++t) dcs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (liveB) {
-                const bool crossed = nxB.j != cb.j;
-                cb = nxB;
-                if (crossed && cb.j < nit) new_item_B();
-                const float uu = ccs_n + 1.f;
-                tkB = (kBn == 0) ? xvB : __fadd_rn(x0vB, __fmul_rn(dxvB, uu) * 0.5f);
-            }
-        }
-        ws_adv<ws_a_ns(LAYER), WS_TILE>(rAsg); ws_adv<2, WS_TILE>(rDin); ws_adv<2, WS_TILE>(rDout);
+        ws_adv<w16_a_ns(LAYER), WS_TILE>(rAsg); ws_adv<2, WS_TILE>(rDin); ws_adv<2, WS_TILE>(rDout);
         WS_T(t2);
         __syncthreads();
         WS_T(t3);
         WS_TIMING_ACC(t0, t1, t2, t3);
+    };
+    for (int s = 0; s < S; s += 2) {
+        step(std::integral_constant<int, 0>{});
+        if (s + 1 < S) step(std::integral_constant<int, 1>{});
     }
     WS_TIMING_OUT(S);
-    if constexpr (IS_TAIL && FRONT) {
-        if (__any(bad) && lane == 0) atomicOr(&reinterpret_cast<Ws16Scal*>(args.scal)->flag, 1u);
-    }
-    if constexpr (IS_TAIL && !FRONT) {
-#pragma unroll
-        for (int t = 0; t < BT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = dW1x[t][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
-                const int f = feat_of(t, r, g);
-                if (p == 0 && f < H1) part[a.poffW[0] + f * (1 + E)] = v * inv_sigma;
-            }
-        if (__any(bad) && lane == 0) atomicOr(&reinterpret_cast<Ws16Scal*>(args.scal)->flag, 1u);
-    }
 }
 
 // ============================================================================================================ wave B1, software-pipelined (round 6)
 // B1 is the LAST role of the pipeline: nothing downstream waits for its result, so its vector tail -- act'(a_1), the dc sums, dW_1[:, 0]:
 // 65 instructions per step that ran un-shadowed behind the 24 matrix instructions of its GEMM -- can lag the GEMM by one step at no cost
-// in rings or latency.  Step s: W_1^T GEMM of element s - 10 into one of two alternating accumulator sets, with the tail of element
-// s - 11 (the OTHER set, and the a_1 signs fetched a step ago) as fillers behind its matrix instructions.  Timing-only ablations had
+// in rings or latency.  Step s: W_1^T GEMM of element s - 12 into one of two alternating accumulator sets, with the tail of element
+// s - 13 (the OTHER set, and the a_1 signs fetched a step ago) as fillers behind its matrix instructions.  Timing-only ablations had
 // put B1 (with F3) on the critical path: its two accumulations alone were 2.9 % of the kernel (EXPERIMENTS.md).  Same arithmetic, same
 // summation order per integral: results are bit-identical to the un-pipelined role.
 // FRONT (middle stage of the three-stage backward): the tail is act'(a_2) and the un-scaling of delta_2 as fillers; its 13 stores to HBM
@@ -1103,7 +1048,7 @@ __device__ __forceinline__ void ws16_role_B(const BwdBf16Args& args, unsigned sh
 template <int NRL, bool FRONT>
 __device__ __forceinline__ void ws16_role_B1p(const BwdBf16Args& args, unsigned short* lds16, int S, const WsShape sh, float* part) {
     constexpr int NLIVE = NRL > 0 ? NRL : 4 * BT;
-    constexpr int LAYER = 1, DB = 11 - LAYER, DT = DB + 1;        // GEMM on element s - DB, tail on element s - DT
+    constexpr int LAYER = 1, DB = 12, DT = DB + 1;                // GEMM on element s - DB, tail on element s - DT
     const BwdArgs& a = args.b;
     const MlpDev& m = a.m;
     const int lane = threadIdx.x & 63, g = lane >> 4, p = lane & 15;
@@ -1142,7 +1087,7 @@ __device__ __forceinline__ void ws16_role_B1p(const BwdBf16Args& args, unsigned 
     if (nit > 0) new_item_B();
 
     WS_TIMING_DECL;
-    int rAsg = ws_ring0<ws_a_ns(LAYER), WS_TILE>(DB), rDin = ws_ring0<2, WS_TILE>(DB);
+    int rAsg = ws_ring0<w16_a_ns(LAYER), WS_TILE>(DB), rDin = ws_ring0<2, WS_TILE>(DB);
     float tkB = 0.f;
     float d2v[BT][4];                                   // (FRONT) delta_2 of the tail's element, un-scaled, on its way to HBM
 #pragma unroll
@@ -1177,8 +1122,8 @@ __device__ __forceinline__ void ws16_role_B1p(const BwdBf16Args& args, unsigned 
         const int kBn = ws_node(sh, nxB);
         float ccs_n = 0.f;
         if constexpr (!FRONT) ccs_n = ws16_ccs(lds16, kBn);
-        const unsigned short* Asg = lds16 + ws_a_off(LAYER) + rAsg + own;                                  // a_1[s - DB]
-        const unsigned short* Din = lds16 + WS_OFF_D + (LAYER + 1 - 2) * 2 * WS_TILE + rDin + own;         // delta_2[s - DB]
+        const unsigned short* Asg = lds16 + w16_a_off(LAYER) + rAsg + own;                                  // a_1[s - DB]
+        const unsigned short* Din = lds16 + W16_OFF_D + (LAYER + 1 - 2) * 2 * WS_TILE + rDin + own;         // delta_2[s - DB]
         BFrag<W16_NP> bd;
 #pragma unroll
         for (int s2 = 0; s2 < BKS; ++s2)
@@ -1260,7 +1205,7 @@ __device__ __forceinline__ void ws16_role_B1p(const BwdBf16Args& args, unsigned 
             tkB = (kBn == 0) ? xvB : __fadd_rn(x0vB, __fmul_rn(dxvB, uu) * 0.5f);
         }
         }
-        ws_adv<ws_a_ns(LAYER), WS_TILE>(rAsg); ws_adv<2, WS_TILE>(rDin);
+        ws_adv<w16_a_ns(LAYER), WS_TILE>(rAsg); ws_adv<2, WS_TILE>(rDin);
         WS_T(t2);
         __syncthreads();
         WS_T(t3);
@@ -1316,7 +1261,7 @@ __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws16_kernel(const Bwd
     sh.tan0 = a.gfx != nullptr ? 1 : 0;
     sh.ne = a.n + 1 + sh.tan0;
     sh.nit = blockIdx.x < a.ngroups ? (int)((a.ngroups - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
-    const int S = sh.nit * sh.ne + WS_DEPTH;
+    const int S = sh.nit * sh.ne + W16_DEPTH;
     // one d_theta slice per workgroup (as the middle stage of the three-stage backward: the first of the workgroup's four -- the
     // front kernels use all four; single-chunk launches only, so every slice entry is written, never accumulated)
     float* part = a.partials + (size_t)blockIdx.x * (FRONT ? UMNN_WAVES_PER_BLOCK : 1) * a.n_params;
@@ -1328,7 +1273,7 @@ __global__ __launch_bounds__(64 * WS_WAVES, 1) void cc_bwd_ws16_kernel(const Bwd
     } else {
         if (role == 0) ws16_role_Cb<NRL>(args, lds16, S, sh, part);
         else if (role == 1) ws16_role_B1p<NRL, FRONT>(args, lds16, S, sh, part);
-        else if (role == 2) ws16_role_B<NRL, 2, FRONT>(args, lds16, S, sh, part);
-        else ws16_role_B<NRL, 3, FRONT>(args, lds16, S, sh, part);
+        else if (role == 2) ws16_role_Bp<NRL, 2>(args, lds16, S);
+        else ws16_role_Bp<NRL, 3>(args, lds16, S);
     }
 }
